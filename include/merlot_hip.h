@@ -1,0 +1,199 @@
+/* libmerlot_hip.so -- C-ABI of the MI355X-native MERLOT pretraining hot path.
+ *
+ * The reference (rowanz/merlot) is pure Python on TF-1.15/XLA: it has NO FFI / plugin registry.
+ * Its seam is the Python surface `MerlotModel` + `merlot.yaml` (model/modeling.py:47-668), which
+ * merlot_amd/modeling.py mirrors; this header is the boundary BELOW that surface.  Every entry
+ * point cites the reference code whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers, explicit dims / leading dimensions (in ELEMENTS), a hipStream_t
+ *     passed as void*.  No torch types.  The caller owns every buffer (including workspaces); the
+ *     library never allocates, never synchronises, keeps no global state => re-entrant per stream.
+ *   - returns MERLOT_OK (0) or a negative MERLOT_E* code; merlot_last_error() gives a thread-local
+ *     message for the last failure.
+ *   - "bf16" buffers are uint16 bit patterns of bfloat16; "f32" are IEEE float.
+ *   - activations are row-major [rows, features]; Linear weights are held [out, in] ("Wt").
+ */
+#ifndef MERLOT_HIP_H
+#define MERLOT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MERLOT_OK 0
+#define MERLOT_ESHAPE (-1)
+#define MERLOT_EDTYPE (-2)
+#define MERLOT_EALIGN (-3)
+#define MERLOT_ELAUNCH (-4)
+
+typedef void* merlot_stream_t;
+
+const char* merlot_last_error(void);
+int merlot_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dense contractions (MFMA).  Replaces tf.layers.dense / tf.matmul at utils/transformer.py:21-25,
+ * 67-82,98,120,130-135,149-161 and their tf.gradients backward (utils/optimization.py:176).
+ * ---------------------------------------------------------------------------------------------- */
+enum merlot_epilogue {
+    MERLOT_EPI_NONE = 0,          /* C = alpha*acc (+bias)                                         */
+    MERLOT_EPI_GELU = 1,          /* u = alpha*acc+bias ; aux_out = u (optional) ; C = gelu(u)     */
+    MERLOT_EPI_RESIDUAL = 2,      /* C = aux_in + dropout(alpha*acc+bias)                          */
+    MERLOT_EPI_DGELU = 3          /* C = (alpha*acc) * gelu'(aux_in)                               */
+};
+
+/* C[M,N] = epilogue(alpha * A[M,K] . Bt[N,K]^T).  A, Bt bf16, K-contiguous; K % 64 == 0;
+ * lda, ldb % 8 == 0.  C is bf16 (out_f32=0) or f32 (out_f32=1; accumulate=1 adds into C).
+ * bias: f32 [N] or NULL.  aux_in / aux_out: bf16 [M, ld*] (see enum).  dropout_p in [0,1):
+ * keep-mask is a counter-based hash of (dropout_seed, m*N+n), survivors scaled 1/(1-p)
+ * (utils/model_utils.py:335-349). */
+int merlot_gemm_bf16_nt(const void* A, int64_t lda, const void* Bt, int64_t ldb, void* C, int64_t ldc,
+                        int64_t M, int64_t N, int64_t K, float alpha, int epilogue, int out_f32, int accumulate,
+                        const float* bias, const void* aux_in, int64_t ld_aux_in, void* aux_out,
+                        int64_t ld_aux_out, float dropout_p, uint64_t dropout_seed, merlot_stream_t stream);
+
+/* Weight gradient: C[M,N] (f32) (+)= alpha * sum_r A[r,M] * B[r,N].  A, B bf16 row-major with the
+ * reduction index r as the SLOW dim (activations / output grads as stored).  M, N even. */
+int merlot_gemm_bf16_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
+                        int64_t M, int64_t N, int64_t R, float alpha, int accumulate, merlot_stream_t stream);
+
+/* Patch-embed 16x16/16 conv as an implicit-im2col GEMM (utils/vision_transformer.py:193-205).
+ * image: bf16 NHWC [n_img, H, W, 3] in [0,1]; Wt: bf16 [hidden, P*P*3] with k=(py,px,c);
+ * bias_folded: f32 [hidden] = conv bias - 0.5*sum_k W (the `image - 0.5`, :193, folded);
+ * out: bf16 [n_img*(H/P)*(W/P), hidden]. */
+int merlot_patch_embed_fwd(const void* image, int n_img, int H, int W, int P, const void* Wt, const float* bias_folded,
+                           void* out, int hidden, merlot_stream_t stream);
+/* dWt[hidden, P*P*3] (f32) (+)= sum_rows dY[row, hidden] * patch[row, k]  (raw pixel values; the caller
+ * subtracts 0.5 * colsum(dY)[hidden] for the `image - 0.5` shift).  dY bf16. */
+int merlot_patch_embed_wgrad(const void* image, int n_img, int H, int W, int P, const void* dY, float* dWt,
+                             int hidden, int accumulate, merlot_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm (utils/model_utils.py:113-130): fp32 statistics, population variance, eps inside rsqrt.
+ * ---------------------------------------------------------------------------------------------- */
+/* y = LN(x) ; x is bf16 (x_f32=0) or f32 ; y_bf16 and/or y_f32 may be NULL ; mean/rstd f32 [rows]
+ * (may be NULL when no backward is needed).  H % 256 == 0, H <= 2048. */
+int merlot_ln_fwd(const void* x, int x_f32, const float* gamma, const float* beta, void* y_bf16, float* y_f32,
+                  float* mean, float* rstd, int64_t rows, int H, float eps, merlot_stream_t stream);
+/* dx = LN'(dy) (+ dres) ; dgamma/dbeta (f32 [H]) are ACCUMULATED with atomics.  dy, x, dres, dx each bf16
+ * or f32 per flag; dres may be NULL. */
+int merlot_ln_bwd(const void* dy, int dy_f32, const void* x, int x_f32, const float* mean, const float* rstd,
+                  const float* gamma, const void* dres, int dres_f32, void* dx, int dx_f32, float* dgamma,
+                  float* dbeta, int64_t rows, int H, merlot_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused scaled-dot-product attention (utils/transformer.py:98-127), head_dim = 64.
+ * qkv: bf16 [B*S, ld] rows = tokens; within a row q | k | v each `heads*64` wide, head h at h*64.
+ * valid: uint8 [B,S] or NULL (=all valid).  mask(b,i,j) = valid[b,i] & valid[b,j]; a masked score is
+ * exactly -1e10 (NOT -inf): a padded query row attends uniformly over all S keys (:109-112).
+ * ---------------------------------------------------------------------------------------------- */
+int merlot_attention_fwd(const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse, const uint8_t* valid,
+                         int B, int S, int heads, float scale, merlot_stream_t stream);
+/* dqkv (bf16, same layout as qkv) from dout.  delta: f32 workspace [B*heads*S]. */
+int merlot_attention_bwd(const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout, int64_t lddo,
+                         const float* lse, const uint8_t* valid, void* dqkv, int64_t lddqkv, float* delta, int B,
+                         int S, int heads, float scale, merlot_stream_t stream);
+/* Side outputs the reference takes from its stacked [B,layers,S,S] head-mean probabilities, without
+ * materialising SxS:  colsum_lo[b,key] += weight * sum_h sum_{q <  qsplit} P[b,h,q,key]
+ *                     colsum_hi[b,key] += weight * sum_h sum_{q >= qsplit} P[b,h,q,key]
+ * valid_q_only=0: every query row counts (padded rows attend uniformly) -- the attention_summs that feed
+ *   masking, model/modeling.py:428-431 (use qsplit = S, colsum_hi = NULL);
+ * valid_q_only=1: only (valid query, valid key) pairs count -- the four viz/lang block sums of the
+ *   attention log, model/modeling.py:186-203 (qsplit = P, the host sums key ranges). */
+int merlot_attention_colsum(const void* qkv, int64_t ld, const float* lse, const uint8_t* valid, float* colsum_lo,
+                            float* colsum_hi, int qsplit, int valid_q_only, float weight, int B, int S, int heads,
+                            float scale, merlot_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Element-wise / gather / reduction helpers.
+ * ---------------------------------------------------------------------------------------------- */
+int merlot_cast_f32_bf16(const float* src, void* dst, int64_t n, merlot_stream_t stream);
+/* dst[C, ld_dst] (bf16) : dst[c, r] = src[r, c] for the f32 matrix src[R,C]; ld_dst >= R */
+int merlot_cast_transpose_f32_bf16(const float* src, void* dst, int64_t R, int64_t C, int64_t ld_dst,
+                                   merlot_stream_t stream);
+/* out[N] (+)= sum_t x[t, n]   (bias gradients) ; x bf16 */
+int merlot_colsum_bf16(const void* x, int64_t ld, float* out, int64_t T, int64_t N, int accumulate,
+                       merlot_stream_t stream);
+/* out[r,:] = a[ia[r],:] + b[ib[r],:] + c[ic[r],:] + d[id[r],:]  (f32 tables H wide; a NULL table or an
+ * index < 0 contributes 0; a NULL index array means identity).  `a` may be bf16 (a_bf16=1).  The embedding sums
+ * at model/modeling.py:262-297 (word + position), :299-337 (pooled grid + img_idx_pe + final_pe) and
+ * utils/vision_transformer.py:231-233 (patches + cls/pos embeddings), as gathers -- never one-hot matmuls. */
+int merlot_gather_add4(const void* a, int a_bf16, const int32_t* ia, const float* b, const int32_t* ib,
+                       const float* c, const int32_t* ic, const float* d, const int32_t* id, float* out, int64_t rows,
+                       int H, merlot_stream_t stream);
+/* y = dropout(x) on bf16 [rows, N] with the same counter-based keep mask (seed, r*N+n) as the GEMM
+ * MERLOT_EPI_RESIDUAL epilogue; used for the backward of that epilogue and for the embedding dropout
+ * (utils/model_utils.py:335-349, model/modeling.py:294). */
+int merlot_dropout_apply(const void* x, void* y, int64_t rows, int64_t N, float p, uint64_t seed,
+                         merlot_stream_t stream);
+/* table[idx[r],:] += src[r,:]  (f32, atomics) ; idx<0 skipped.  Backward of the gathers. */
+int merlot_scatter_add_rows(const float* src, const int32_t* idx, float* table, int64_t rows, int H,
+                            merlot_stream_t stream);
+/* 2x2 VALID average pool of a [n_img, h1, w1, H] bf16 grid taken from rows [n, cls_skip + h*w1 + w] of
+ * x[n_img, S, H]; writes f32 [n_img, 1 + h2*w2, H] with row 0 = x[n,0,:] (the CLS slot)
+ * (utils/vision_transformer.py:251-267 + model/modeling.py:101-105). */
+int merlot_cls_avgpool_fwd(const void* x, float* out, int n_img, int h1, int w1, int cls_skip, int pool, int H,
+                           merlot_stream_t stream);
+int merlot_cls_avgpool_bwd(const float* dout, void* dx, int n_img, int h1, int w1, int cls_skip, int pool, int H,
+                           merlot_stream_t stream);
+
+/* Row softmax cross-entropy (utils/model_utils.py:313-332): logits f32 [rows, ld] (first C columns
+ * used), labels int32.  loss[r] = -log_softmax(logits[r])[label[r]] ; argmax[r] (first max).
+ * If dlogits != NULL: dlogits[r, :C] = rowscale[r] * (softmax - onehot) written as bf16 (dl_bf16=1,
+ * leading dim ld_dl, columns C..ld_dl zero-filled) or f32. */
+int merlot_softmax_ce(const float* logits, int64_t ld, const int32_t* labels, float* loss, int32_t* argmax,
+                      const float* rowscale, void* dlogits, int dl_bf16, int64_t ld_dl, int64_t rows, int C,
+                      merlot_stream_t stream);
+
+/* x * rsqrt(max(sum x^2, 1e-12))  (tf.math.l2_normalize, model/modeling.py:43) ; f32 [rows, H] */
+int merlot_l2norm_fwd(const float* x, float* y, float* inv_norm, int64_t rows, int H, merlot_stream_t stream);
+int merlot_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, float* dx, int64_t rows, int H,
+                      merlot_stream_t stream);
+/* exact erf GELU on f32 buffers (heads) */
+int merlot_gelu_fwd(const float* x, float* y, int64_t n, merlot_stream_t stream);
+int merlot_gelu_bwd(const float* dy, const float* x, float* dx, int64_t n, merlot_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Integer / index work (bit-exact given the explicit noise inputs).
+ * ---------------------------------------------------------------------------------------------- */
+/* model/modeling.py:381-489 + utils/model_utils.py:640-649.  One workgroup per group row.
+ * ids [B,L] int32; attention_summs f32 [B,L] (NULL => masking_use_attn False); gumbel f32 [B,L];
+ * span_lower/upper int32 [B,nm] (NULL => no spanbert); random_ids, option int32 [B,L];
+ * log_nontopk/log_topk = float32 log() of the two mask weights, w_nontopk/w_topk the weights,
+ * max_weight = reduce_max(mask_weight) over the whole batch (modeling.py:468; known on the host).
+ * outputs masked_ids [B,L], masked_idx [B,nm] (ascending).  L <= 1024. */
+int merlot_mask_inputs(const int32_t* ids, const float* attention_summs, const float* gumbel,
+                       const int32_t* span_lower, const int32_t* span_upper, const int32_t* random_ids,
+                       const int32_t* option, int32_t* masked_ids, int32_t* masked_idx, int B, int L, int num_topk,
+                       int num_to_mask, float w_nontopk, float w_topk, float log_nontopk, float log_topk,
+                       float max_weight, int mask_token, merlot_stream_t stream);
+/* model/modeling.py:598-620, 635, 649-652: labels int32 [B*n*n], weights f32 [B*n*n]. */
+int merlot_temporal_labels(const int32_t* video_src_ids, const int32_t* shuffled_idx, int32_t* labels,
+                           float* weights, int B, int n, merlot_stream_t stream);
+/* model/dataloader.py:224-257: shuffled_idx [B*n] from explicit draws. */
+int merlot_shuffled_idx(const int32_t* num_shuffle, const float* u_select, const float* u_perm, int32_t* out, int B,
+                        int n, int shuffle_offset, merlot_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * AdamW with bias correction and bf16 m / sign-encoded bf16 v (utils/optimization.py:267-288,339-416).
+ * param/grad f32 [n]; m, v bf16 bit patterns (state_bf16=1) or f32.  lr already includes the schedule
+ * scale and sqrt(bc2)/bc1.  grad_scale multiplies the gradient first (1/world for mean reduce).
+ * ---------------------------------------------------------------------------------------------- */
+int merlot_adamw_step(float* param, const float* grad, void* m, void* v, int64_t n, float lr, float beta1,
+                      float beta2, float eps, float weight_decay, float grad_scale, int state_bf16,
+                      merlot_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Hardware-layout probes (diagnostics; used by tests to pin the MFMA / LDS-transpose lane maps the
+ * kernels above assume).  out_* are small device buffers, see csrc/probe.hip.
+ * ---------------------------------------------------------------------------------------------- */
+int merlot_probe_mfma32(const void* a, const void* b, float* d, merlot_stream_t stream);
+int merlot_probe_tr16(const void* tile, void* out, merlot_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MERLOT_HIP_H */

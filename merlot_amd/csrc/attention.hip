@@ -1,0 +1,604 @@
+// Fused scaled-dot-product attention for gfx950, head_dim 64 (utils/transformer.py:98-127).
+//
+// Layout idea: every MFMA is issued "transposed" so that one lane owns one QUERY row of the score tile
+// (S^T = K Q^T, 32x32x16 bf16 MFMA: lane = query column, 16 regs = 16 keys, partner lane+32 = other 16).
+// The online softmax is then lane-local (one cross-lane exchange with lane^32 per tile), P converts to
+// bf16 in registers and is fed straight back as the B operand of O^T = V^T P^T.  The V^T (and, in the
+// backward, K^T / Q^T / dO^T) operand is produced from the row-major LDS tile by the gfx950 LDS
+// transpose read `ds_read_b64_tr_b16` (4 rows x 16 columns per 16-lane group).
+//
+// LDS tile image ("H2"): R rows x 64 bf16 kept as two 32-column halves [2][R][64 B]; inside a half-row
+// the four 16-B chunks are XOR-swizzled with (row>>2)&3.  Row stride 64 B puts the 4 rows of one
+// transpose read in 4 disjoint bank quarters, and the swizzle makes the 16 rows of a ds_read_b128
+// lane group hit 16 distinct slots.
+//
+// Masking semantics of the reference are kept: mask(b,i,j) = valid[b,i] & valid[b,j]; a masked score is the
+// finite constant -1e10, so a padded QUERY row (every pair masked) attends uniformly over all S keys.  For such
+// rows the kernels use the score 0 for every key instead of -1e10: the softmax is the same uniform 1/S, but the
+// saved log-sum-exp is log(S) -- representable -- whereas -1e10 + log(S) rounds to -1e10 in fp32 and would make
+// the recomputed probabilities of the backward / column-sum kernels 1 instead of 1/S.
+#include "common.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+constexpr float MASKED_T = -1.0e10f * LOG2E;  // -1e10 in log2 units
+
+struct AttnArgs {
+    const bf16* qkv;
+    int64_t ld;
+    bf16* out;
+    int64_t ldo;
+    const bf16* dout;
+    int64_t lddo;
+    float* lse;          // [B, heads, S] natural log
+    const float* delta;  // [B, heads, S]
+    const uint8_t* valid;
+    bf16* dqkv;
+    int64_t lddqkv;
+    int B, S, heads;
+    float scale;
+    // side outputs
+    float* colsum_lo;
+    float* colsum_hi;
+    int qsplit;
+    int valid_q_only;
+    float weight;
+};
+
+__device__ __forceinline__ int h2_off(int R, int row, int chunk) {
+    return (chunk >> 2) * R * 64 + row * 64 + ((((chunk & 3) ^ (row >> 2)) & 3) << 4);
+}
+
+// cooperative copy of a [rows<=R][64] bf16 tile (global row stride ld) into an H2 LDS image.
+// 256 threads; R*8 16-B chunks.  Rows beyond `nrows_valid` are clamped to the last valid row.
+template <int R>
+__device__ __forceinline__ void tile_load_regs(const bf16* g, int64_t ld, int row0, int row_max, u32x4 (&regs)[R / 32],
+                                               int tid) {
+#pragma unroll
+    for (int it = 0; it < R / 32; ++it) {
+        const int idx = it * 256 + tid;
+        const int half = idx / (R * 4);
+        const int rem = idx - half * (R * 4);
+        const int row = rem >> 2;
+        const int chunk = half * 4 + (rem & 3);
+        const int gr = min(row0 + row, row_max);
+        regs[it] = *reinterpret_cast<const u32x4*>(g + (int64_t)gr * ld + chunk * 8);
+    }
+}
+template <int R>
+__device__ __forceinline__ void tile_store_lds(char* lds, const u32x4 (&regs)[R / 32], int tid) {
+#pragma unroll
+    for (int it = 0; it < R / 32; ++it) {
+        const int idx = it * 256 + tid;
+        const int half = idx / (R * 4);
+        const int rem = idx - half * (R * 4);
+        const int row = rem >> 2;
+        const int chunk = half * 4 + (rem & 3);
+        *reinterpret_cast<u32x4*>(lds + h2_off(R, row, chunk)) = regs[it];
+    }
+}
+
+// transpose-read fragment: returns X^T fragment for a 32x32x16 MFMA operand whose MFMA-row/col index is
+// the tile COLUMN (d) and whose 8 k-slots are tile ROWS  rb + {0..3} (slots 0-3) and rb + 8 + {0..3} (4-7),
+// with rb already including the lane's 4*hi offset.  Column = d0 + (lane & 31).
+template <int R>
+__device__ __forceinline__ bf16x8 tr_frag(const char* lds, int rb, int d0, int lane) {
+    const int i = lane & 15;
+    const int col = d0 + ((lane >> 4) & 1) * 16 + 4 * (i & 3);
+    const int row = rb + (i >> 2);
+    const int o0 = h2_off(R, row, col >> 3) + (i & 1) * 8;
+    const int o1 = h2_off(R, row + 8, col >> 3) + (i & 1) * 8;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+        (__attribute__((address_space(3))) bf16x4*)(lds + o0));
+    const bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+        (__attribute__((address_space(3))) bf16x4*)(lds + o1));
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        r[e] = lo[e];
+        r[4 + e] = hi4[e];
+    }
+    return r;
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    return z;
+}
+
+// row index inside a 32x32 accumulator for register r of a lane with half-index hi
+__device__ __forceinline__ constexpr int acc_row(int r) { return (r & 3) + 8 * (r >> 2); }
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
+    __shared__ __attribute__((aligned(1024))) char smem[2 * 8192];
+    char* ldsK = smem;
+    char* ldsV = smem + 8192;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int S = p.S;
+    const int qw0 = blockIdx.x * 128 + wave * 32;  // first query row of this wave
+    const bool wave_active = qw0 < S;
+    const bf16* base = p.qkv + (int64_t)b * S * p.ld + h * 64;
+    const bf16* kbase = base + p.heads * 64;
+    const bf16* vbase = base + 2 * p.heads * 64;
+    const uint8_t* vrow = p.valid ? p.valid + (int64_t)b * S : nullptr;
+
+    const int q = min(qw0 + (lane & 31), S - 1);
+    const bool qv = vrow ? (vrow[q] != 0) : true;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+        qf[kk] = *reinterpret_cast<const bf16x8*>(base + (int64_t)q * p.ld + kk * 16 + hi * 8);
+
+    f32x16 o[2] = {zero16(), zero16()};
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sc = p.scale * LOG2E;
+
+    const int nkt = (S + 63) / 64;
+    u32x4 kreg[2], vreg[2];
+    tile_load_regs<64>(kbase, p.ld, 0, S - 1, kreg, tid);
+    tile_load_regs<64>(vbase, p.ld, 0, S - 1, vreg, tid);
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();
+        tile_store_lds<64>(ldsK, kreg, tid);
+        tile_store_lds<64>(ldsV, vreg, tid);
+        __syncthreads();
+        if (kt + 1 < nkt) {
+            tile_load_regs<64>(kbase, p.ld, (kt + 1) * 64, S - 1, kreg, tid);
+            tile_load_regs<64>(vbase, p.ld, (kt + 1) * 64, S - 1, vreg, tid);
+        }
+        if (!wave_active) continue;
+
+        // key validity / range masks for this tile (bit = key index inside the tile)
+        const int kidx = kt * 64 + lane;
+        const bool in_range = kidx < S;
+        const bool kval = in_range && (vrow ? vrow[min(kidx, S - 1)] != 0 : true);
+        const uint64_t rmask = __ballot(in_range) >> (4 * hi);
+        const uint64_t vmask = __ballot(kval) >> (4 * hi);
+
+        f32x16 st[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            st[kb] = zero16();
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ldsK + h2_off(64, kb * 32 + (lane & 31), 2 * kk + hi));
+                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], st[kb], 0, 0, 0);
+            }
+        }
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int bit = kb * 32 + acc_row(r);
+                float t = st[kb][r] * sc;
+                t = ((vmask >> bit) & 1) ? t : MASKED_T;
+                t = qv ? t : 0.f;                       // padded query row: uniform over all keys (see header note)
+                t = ((rmask >> bit) & 1) ? t : -INFINITY;
+                st[kb][r] = t;
+                mloc = fmaxf(mloc, t);
+            }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = exp2f(m_run - m_new);
+        float lsum = 0.f;
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = exp2f(st[kb][r] - m_new);
+                lsum += pv;
+                pf[kb][r >> 3][r & 7] = (bf16)pv;
+            }
+        lsum += __shfl_xor(lsum, 32, 64);
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const bf16x8 vf = tr_frag<64>(ldsV, kb * 32 + hf * 16 + 4 * hi, db * 32, lane);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][hf], o[db], 0, 0, 0);
+                }
+        }
+    }
+
+    if (wave_active && qw0 + (lane & 31) < S) {
+        const float inv = 1.0f / l_run;
+        bf16* orow = p.out + ((int64_t)b * S + q) * p.ldo + h * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 v4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v4[e] = (bf16)(o[db][4 * g + e] * inv);
+                *reinterpret_cast<bf16x4*>(orow + db * 32 + 8 * g + 4 * hi) = v4;
+            }
+        if (hi == 0 && p.lse) p.lse[((int64_t)b * p.heads + h) * S + q] = m_run * LN2 + logf(l_run);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward preprocess: delta[b,h,s] = sum_d dO * O
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs p, float* delta) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nrows = (int64_t)p.B * p.S;
+    if (row >= nrows) return;
+    const int b = (int)(row / p.S), s = (int)(row - (int64_t)b * p.S);
+    // each lane handles 8 contiguous features, 8 lanes per head, 64 lanes = 8 heads per pass
+    for (int h0 = 0; h0 < p.heads; h0 += 8) {
+        const int h = h0 + (lane >> 3);
+        float acc = 0.f;
+        if (h < p.heads) {
+            const int col = h * 64 + (lane & 7) * 8;
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(p.out + row * p.ldo + col);
+            const bf16x8 d = *reinterpret_cast<const bf16x8*>(p.dout + row * p.lddo + col);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += (float)a[e] * (float)d[e];
+        }
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 4, 64);
+        if (h < p.heads && (lane & 7) == 0) delta[((int64_t)b * p.heads + h) * p.S + s] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward dQ: one wave per 32 query rows, loop over key tiles (same lane<->query layout as forward)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
+    __shared__ __attribute__((aligned(1024))) char smem[2 * 8192];
+    char* ldsK = smem;
+    char* ldsV = smem + 8192;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int S = p.S;
+    const int qw0 = blockIdx.x * 128 + wave * 32;
+    const bool wave_active = qw0 < S;
+    const bf16* base = p.qkv + (int64_t)b * S * p.ld + h * 64;
+    const bf16* kbase = base + p.heads * 64;
+    const bf16* vbase = base + 2 * p.heads * 64;
+    const uint8_t* vrow = p.valid ? p.valid + (int64_t)b * S : nullptr;
+
+    const int q = min(qw0 + (lane & 31), S - 1);
+    const bool qv = vrow ? (vrow[q] != 0) : true;
+    bf16x8 qf[4], dof[4];
+    const bf16* dorow = p.dout + ((int64_t)b * S + q) * p.lddo + h * 64;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        qf[kk] = *reinterpret_cast<const bf16x8*>(base + (int64_t)q * p.ld + kk * 16 + hi * 8);
+        dof[kk] = *reinterpret_cast<const bf16x8*>(dorow + kk * 16 + hi * 8);
+    }
+    const int64_t stat = ((int64_t)b * p.heads + h) * S + q;
+    const float lse2 = p.lse[stat] * LOG2E;
+    const float dl = p.delta[stat];
+    const float sc = p.scale * LOG2E;
+
+    f32x16 dq[2] = {zero16(), zero16()};
+    const int nkt = (S + 63) / 64;
+    u32x4 kreg[2], vreg[2];
+    tile_load_regs<64>(kbase, p.ld, 0, S - 1, kreg, tid);
+    tile_load_regs<64>(vbase, p.ld, 0, S - 1, vreg, tid);
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();
+        tile_store_lds<64>(ldsK, kreg, tid);
+        tile_store_lds<64>(ldsV, vreg, tid);
+        __syncthreads();
+        if (kt + 1 < nkt) {
+            tile_load_regs<64>(kbase, p.ld, (kt + 1) * 64, S - 1, kreg, tid);
+            tile_load_regs<64>(vbase, p.ld, (kt + 1) * 64, S - 1, vreg, tid);
+        }
+        if (!wave_active) continue;
+        const int kidx = kt * 64 + lane;
+        const bool in_range = kidx < S;
+        const bool kval = in_range && (vrow ? vrow[min(kidx, S - 1)] != 0 : true);
+        const uint64_t rmask = __ballot(in_range) >> (4 * hi);
+        const uint64_t vmask = __ballot(kval) >> (4 * hi);
+
+        bf16x8 dsf[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16 st = zero16(), dp = zero16();
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int off = h2_off(64, kb * 32 + (lane & 31), 2 * kk + hi);
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ldsK + off);
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(ldsV + off);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], st, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[kk], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int bit = kb * 32 + acc_row(r);
+                const bool live = qv && ((vmask >> bit) & 1);
+                float t = ((vmask >> bit) & 1) ? st[r] * sc : MASKED_T;
+                t = qv ? t : 0.f;
+                t = ((rmask >> bit) & 1) ? t : -INFINITY;
+                const float pv = exp2f(t - lse2);
+                const float ds = live ? pv * (dp[r] - dl) * p.scale : 0.f;
+                dsf[kb][r >> 3][r & 7] = (bf16)ds;
+            }
+        }
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const bf16x8 ktf = tr_frag<64>(ldsK, kb * 32 + hf * 16 + 4 * hi, db * 32, lane);
+                    dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf[kb][hf], dq[db], 0, 0, 0);
+                }
+    }
+    if (wave_active && qw0 + (lane & 31) < S) {
+        bf16* drow = p.dqkv + ((int64_t)b * S + q) * p.lddqkv + h * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 v4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v4[e] = (bf16)dq[db][4 * g + e];
+                *reinterpret_cast<bf16x4*>(drow + db * 32 + 8 * g + 4 * hi) = v4;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward dK/dV: one wave per 32 keys, loop over 64-row query tiles (lane <-> key layout)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnArgs p) {
+    // Q tile 8 KB | dO tile 8 KB | lse2[64] | delta[64] | qvalid mask (2 dwords) + qrange mask (2 dwords)
+    __shared__ __attribute__((aligned(1024))) char smem[2 * 8192 + 64 * 4 * 2 + 32];
+    char* ldsQ = smem;
+    char* ldsO = smem + 8192;
+    float* lds_lse = reinterpret_cast<float*>(smem + 16384);
+    float* lds_dl = lds_lse + 64;
+    uint64_t* lds_mask = reinterpret_cast<uint64_t*>(smem + 16384 + 512);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int S = p.S;
+    const int kw0 = blockIdx.x * 128 + wave * 32;
+    const bool wave_active = kw0 < S;
+    const bf16* base = p.qkv + (int64_t)b * S * p.ld + h * 64;
+    const bf16* kbase = base + p.heads * 64;
+    const bf16* vbase = base + 2 * p.heads * 64;
+    const bf16* dobase = p.dout + (int64_t)b * S * p.lddo + h * 64;
+    const uint8_t* vrow = p.valid ? p.valid + (int64_t)b * S : nullptr;
+    const float* lse_b = p.lse + ((int64_t)b * p.heads + h) * S;
+    const float* dl_b = p.delta + ((int64_t)b * p.heads + h) * S;
+
+    const int key = min(kw0 + (lane & 31), S - 1);
+    const bool key_in = kw0 + (lane & 31) < S;
+    const bool kv = key_in && (vrow ? vrow[key] != 0 : true);
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        kf[kk] = *reinterpret_cast<const bf16x8*>(kbase + (int64_t)key * p.ld + kk * 16 + hi * 8);
+        vf[kk] = *reinterpret_cast<const bf16x8*>(vbase + (int64_t)key * p.ld + kk * 16 + hi * 8);
+    }
+    const float sc = p.scale * LOG2E;
+    f32x16 dk[2] = {zero16(), zero16()};
+    f32x16 dv[2] = {zero16(), zero16()};
+
+    const int nqt = (S + 63) / 64;
+    u32x4 qreg[2], oreg[2];
+    tile_load_regs<64>(base, p.ld, 0, S - 1, qreg, tid);
+    tile_load_regs<64>(dobase, p.lddo, 0, S - 1, oreg, tid);
+    for (int qt = 0; qt < nqt; ++qt) {
+        __syncthreads();
+        tile_store_lds<64>(ldsQ, qreg, tid);
+        tile_store_lds<64>(ldsO, oreg, tid);
+        if (tid < 64) {
+            const int qi = qt * 64 + tid;
+            const bool in = qi < S;
+            lds_lse[tid] = in ? lse_b[qi] * LOG2E : INFINITY;  // +inf => p = 0 for padded query rows
+            lds_dl[tid] = in ? dl_b[qi] : 0.f;
+            const bool qvl = in && (vrow ? vrow[min(qi, S - 1)] != 0 : true);
+            const uint64_t m = __ballot(qvl);
+            if (tid == 0) lds_mask[0] = m;
+        }
+        __syncthreads();
+        if (qt + 1 < nqt) {
+            tile_load_regs<64>(base, p.ld, (qt + 1) * 64, S - 1, qreg, tid);
+            tile_load_regs<64>(dobase, p.lddo, (qt + 1) * 64, S - 1, oreg, tid);
+        }
+        if (!wave_active) continue;
+        const uint64_t qmask = lds_mask[0] >> (4 * hi);
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            f32x16 st = zero16(), dp = zero16();
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int off = h2_off(64, qb * 32 + (lane & 31), 2 * kk + hi);
+                const bf16x8 qfr = *reinterpret_cast<const bf16x8*>(ldsQ + off);
+                const bf16x8 dofr = *reinterpret_cast<const bf16x8*>(ldsO + off);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr, kf[kk], st, 0, 0, 0);    // D[q][key]
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dofr, vf[kk], dp, 0, 0, 0);
+            }
+            bf16x8 pf[2], dsf[2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lds_lse + qb * 32 + 8 * g + 4 * hi);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(lds_dl + qb * 32 + 8 * g + 4 * hi);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    const int bit = qb * 32 + acc_row(r);
+                    const bool qvb = (qmask >> bit) & 1;
+                    const bool live = kv && qvb;
+                    const float t = qvb ? (kv ? st[r] * sc : MASKED_T) : 0.f;
+                    float pv = exp2f(t - l4[e]);
+                    pv = key_in ? pv : 0.f;
+                    const float ds = live ? pv * (dp[r] - d4[e]) * p.scale : 0.f;
+                    pf[r >> 3][r & 7] = (bf16)pv;
+                    dsf[r >> 3][r & 7] = (bf16)ds;
+                }
+            }
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int rb = qb * 32 + hf * 16 + 4 * hi;
+                    const bf16x8 dot = tr_frag<64>(ldsO, rb, db * 32, lane);
+                    const bf16x8 qtf = tr_frag<64>(ldsQ, rb, db * 32, lane);
+                    dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot, pf[hf], dv[db], 0, 0, 0);   // D[d][key]
+                    dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsf[hf], dk[db], 0, 0, 0);
+                }
+        }
+    }
+    if (wave_active && key_in) {
+        bf16* krow = p.dqkv + ((int64_t)b * S + key) * p.lddqkv + p.heads * 64 + h * 64;
+        bf16* vrowp = krow + p.heads * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 k4, v4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    k4[e] = (bf16)dk[db][4 * g + e];
+                    v4[e] = (bf16)dv[db][4 * g + e];
+                }
+                *reinterpret_cast<bf16x4*>(krow + db * 32 + 8 * g + 4 * hi) = k4;
+                *reinterpret_cast<bf16x4*>(vrowp + db * 32 + 8 * g + 4 * hi) = v4;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// side output: per-key column sums of the probabilities (one wave per (32 keys, head, batch))
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void attn_colsum_kernel(const AttnArgs p) {
+    const int lane = threadIdx.x;
+    const int hi = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int S = p.S;
+    const int k0 = blockIdx.x * 32;
+    const bf16* base = p.qkv + (int64_t)b * S * p.ld + h * 64;
+    const bf16* kbase = base + p.heads * 64;
+    const uint8_t* vrow = p.valid ? p.valid + (int64_t)b * S : nullptr;
+    const float* lse_b = p.lse + ((int64_t)b * p.heads + h) * S;
+    const int key = min(k0 + (lane & 31), S - 1);
+    const bool key_in = k0 + (lane & 31) < S;
+    const bool kv = key_in && (vrow ? vrow[key] != 0 : true);
+    bf16x8 kf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+        kf[kk] = *reinterpret_cast<const bf16x8*>(kbase + (int64_t)key * p.ld + kk * 16 + hi * 8);
+    const float sc = p.scale * LOG2E;
+    float acc_lo = 0.f, acc_hi = 0.f;
+    const int nqb = (S + 31) / 32;
+    for (int qb = 0; qb < nqb; ++qb) {
+        const int qrow = min(qb * 32 + (lane & 31), S - 1);
+        f32x16 st = zero16();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const bf16x8 qfr = *reinterpret_cast<const bf16x8*>(base + (int64_t)qrow * p.ld + kk * 16 + hi * 8);
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr, kf[kk], st, 0, 0, 0);  // D[q][key]
+        }
+        const int ql = qb * 32 + (lane & 31);
+        const bool q_in = ql < S;
+        const bool qvl = q_in && (vrow ? vrow[min(ql, S - 1)] != 0 : true);
+        const uint64_t qin_mask = __ballot(q_in && lane < 32) >> (4 * hi);
+        const uint64_t qv_mask = __ballot(qvl && lane < 32) >> (4 * hi);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int bit = acc_row(r);
+            const int qi = qb * 32 + bit + 4 * hi;
+            const bool qin = (qin_mask >> bit) & 1;
+            const bool qvalid = (qv_mask >> bit) & 1;
+            const bool live = kv && qvalid;
+            const float t = qvalid ? (kv ? st[r] * sc : MASKED_T) : 0.f;
+            const float l2 = lse_b[min(qi, S - 1)] * LOG2E;
+            float pv = exp2f(t - l2);
+            const bool count = qin && (p.valid_q_only ? live : true);
+            pv = count ? pv : 0.f;
+            if (qi < p.qsplit) acc_lo += pv; else acc_hi += pv;
+        }
+    }
+    acc_lo += __shfl_xor(acc_lo, 32, 64);
+    acc_hi += __shfl_xor(acc_hi, 32, 64);
+    if (lane < 32 && key_in) {
+        if (p.colsum_lo) atomicAdd(p.colsum_lo + (int64_t)b * S + key, acc_lo * p.weight);
+        if (p.colsum_hi) atomicAdd(p.colsum_hi + (int64_t)b * S + key, acc_hi * p.weight);
+    }
+}
+
+int check_attn(const void* qkv, int64_t ld, int B, int S, int heads) {
+    MERLOT_CHECK(qkv != nullptr, MERLOT_ESHAPE, "attention: null qkv");
+    MERLOT_CHECK(B > 0 && S > 0 && heads > 0, MERLOT_ESHAPE, "attention: bad dims B=%d S=%d heads=%d", B, S, heads);
+    MERLOT_CHECK(ld >= 3 * heads * 64 && ld % 8 == 0, MERLOT_EALIGN, "attention: ld=%lld too small / unaligned",
+                 (long long)ld);
+    MERLOT_CHECK(((uintptr_t)qkv & 15) == 0, MERLOT_EALIGN, "attention: qkv must be 16-byte aligned");
+    MERLOT_CHECK(heads <= 65535 && B <= 65535, MERLOT_ESHAPE, "attention: grid too large");
+    return MERLOT_OK;
+}
+
+}  // namespace
+
+extern "C" int merlot_attention_fwd(const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse,
+                                    const uint8_t* valid, int B, int S, int heads, float scale, merlot_stream_t stream) {
+    int rc = check_attn(qkv, ld, B, S, heads);
+    if (rc) return rc;
+    MERLOT_CHECK(out && ldo >= heads * 64 && ldo % 4 == 0, MERLOT_ESHAPE, "attention_fwd: bad out/ldo");
+    AttnArgs a{};
+    a.qkv = (const bf16*)qkv; a.ld = ld; a.out = (bf16*)out; a.ldo = ldo; a.lse = lse; a.valid = valid;
+    a.B = B; a.S = S; a.heads = heads; a.scale = scale;
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(cdiv(S, 128), heads, B), dim3(256), 0, (hipStream_t)stream, a);
+    return merlot_launch_status("merlot_attention_fwd");
+}
+
+extern "C" int merlot_attention_bwd(const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout,
+                                    int64_t lddo, const float* lse, const uint8_t* valid, void* dqkv, int64_t lddqkv,
+                                    float* delta, int B, int S, int heads, float scale, merlot_stream_t stream) {
+    int rc = check_attn(qkv, ld, B, S, heads);
+    if (rc) return rc;
+    MERLOT_CHECK(out && dout && lse && dqkv && delta, MERLOT_ESHAPE, "attention_bwd: null operand");
+    MERLOT_CHECK(ldo % 8 == 0 && lddo % 8 == 0 && lddqkv % 4 == 0 && lddqkv >= 3 * heads * 64, MERLOT_EALIGN,
+                 "attention_bwd: bad leading dims");
+    AttnArgs a{};
+    a.qkv = (const bf16*)qkv; a.ld = ld; a.out = (bf16*)out; a.ldo = ldo; a.dout = (const bf16*)dout; a.lddo = lddo;
+    a.lse = (float*)lse; a.delta = delta; a.valid = valid; a.dqkv = (bf16*)dqkv; a.lddqkv = lddqkv;
+    a.B = B; a.S = S; a.heads = heads; a.scale = scale;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv((int64_t)B * S, 4)), dim3(256), 0, s, a, delta);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);
+    return merlot_launch_status("merlot_attention_bwd");
+}
+
+extern "C" int merlot_attention_colsum(const void* qkv, int64_t ld, const float* lse, const uint8_t* valid,
+                                       float* colsum_lo, float* colsum_hi, int qsplit, int valid_q_only, float weight,
+                                       int B, int S, int heads, float scale, merlot_stream_t stream) {
+    int rc = check_attn(qkv, ld, B, S, heads);
+    if (rc) return rc;
+    MERLOT_CHECK(lse && (colsum_lo || colsum_hi), MERLOT_ESHAPE, "attention_colsum: null operand");
+    AttnArgs a{};
+    a.qkv = (const bf16*)qkv; a.ld = ld; a.lse = (float*)lse; a.valid = valid;
+    a.colsum_lo = colsum_lo; a.colsum_hi = colsum_hi; a.qsplit = qsplit; a.valid_q_only = valid_q_only;
+    a.weight = weight; a.B = B; a.S = S; a.heads = heads; a.scale = scale;
+    hipLaunchKernelGGL(attn_colsum_kernel, dim3(cdiv(S, 32), heads, B), dim3(64), 0, (hipStream_t)stream, a);
+    return merlot_launch_status("merlot_attention_colsum");
+}

@@ -1,0 +1,222 @@
+// LayerNorm forward / backward for gfx950 (utils/model_utils.py:113-130): fp32 statistics, population
+// variance, eps inside the rsqrt, y = x*s - mean*s + beta with s = rstd*gamma.
+// HBM-bound: one wave per row, each lane owns 4 contiguous features per 256-wide slab (8-byte bf16 /
+// 16-byte f32 accesses, 512 B / 1 KiB coalesced per wave instruction); row statistics by wave shuffles.
+#include "common.h"
+
+namespace {
+
+template <typename T>
+__device__ __forceinline__ void load4(const T* p, float (&v)[4]);
+template <>
+__device__ __forceinline__ void load4<bf16>(const bf16* p, float (&v)[4]) {
+    const bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (float)t[e];
+}
+template <>
+__device__ __forceinline__ void load4<float>(const float* p, float (&v)[4]) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = t[e];
+}
+__device__ __forceinline__ void store4(bf16* p, const float (&v)[4]) {
+    bf16x4 t;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[e] = (bf16)v[e];
+    *reinterpret_cast<bf16x4*>(p) = t;
+}
+__device__ __forceinline__ void store4(float* p, const float (&v)[4]) {
+    f32x4 t;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[e] = v[e];
+    *reinterpret_cast<f32x4*>(p) = t;
+}
+
+template <int NS, typename TX>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, bf16* __restrict__ y16,
+                                                     float* __restrict__ y32, float* __restrict__ mean_out,
+                                                     float* __restrict__ rstd_out, int64_t rows, float eps) {
+    constexpr int H = NS * 256;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[NS][4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        load4<TX>(x + row * H + i * 256 + lane * 4, v[i]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += v[i][e];
+    }
+    const float mean = wave_sum(s) * (1.0f / H);
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = v[i][e] - mean;
+            ss += d * d;
+        }
+    const float var = wave_sum(ss) * (1.0f / H);
+    const float rstd = rsqrtf(var + eps);
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        float g[4], bt[4], o[4];
+        load4<float>(gamma + i * 256 + lane * 4, g);
+        load4<float>(beta + i * 256 + lane * 4, bt);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float sc = rstd * g[e];
+            o[e] = v[i][e] * sc - mean * sc + bt[e];
+        }
+        if (y16) store4(y16 + row * H + i * 256 + lane * 4, o);
+        if (y32) store4(y32 + row * H + i * 256 + lane * 4, o);
+    }
+    if (lane == 0) {
+        if (mean_out) mean_out[row] = mean;
+        if (rstd_out) rstd_out[row] = rstd;
+    }
+}
+
+// backward: grid-stride over rows; each wave keeps per-lane partial dgamma/dbeta for its 4*NS columns,
+// reduced across the 4 waves through LDS and pushed with one atomicAdd per column per block.
+template <int NS, typename TDY, typename TX, typename TR, typename TDX>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, const TR* __restrict__ dres,
+                                                     TDX* __restrict__ dx, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int64_t rows) {
+    constexpr int H = NS * 256;
+    __shared__ float red[2][4][H];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float g[NS][4], dg[NS][4], db[NS][4];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        load4<float>(gamma + i * 256 + lane * 4, g[i]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dg[i][e] = db[i][e] = 0.f;
+    }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float dyv[NS][4], xh[NS][4];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            float xv[4];
+            load4<TDY>(dy + row * H + i * 256 + lane * 4, dyv[i]);
+            load4<TX>(x + row * H + i * 256 + lane * 4, xv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xh[i][e] = (xv[e] - mu) * rs;
+                const float gd = dyv[i][e] * g[i][e];
+                c1 += gd;
+                c2 += gd * xh[i][e];
+                dg[i][e] += dyv[i][e] * xh[i][e];
+                db[i][e] += dyv[i][e];
+            }
+        }
+        c1 = wave_sum(c1) * (1.0f / H);
+        c2 = wave_sum(c2) * (1.0f / H);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = rs * (dyv[i][e] * g[i][e] - c1 - xh[i][e] * c2);
+            if (dres) {
+                float r[4];
+                load4<TR>(dres + row * H + i * 256 + lane * 4, r);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] += r[e];
+            }
+            store4(dx + row * H + i * 256 + lane * 4, o);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[0][wave][i * 256 + lane * 4 + e] = dg[i][e];
+            red[1][wave][i * 256 + lane * 4 + e] = db[i][e];
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += 256) {
+        const float sg = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+        const float sb = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+        if (dgamma) atomicAdd(dgamma + c, sg);
+        if (dbeta) atomicAdd(dbeta + c, sb);
+    }
+}
+
+template <int NS>
+int ln_fwd_launch(const void* x, int x_f32, const float* gamma, const float* beta, void* y16, float* y32, float* mean,
+                  float* rstd, int64_t rows, float eps, hipStream_t s) {
+    const dim3 grid(cdiv(rows, 4)), block(256);
+    if (x_f32)
+        hipLaunchKernelGGL((ln_fwd_kernel<NS, float>), grid, block, 0, s, (const float*)x, gamma, beta, (bf16*)y16, y32,
+                           mean, rstd, rows, eps);
+    else
+        hipLaunchKernelGGL((ln_fwd_kernel<NS, bf16>), grid, block, 0, s, (const bf16*)x, gamma, beta, (bf16*)y16, y32,
+                           mean, rstd, rows, eps);
+    return merlot_launch_status("merlot_ln_fwd");
+}
+
+// supported dtype combinations of the backward (dy, x, dres, dx):
+//   0: bf16 bf16 bf16 bf16   (transformer layers)
+//   1: f32  f32  f32  f32    (heads / embedding sites)
+//   2: bf16 f32  f32  f32    (embedding LN whose output was bf16, input f32)
+//   3: f32  bf16 bf16 bf16
+template <int NS>
+int ln_bwd_launch(int combo, const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                  const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, hipStream_t s) {
+    int nblk = cdiv(rows, 4);
+    if (nblk > 2048) nblk = 2048;
+    const dim3 grid(nblk), block(256);
+#define LN_BWD(TDY, TX, TR, TDX)                                                                                      \
+    hipLaunchKernelGGL((ln_bwd_kernel<NS, TDY, TX, TR, TDX>), grid, block, 0, s, (const TDY*)dy, (const TX*)x, mean,  \
+                       rstd, gamma, (const TR*)dres, (TDX*)dx, dgamma, dbeta, rows)
+    switch (combo) {
+        case 0: LN_BWD(bf16, bf16, bf16, bf16); break;
+        case 1: LN_BWD(float, float, float, float); break;
+        case 2: LN_BWD(bf16, float, float, float); break;
+        case 3: LN_BWD(float, bf16, bf16, bf16); break;
+        default: merlot_set_error("merlot_ln_bwd: unsupported dtype combination"); return MERLOT_EDTYPE;
+    }
+#undef LN_BWD
+    return merlot_launch_status("merlot_ln_bwd");
+}
+
+}  // namespace
+
+#define LN_DISPATCH_H(H, CALL)                                                                  \
+    switch (H) {                                                                                \
+        case 256: { constexpr int NS = 1; return CALL; }                                        \
+        case 512: { constexpr int NS = 2; return CALL; }                                        \
+        case 768: { constexpr int NS = 3; return CALL; }                                        \
+        case 1024: { constexpr int NS = 4; return CALL; }                                       \
+        default: merlot_set_error("LayerNorm: H=%d unsupported (256/512/768/1024)", H); return MERLOT_ESHAPE; \
+    }
+
+extern "C" int merlot_ln_fwd(const void* x, int x_f32, const float* gamma, const float* beta, void* y_bf16, float* y_f32,
+                             float* mean, float* rstd, int64_t rows, int H, float eps, merlot_stream_t stream) {
+    MERLOT_CHECK(x && gamma && beta && (y_bf16 || y_f32), MERLOT_ESHAPE, "merlot_ln_fwd: null operand");
+    MERLOT_CHECK(rows > 0, MERLOT_ESHAPE, "merlot_ln_fwd: rows must be > 0");
+    hipStream_t s = (hipStream_t)stream;
+    LN_DISPATCH_H(H, (ln_fwd_launch<NS>(x, x_f32, gamma, beta, y_bf16, y_f32, mean, rstd, rows, eps, s)));
+}
+
+extern "C" int merlot_ln_bwd(const void* dy, int dy_f32, const void* x, int x_f32, const float* mean, const float* rstd,
+                             const float* gamma, const void* dres, int dres_f32, void* dx, int dx_f32, float* dgamma,
+                             float* dbeta, int64_t rows, int H, merlot_stream_t stream) {
+    MERLOT_CHECK(dy && x && mean && rstd && gamma && dx, MERLOT_ESHAPE, "merlot_ln_bwd: null operand");
+    MERLOT_CHECK(rows > 0, MERLOT_ESHAPE, "merlot_ln_bwd: rows must be > 0");
+    if (!dres) dres_f32 = dx_f32;
+    int combo = -1;
+    if (!dy_f32 && !x_f32 && !dres_f32 && !dx_f32) combo = 0;
+    else if (dy_f32 && x_f32 && dres_f32 && dx_f32) combo = 1;
+    else if (!dy_f32 && x_f32 && dres_f32 && dx_f32) combo = 2;
+    else if (dy_f32 && !x_f32 && !dres_f32 && !dx_f32) combo = 3;
+    hipStream_t s = (hipStream_t)stream;
+    LN_DISPATCH_H(H, (ln_bwd_launch<NS>(combo, dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, rows, s)));
+}

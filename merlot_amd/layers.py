@@ -1,0 +1,339 @@
+"""autograd glue between the model code and the HIP kernels.
+
+Granularity is deliberately coarse: one autograd.Function per transformer STACK (forward and backward walk the
+12 layers calling the C-ABI directly, activations kept in bf16), one per Linear / LayerNorm / embedding site of
+the small heads.  Parameter gradients are not returned to autograd: every backward ACCUMULATES straight into the
+flat fp32 gradient arena of `ParamStore` (wgrad GEMMs with beta=1, atomically-added bias / LayerNorm grads) and
+then signals `store.notify_ready(group)` so the DP reducer can launch that bucket's all-reduce while the rest of
+the backward is still running.
+
+Reference being replaced: utils/transformer.py:171-247 (stack), :33-138 (attention), :141-163 (MLP),
+utils/model_utils.py:113-130 (LayerNorm), tf.gradients at utils/optimization.py:176.
+"""
+import torch
+
+from . import ops
+from .ops import BF16, F32, EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU
+
+
+class LayerW(object):
+    __slots__ = ('ln1', 'qkv', 'proj', 'ln2', 'fc1', 'fc2', 'name')
+
+
+class StackW(object):
+    """Weights of one transformer stack (`scope` = 'encoder' or 'vision_backbone/vision_transformer')."""
+
+    def __init__(self, store, scope, num_layers):
+        self.store = store
+        self.scope = scope
+        self.layers = []
+        for l in range(num_layers):
+            ls = f'{scope}/layer{l:02d}'
+            w = LayerW()
+            w.name = ls
+            w.ln1 = store.ln(f'{ls}/LayerNorm_attn_ln0')
+            w.qkv = store.lin(f'{ls}/qkv')
+            w.proj = store.lin(f'{ls}/context_projection_layer')
+            w.ln2 = store.ln(f'{ls}/LayerNorm_mlp_ln0')
+            w.fc1 = store.lin(f'{ls}/intermediate')
+            w.fc2 = store.lin(f'{ls}/output')
+            self.layers.append(w)
+        self.ln_final = store.ln(f'{scope}/LayerNorm_ln_final')
+
+
+def _site_seed(seed, layer, site):
+    return (int(seed) * 1000003 + layer * 16 + site) & 0xFFFFFFFFFFFFFFFF
+
+
+class TransformerStackFn(torch.autograd.Function):
+    """hidden [B*S, H] bf16 -> LN_final(stack(hidden)) [B*S, H] bf16.
+
+    opts: dict(heads, dropout_p, seed, colsum (f32 [B,S] accumulated over layers, all query rows, weight 1/heads),
+               log_lo / log_hi (f32 [B,S], valid pairs only, queries < / >= log_split), num_layers)
+    """
+
+    @staticmethod
+    def forward(ctx, h, stack, B, S, valid, opts):
+        heads = opts['heads']
+        p = float(opts.get('dropout_p', 0.0))
+        seed = opts.get('seed', 0)
+        nl = opts.get('num_layers', len(stack.layers))
+        colsum = opts.get('colsum')
+        log_lo, log_hi = opts.get('log_lo'), opts.get('log_hi')
+        need_bwd = ctx.needs_input_grad[0]
+        saved = []
+        h = h.contiguous()
+        for l in range(nl):
+            w = stack.layers[l]
+            x1, _, mean1, rstd1 = ops.ln_fwd(h, w.ln1.gamma, w.ln1.beta)
+            qkv = ops.gemm_nt(x1, w.qkv.wb, bias=w.qkv.b)
+            ctx_, lse = ops.attention_fwd(qkv, B, S, heads, valid)
+            if colsum is not None:
+                ops.attention_colsum(qkv, lse, B, S, heads, colsum, valid=valid, valid_q_only=False, weight=1.0 / heads)
+            if log_lo is not None:
+                ops.attention_colsum(qkv, lse, B, S, heads, log_lo, log_hi, qsplit=opts['log_split'], valid=valid,
+                                     valid_q_only=True, weight=1.0 / heads)
+            h_mid = ops.gemm_nt(ctx_, w.proj.wb, bias=w.proj.b, epilogue=EPI_RESIDUAL, aux_in=h, dropout_p=p,
+                                dropout_seed=_site_seed(seed, l, 0))
+            x2, _, mean2, rstd2 = ops.ln_fwd(h_mid, w.ln2.gamma, w.ln2.beta)
+            u = torch.empty((x2.shape[0], w.fc1.wb.shape[0]), device=h.device, dtype=BF16)
+            a = ops.gemm_nt(x2, w.fc1.wb, bias=w.fc1.b, epilogue=EPI_GELU, aux_out=u)
+            h_out = ops.gemm_nt(a, w.fc2.wb, bias=w.fc2.b, epilogue=EPI_RESIDUAL, aux_in=h_mid, dropout_p=p,
+                                dropout_seed=_site_seed(seed, l, 1))
+            if need_bwd:
+                saved.append((h, mean1, rstd1, x1, qkv, ctx_, lse, h_mid, mean2, rstd2, x2, u, a))
+            h = h_out
+        y, _, meanf, rstdf = ops.ln_fwd(h, stack.ln_final.gamma, stack.ln_final.beta)
+        ctx.stack, ctx.B, ctx.S, ctx.valid, ctx.heads, ctx.p, ctx.seed, ctx.nl = stack, B, S, valid, heads, p, seed, nl
+        ctx.saved = saved
+        ctx.final = (h, meanf, rstdf)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        stack, B, S, valid, heads, p, seed = ctx.stack, ctx.B, ctx.S, ctx.valid, ctx.heads, ctx.p, ctx.seed
+        store = stack.store
+        hL, meanf, rstdf = ctx.final
+        dy = dy.contiguous()
+        dh = ops.ln_bwd(dy, hL, meanf, rstdf, stack.ln_final.gamma, stack.ln_final.ggamma, stack.ln_final.gbeta)
+        for l in range(ctx.nl - 1, -1, -1):
+            w = stack.layers[l]
+            h, mean1, rstd1, x1, qkv, ctx_, lse, h_mid, mean2, rstd2, x2, u, a = ctx.saved[l]
+            ctx.saved[l] = None
+            # ---- MLP branch: h_out = h_mid + drop(fc2(gelu(fc1(LN2(h_mid)))))
+            db2 = ops.dropout_apply(dh, p, _site_seed(seed, l, 1)) if p > 0 else dh
+            ops.colsum_bf16(db2, w.fc2.gb)
+            ops.gemm_tn(db2, a, w.fc2.gw)                                       # dW2[H, I]
+            du = ops.gemm_nt(db2, w.fc2.wbT, epilogue=EPI_DGELU, aux_in=u)      # [T, I]
+            ops.colsum_bf16(du, w.fc1.gb)
+            ops.gemm_tn(du, x2, w.fc1.gw)                                       # dW1[I, H]
+            dx2 = ops.gemm_nt(du, w.fc1.wbT)
+            dh_mid = ops.ln_bwd(dx2, h_mid, mean2, rstd2, w.ln2.gamma, w.ln2.ggamma, w.ln2.gbeta, dres=dh)
+            # ---- attention branch: h_mid = h + drop(proj(attn(qkv(LN1(h)))))
+            db1 = ops.dropout_apply(dh_mid, p, _site_seed(seed, l, 0)) if p > 0 else dh_mid
+            ops.colsum_bf16(db1, w.proj.gb)
+            ops.gemm_tn(db1, ctx_, w.proj.gw)
+            dctx = ops.gemm_nt(db1, w.proj.wbT)
+            dqkv = ops.attention_bwd(qkv, ctx_, dctx, lse, B, S, heads, valid)
+            ops.colsum_bf16(dqkv, w.qkv.gb)
+            ops.gemm_tn(dqkv, x1, w.qkv.gw)
+            dx1 = ops.gemm_nt(dqkv, w.qkv.wbT)
+            dh = ops.ln_bwd(dx1, h, mean1, rstd1, w.ln1.gamma, w.ln1.ggamma, w.ln1.gbeta, dres=dh_mid)
+            store.notify_ready(w.name)
+        store.notify_ready(stack.scope + '/LayerNorm_ln_final')
+        ctx.saved = None
+        ctx.final = None
+        return dh, None, None, None, None, None
+
+
+def transformer_stack(h, stack, B, S, valid, opts):
+    return TransformerStackFn.apply(h, stack, B, S, valid, opts)
+
+
+class LinearFn(torch.autograd.Function):
+    """y = act(x @ W^T + b) for the small heads.  x: [T, in] f32 or bf16 -> y f32 (heads are kept fp32 outside
+    the MFMA contraction, model/modeling.py:184).  act in {None, 'gelu'}."""
+
+    @staticmethod
+    def forward(ctx, x, lin, act):
+        xb = x if x.dtype == BF16 else ops.cast_bf16(x.contiguous())
+        y = ops.gemm_nt(xb, lin.wb, bias=lin.b, out_dtype=F32)
+        ctx.lin, ctx.act, ctx.xb, ctx.x_dtype = lin, act, xb, x.dtype
+        if act == 'gelu':
+            ctx.pre = y
+            y = ops.gelu_fwd(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lin = ctx.lin
+        dy = dy.contiguous()
+        if ctx.act == 'gelu':
+            dy = ops.gelu_bwd(dy, ctx.pre)
+        dyb = ops.cast_bf16(dy)
+        if lin.gb is not None:
+            ops.colsum_bf16(dyb, lin.gb)
+        out_dim = lin.w.shape[0]
+        if out_dim % 2 == 0:
+            ops.gemm_tn(dyb, ctx.xb, lin.gw)
+        else:
+            raise ValueError("LinearFn: odd output width unsupported")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            # K of the dgrad = out_dim must be a multiple of 64; the 4-wide temporal logits pad through wbT rows
+            if out_dim % 64 == 0:
+                dx = ops.gemm_nt(dyb, lin.wbT, out_dtype=F32 if ctx.x_dtype == F32 else BF16)
+            else:
+                kp = (out_dim + 63) // 64 * 64
+                dyp = torch.zeros((dyb.shape[0], kp), device=dyb.device, dtype=BF16)
+                dyp[:, :out_dim] = dyb
+                wp = torch.zeros((lin.wbT.shape[0], kp), device=dyb.device, dtype=BF16)
+                wp[:, :out_dim] = lin.wbT
+                dx = ops.gemm_nt(dyp, wp, out_dtype=F32 if ctx.x_dtype == F32 else BF16)
+        return dx, None, None
+
+
+def linear(x, lin, act=None):
+    return LinearFn.apply(x, lin, act)
+
+
+class LayerNormFn(torch.autograd.Function):
+    """LN on f32 rows; output f32 or bf16."""
+
+    @staticmethod
+    def forward(ctx, x, ln, out_bf16):
+        x = x.contiguous()
+        y16, y32, mean, rstd = ops.ln_fwd(x, ln.gamma, ln.beta, out_bf16=out_bf16, out_f32=not out_bf16)
+        ctx.ln, ctx.x, ctx.mean, ctx.rstd = ln, x, mean, rstd
+        return y16 if out_bf16 else y32
+
+    @staticmethod
+    def backward(ctx, dy):
+        ln = ctx.ln
+        dx = ops.ln_bwd(dy.contiguous(), ctx.x, ctx.mean, ctx.rstd, ln.gamma, ln.ggamma, ln.gbeta, dx_dtype=ctx.x.dtype)
+        return dx, None, None
+
+
+def layer_norm(x, ln, out_bf16=False):
+    return LayerNormFn.apply(x, ln, out_bf16)
+
+
+class GatherAddFn(torch.autograd.Function):
+    """out[r] = sum_k table_k[idx_k[r]]   (f32).  `act` (optional) is an activation tensor source (bf16 or f32,
+    differentiable through autograd); tables are (param, grad) pairs from the store, gradients scatter-added."""
+
+    @staticmethod
+    def forward(ctx, act, act_idx, tables, rows, H, anchor):
+        srcs = []
+        if act is not None:
+            srcs.append((act.contiguous().view(-1, H), act_idx))
+        for (tab, _g, idx) in tables:
+            srcs.append((tab.view(-1, H), idx))
+        while len(srcs) < 4:
+            srcs.append((None, None))
+        # slot `a` is the only one that may be bf16: put the activation there
+        (a, ia), (b, ib), (c, ic), (d, id_) = srcs[:4]
+        out = ops.gather_add4(rows, H, a=a, ia=ia, b=b, ib=ib, c=c, ic=ic, d=d, id_=id_)
+        ctx.act_shape = None if act is None else act.shape
+        ctx.act_dtype = None if act is None else act.dtype
+        ctx.act_idx, ctx.tables, ctx.H = act_idx, tables, H
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        H = ctx.H
+        for (tab, gtab, idx) in ctx.tables:
+            ops.scatter_add_rows(dout, idx, gtab.view(-1, H))
+        dact = None
+        if ctx.act_shape is not None and ctx.needs_input_grad[0]:
+            if ctx.act_idx is None:
+                dact = dout.view(ctx.act_shape).to(ctx.act_dtype)
+            else:
+                n_src = 1
+                for s in ctx.act_shape[:-1]:
+                    n_src *= s
+                buf = torch.zeros((n_src, H), device=dout.device, dtype=F32)
+                ops.scatter_add_rows(dout, ctx.act_idx, buf)
+                dact = buf.view(ctx.act_shape).to(ctx.act_dtype)
+        return dact, None, None, None, None, None
+
+
+def gather_add(act, act_idx, tables, rows, H, anchor):
+    """`anchor`: the store's dummy requires-grad tensor, so a gather of parameters only is still a graph root."""
+    return GatherAddFn.apply(act, act_idx, tables, rows, H, anchor)
+
+
+class ClsAvgPoolFn(torch.autograd.Function):
+    """[n_img, S, H] bf16 ViT output -> f32 [n_img, 1 + h2*w2, H] = [cls slot 0 ; 2x2 avg-pooled grid]."""
+
+    @staticmethod
+    def forward(ctx, x, n_img, h1, w1, cls_skip, pool):
+        ctx.args = (n_img, h1, w1, cls_skip, pool)
+        return ops.cls_avgpool_fwd(x.contiguous(), n_img, h1, w1, cls_skip, pool)
+
+    @staticmethod
+    def backward(ctx, dout):
+        n_img, h1, w1, cls_skip, pool = ctx.args
+        dx = ops.cls_avgpool_bwd(dout.contiguous(), n_img, h1, w1, cls_skip, pool)
+        return dx.view(n_img * (cls_skip + h1 * w1), -1), None, None, None, None, None
+
+
+class PatchEmbedFn(torch.autograd.Function):
+    """image NHWC bf16 -> [n_img*h1*w1, H] bf16 (utils/vision_transformer.py:193-205); image gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, image, lin, patch, anchor):
+        # fold the `image - 0.5` into the bias: (x - 0.5) W = x W - 0.5 * sum_k W[:, k]   (bf16 weights, fp32 sum)
+        bias_folded = lin.b - 0.5 * lin.wb.float().sum(1)
+        ctx.image, ctx.lin, ctx.patch = image, lin, patch
+        return ops.patch_embed_fwd(image, lin.wb, bias_folded.contiguous(), patch)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lin = ctx.lin
+        dy = dy.contiguous()
+        db = torch.zeros_like(lin.gb)
+        ops.colsum_bf16(dy, db, accumulate=False)
+        lin.gb.add_(db)
+        ops.patch_embed_wgrad(ctx.image, dy, lin.gw, ctx.patch, accumulate=True)
+        lin.gw.sub_(0.5 * db[:, None])           # the -0.5 shift of every pixel
+        return None, None, None, None
+
+
+class L2NormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y, inv = ops.l2norm_fwd(x.contiguous())
+        ctx.y, ctx.inv = y, inv
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.l2norm_bwd(dy, ctx.y, ctx.inv)
+
+
+class SoftmaxCEFn(torch.autograd.Function):
+    """per-row cross entropy of f32 logits [rows, >=C]; returns (loss[rows], argmax[rows])."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, C):
+        loss, am, dl = ops.softmax_ce(logits, labels, C, dlogits_dtype=F32, ld_dl=logits.shape[1])
+        ctx.dl = dl
+        ctx.mark_non_differentiable(am)
+        return loss, am
+
+    @staticmethod
+    def backward(ctx, dloss, _dam):
+        return ctx.dl * dloss[:, None], None, None
+
+
+class VocabCEFn(torch.autograd.Function):
+    """Masked-LM head tail (model/modeling.py:217-223, 539-545): logits = h @ E^T + output_bias, CE vs targets,
+    weighted row sum.  h: [T, H] f32 ; emb: Lin handle of the tied word-embedding table ; rowweight f32 [T].
+    Returns (sum_r rowweight[r] * ce[r]  (differentiable scalar), ce[T], argmax[T])."""
+
+    @staticmethod
+    def forward(ctx, h, emb, out_bias, gout_bias, targets, rowweight, vocab):
+        hb = ops.cast_bf16(h.contiguous())
+        vpad = emb.wbT.shape[1]
+        logits = torch.empty((h.shape[0], vpad), device=h.device, dtype=F32)
+        ops.gemm_nt(hb, emb.wb, bias=out_bias, out=logits, n=vocab)
+        loss, am, dl = ops.softmax_ce(logits, targets, vocab, rowscale=rowweight, dlogits_dtype=BF16, ld_dl=vpad)
+        del logits
+        ctx.hb, ctx.emb, ctx.dl, ctx.gout_bias, ctx.vocab = hb, emb, dl, gout_bias, vocab
+        ctx.mark_non_differentiable(loss, am)
+        return (loss * rowweight).sum(), loss, am
+
+    @staticmethod
+    def backward(ctx, g, _dl, _dam):
+        emb, vocab, dl = ctx.emb, ctx.vocab, ctx.dl          # dl already carries rowweight; g is the scalar upstream
+        if ctx.gout_bias is not None:
+            tmp = torch.zeros_like(ctx.gout_bias)
+            ops.colsum_bf16(dl, tmp, accumulate=False, n=vocab)
+            ctx.gout_bias.add_(tmp * g)
+        hg = (ctx.hb.float() * g).to(BF16)
+        ops.gemm_tn(dl, hg, emb.gw, m=vocab)                             # dE[V, H] += dlogits^T h
+        dh = ops.gemm_nt(dl, emb.wbT, out_dtype=F32) * g                 # [T, H]
+        ctx.dl = None
+        return dh, None, None, None, None, None, None

@@ -1,0 +1,78 @@
+"""ctypes binding of libmerlot_hip.so (the C-ABI in include/merlot_hip.h).
+
+The prototypes are parsed from the header itself, so the Python side can never drift from the ABI.
+There is NO fallback: if the shared library is missing the import of any op raises, loudly.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'merlot_hip.h')
+LIB_PATH = os.path.join(_HERE, 'libmerlot_hip.so')
+
+_CTYPES = {
+    'const void*': ctypes.c_void_p, 'void*': ctypes.c_void_p,
+    'const float*': ctypes.c_void_p, 'float*': ctypes.c_void_p,
+    'const int32_t*': ctypes.c_void_p, 'int32_t*': ctypes.c_void_p,
+    'const uint8_t*': ctypes.c_void_p,
+    'int64_t': ctypes.c_int64, 'uint64_t': ctypes.c_uint64, 'int': ctypes.c_int, 'float': ctypes.c_float,
+    'merlot_stream_t': ctypes.c_void_p,
+}
+
+
+class MerlotHipError(RuntimeError):
+    pass
+
+
+def parse_header(path=HEADER):
+    """-> {name: (restype_str, [(ctype_str, argname), ...])} for every function the header declares."""
+    src = open(path).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r'\b(int|const char\*)\s+(merlot_\w+)\s*\(([^)]*)\)\s*;', src):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        arglist = []
+        if args and args != 'void':
+            for a in args.split(','):
+                a = ' '.join(a.split())
+                mm = re.match(r'^(.*?)(\w+)$', a)
+                ty = mm.group(1).strip().replace(' *', '*')
+                arglist.append((ty, mm.group(2)))
+        protos[name] = (ret, arglist)
+    return protos
+
+
+class _Lib(object):
+    def __init__(self):
+        self._dll = None
+        self.protos = parse_header()
+
+    def load(self):
+        if self._dll is not None:
+            return self._dll
+        if not os.path.exists(LIB_PATH):
+            raise MerlotHipError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+                f"g.build()'` (or merlot_amd/csrc/build.sh). There is no CPU fallback for the product path.")
+        dll = ctypes.CDLL(LIB_PATH)
+        for name, (ret, args) in self.protos.items():
+            fn = getattr(dll, name)
+            fn.restype = ctypes.c_char_p if ret != 'int' else ctypes.c_int
+            fn.argtypes = [_CTYPES[t] for t, _ in args]
+        self._dll = dll
+        return dll
+
+    def call(self, name, *args):
+        dll = self.load()
+        rc = getattr(dll, name)(*args)
+        if rc != 0:
+            msg = dll.merlot_last_error()
+            raise MerlotHipError(f"{name} failed ({rc}): {msg.decode() if msg else '?'}")
+
+
+LIB = _Lib()
+
+
+def call(name, *args):
+    LIB.call(name, *args)

@@ -1,0 +1,292 @@
+"""Tensor-level wrappers over the C-ABI (raw pointers + the current HIP stream).  No autograd here.
+
+PyTorch is plumbing only: it owns device memory and the stream; every op below is one or more
+hand-written gfx950 kernels in libmerlot_hip.so.  There is no eager / CPU fallback.
+"""
+import torch
+
+from .lib import call
+
+EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU = 0, 1, 2, 3
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, dtype, name):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise ValueError(f"{name}: expected a GPU tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise ValueError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if t.stride(-1) != 1:
+        raise ValueError(f"{name}: last dim must be contiguous")
+
+
+def gemm_nt(a, bt, *, bias=None, epilogue=EPI_NONE, out=None, out_dtype=BF16, accumulate=False, alpha=1.0,
+            aux_in=None, aux_out=None, dropout_p=0.0, dropout_seed=0, n=None):
+    """C[M,N] = epi(alpha * a[M,K] @ bt[N,K]^T).  a, bt bf16 2-D (row stride = leading dim)."""
+    _chk(a, BF16, 'a'); _chk(bt, BF16, 'bt'); _chk(bias, F32, 'bias'); _chk(aux_in, BF16, 'aux_in'); _chk(aux_out, BF16, 'aux_out')
+    M, K = a.shape
+    N = bt.shape[0] if n is None else n
+    if bt.shape[1] != K:
+        raise ValueError(f"gemm_nt: K mismatch {a.shape} vs {bt.shape}")
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=out_dtype)
+    _chk(out, out.dtype, 'out')
+    call('merlot_gemm_bf16_nt', _p(a), a.stride(0), _p(bt), bt.stride(0), _p(out), out.stride(0), M, N, K, float(alpha),
+         int(epilogue), 1 if out.dtype == F32 else 0, 1 if accumulate else 0, _p(bias), _p(aux_in),
+         aux_in.stride(0) if aux_in is not None else 0, _p(aux_out), aux_out.stride(0) if aux_out is not None else 0,
+         float(dropout_p), int(dropout_seed) & 0xFFFFFFFFFFFFFFFF, _stream())
+    return out
+
+
+def gemm_tn(a, b, out, *, accumulate=True, alpha=1.0, m=None, n=None):
+    """out[M,N] (f32) (+)= alpha * a[R,M]^T @ b[R,N]."""
+    _chk(a, BF16, 'a'); _chk(b, BF16, 'b'); _chk(out, F32, 'out')
+    R = a.shape[0]
+    M = a.shape[1] if m is None else m
+    N = b.shape[1] if n is None else n
+    call('merlot_gemm_bf16_tn', _p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, R, float(alpha),
+         1 if accumulate else 0, _stream())
+    return out
+
+
+def patch_embed_fwd(image, wt, bias_folded, patch):
+    _chk(image, BF16, 'image'); _chk(wt, BF16, 'wt'); _chk(bias_folded, F32, 'bias')
+    n, H, W, c = image.shape
+    assert c == 3 and image.is_contiguous()
+    hidden = wt.shape[0]
+    out = torch.empty((n * (H // patch) * (W // patch), hidden), device=image.device, dtype=BF16)
+    call('merlot_patch_embed_fwd', _p(image), n, H, W, patch, _p(wt), _p(bias_folded), _p(out), hidden, _stream())
+    return out
+
+
+def patch_embed_wgrad(image, dy, dwt, patch, accumulate=True):
+    _chk(image, BF16, 'image'); _chk(dy, BF16, 'dy'); _chk(dwt, F32, 'dwt')
+    n, H, W, _ = image.shape
+    assert dy.is_contiguous() and dwt.is_contiguous()
+    call('merlot_patch_embed_wgrad', _p(image), n, H, W, patch, _p(dy), _p(dwt), dwt.shape[0], 1 if accumulate else 0,
+         _stream())
+
+
+def ln_fwd(x, gamma, beta, *, out_bf16=True, out_f32=False, save_stats=True, eps=1e-5):
+    assert x.dtype in (BF16, F32) and x.is_contiguous()
+    _chk(gamma, F32, 'gamma'); _chk(beta, F32, 'beta')
+    H = x.shape[-1]
+    rows = x.numel() // H
+    y16 = torch.empty(x.shape, device=x.device, dtype=BF16) if out_bf16 else None
+    y32 = torch.empty(x.shape, device=x.device, dtype=F32) if out_f32 else None
+    mean = torch.empty(rows, device=x.device, dtype=F32) if save_stats else None
+    rstd = torch.empty(rows, device=x.device, dtype=F32) if save_stats else None
+    call('merlot_ln_fwd', _p(x), 1 if x.dtype == F32 else 0, _p(gamma), _p(beta), _p(y16), _p(y32), _p(mean), _p(rstd),
+         rows, H, float(eps), _stream())
+    return y16, y32, mean, rstd
+
+
+def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, dres=None, dx_dtype=None):
+    """dx = LN'(dy) (+dres); dgamma/dbeta accumulated in place."""
+    assert dy.is_contiguous() and x.is_contiguous()
+    H = x.shape[-1]
+    rows = x.numel() // H
+    dx_dtype = dx_dtype or x.dtype
+    dx = torch.empty(x.shape, device=x.device, dtype=dx_dtype)
+    call('merlot_ln_bwd', _p(dy), 1 if dy.dtype == F32 else 0, _p(x), 1 if x.dtype == F32 else 0, _p(mean), _p(rstd),
+         _p(gamma), _p(dres), 1 if (dres is not None and dres.dtype == F32) else 0, _p(dx), 1 if dx_dtype == F32 else 0,
+         _p(dgamma), _p(dbeta), rows, H, _stream())
+    return dx
+
+
+def attention_fwd(qkv, B, S, heads, valid=None, need_lse=True):
+    _chk(qkv, BF16, 'qkv')
+    out = torch.empty((B * S, heads * 64), device=qkv.device, dtype=BF16)
+    lse = torch.empty((B, heads, S), device=qkv.device, dtype=F32) if need_lse else None
+    call('merlot_attention_fwd', _p(qkv), qkv.stride(0), _p(out), out.stride(0), _p(lse), _p(valid), B, S, heads,
+         0.125, _stream())
+    return out, lse
+
+
+def attention_bwd(qkv, out, dout, lse, B, S, heads, valid=None):
+    _chk(dout, BF16, 'dout')
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((B, heads, S), device=qkv.device, dtype=F32)
+    call('merlot_attention_bwd', _p(qkv), qkv.stride(0), _p(out), out.stride(0), _p(dout), dout.stride(0), _p(lse),
+         _p(valid), _p(dqkv), dqkv.stride(0), _p(delta), B, S, heads, 0.125, _stream())
+    return dqkv
+
+
+def attention_colsum(qkv, lse, B, S, heads, colsum_lo, colsum_hi=None, *, qsplit=None, valid=None, valid_q_only=False,
+                     weight=1.0):
+    call('merlot_attention_colsum', _p(qkv), qkv.stride(0), _p(lse), _p(valid), _p(colsum_lo), _p(colsum_hi),
+         S if qsplit is None else qsplit, 1 if valid_q_only else 0, float(weight), B, S, heads, 0.125, _stream())
+
+
+def cast_bf16(src, dst=None):
+    _chk(src, F32, 'src')
+    assert src.is_contiguous()
+    if dst is None:
+        dst = torch.empty(src.shape, device=src.device, dtype=BF16)
+    call('merlot_cast_f32_bf16', _p(src), _p(dst), src.numel(), _stream())
+    return dst
+
+
+def cast_transpose_bf16(src, dst=None, ld_dst=None):
+    _chk(src, F32, 'src')
+    assert src.dim() == 2 and src.is_contiguous()
+    R, C = src.shape
+    if dst is None:
+        dst = torch.empty((C, R), device=src.device, dtype=BF16)
+    call('merlot_cast_transpose_f32_bf16', _p(src), _p(dst), R, C, R if ld_dst is None else ld_dst, _stream())
+    return dst
+
+
+def colsum_bf16(x, out, accumulate=True, n=None):
+    _chk(x, BF16, 'x'); _chk(out, F32, 'out')
+    T = x.shape[0]
+    N = x.shape[1] if n is None else n
+    call('merlot_colsum_bf16', _p(x), x.stride(0), _p(out), T, N, 1 if accumulate else 0, _stream())
+
+
+def gather_add4(rows, H, a=None, ia=None, b=None, ib=None, c=None, ic=None, d=None, id_=None):
+    dev = next(t for t in (a, b, c, d) if t is not None).device
+    out = torch.empty((rows, H), device=dev, dtype=F32)
+    a_bf16 = 1 if (a is not None and a.dtype == BF16) else 0
+    for t in (b, c, d):
+        _chk(t, F32, 'table')
+    for t in (ia, ib, ic, id_):
+        _chk(t, torch.int32, 'index')
+    call('merlot_gather_add4', _p(a), a_bf16, _p(ia), _p(b), _p(ib), _p(c), _p(ic), _p(d), _p(id_), _p(out), rows, H,
+         _stream())
+    return out
+
+
+def scatter_add_rows(src, idx, table):
+    _chk(src, F32, 'src'); _chk(table, F32, 'table'); _chk(idx, torch.int32, 'idx')
+    assert src.is_contiguous() and table.is_contiguous()
+    H = src.shape[-1]
+    call('merlot_scatter_add_rows', _p(src), _p(idx), _p(table), src.numel() // H, H, _stream())
+
+
+def dropout_apply(x, p, seed):
+    _chk(x, BF16, 'x')
+    assert x.is_contiguous()
+    y = torch.empty_like(x)
+    N = x.shape[-1]
+    call('merlot_dropout_apply', _p(x), _p(y), x.numel() // N, N, float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, _stream())
+    return y
+
+
+def cls_avgpool_fwd(x, n_img, h1, w1, cls_skip, pool):
+    _chk(x, BF16, 'x')
+    H = x.shape[-1]
+    vl = 1 + (h1 // pool) * (w1 // pool)
+    out = torch.empty((n_img, vl, H), device=x.device, dtype=F32)
+    call('merlot_cls_avgpool_fwd', _p(x), _p(out), n_img, h1, w1, cls_skip, pool, H, _stream())
+    return out
+
+
+def cls_avgpool_bwd(dout, n_img, h1, w1, cls_skip, pool):
+    _chk(dout, F32, 'dout')
+    assert dout.is_contiguous()
+    H = dout.shape[-1]
+    dx = torch.empty((n_img, cls_skip + h1 * w1, H), device=dout.device, dtype=BF16)
+    call('merlot_cls_avgpool_bwd', _p(dout), _p(dx), n_img, h1, w1, cls_skip, pool, H, _stream())
+    return dx
+
+
+def softmax_ce(logits, labels, C, *, rowscale=None, dlogits_dtype=None, ld_dl=None, want_argmax=True):
+    _chk(logits, F32, 'logits'); _chk(labels, torch.int32, 'labels'); _chk(rowscale, F32, 'rowscale')
+    rows = logits.shape[0]
+    loss = torch.empty(rows, device=logits.device, dtype=F32)
+    am = torch.empty(rows, device=logits.device, dtype=torch.int32) if want_argmax else None
+    dl = None
+    if dlogits_dtype is not None:
+        ld_dl = ld_dl or logits.shape[1]
+        dl = torch.empty((rows, ld_dl), device=logits.device, dtype=dlogits_dtype)
+    call('merlot_softmax_ce', _p(logits), logits.stride(0), _p(labels), _p(loss), _p(am), _p(rowscale), _p(dl),
+         1 if dlogits_dtype == BF16 else 0, ld_dl or 0, rows, C, _stream())
+    return loss, am, dl
+
+
+def l2norm_fwd(x):
+    _chk(x, F32, 'x')
+    assert x.is_contiguous()
+    y = torch.empty_like(x)
+    inv = torch.empty(x.shape[0], device=x.device, dtype=F32)
+    call('merlot_l2norm_fwd', _p(x), _p(y), _p(inv), x.shape[0], x.shape[1], _stream())
+    return y, inv
+
+
+def l2norm_bwd(dy, y, inv):
+    dx = torch.empty_like(y)
+    call('merlot_l2norm_bwd', _p(dy.contiguous()), _p(y), _p(inv), _p(dx), y.shape[0], y.shape[1], _stream())
+    return dx
+
+
+def gelu_fwd(x):
+    _chk(x, F32, 'x')
+    y = torch.empty_like(x)
+    call('merlot_gelu_fwd', _p(x), _p(y), x.numel(), _stream())
+    return y
+
+
+def gelu_bwd(dy, x):
+    dx = torch.empty_like(x)
+    call('merlot_gelu_bwd', _p(dy.contiguous()), _p(x), _p(dx), x.numel(), _stream())
+    return dx
+
+
+def mask_inputs(ids, summs, gumbel, span_lower, span_upper, random_ids, option, num_topk, num_to_mask, w_nontopk, w_topk,
+                log_nontopk, log_topk, max_weight, mask_token=1):
+    B, L = ids.shape
+    for t in (ids, span_lower, span_upper, random_ids, option):
+        _chk(t, torch.int32, 'int input')
+    _chk(summs, F32, 'summs'); _chk(gumbel, F32, 'gumbel')
+    masked_ids = torch.empty_like(ids)
+    masked_idx = torch.empty((B, num_to_mask), device=ids.device, dtype=torch.int32)
+    call('merlot_mask_inputs', _p(ids), _p(summs), _p(gumbel), _p(span_lower), _p(span_upper), _p(random_ids), _p(option),
+         _p(masked_ids), _p(masked_idx), B, L, num_topk, num_to_mask, float(w_nontopk), float(w_topk), float(log_nontopk),
+         float(log_topk), float(max_weight), mask_token, _stream())
+    return masked_ids, masked_idx
+
+
+def temporal_labels(video_src_ids, shuffled_idx, B, n):
+    _chk(video_src_ids, torch.int32, 'video_src_ids'); _chk(shuffled_idx, torch.int32, 'shuffled_idx')
+    labels = torch.empty(B * n * n, device=video_src_ids.device, dtype=torch.int32)
+    weights = torch.empty(B * n * n, device=video_src_ids.device, dtype=F32)
+    call('merlot_temporal_labels', _p(video_src_ids), _p(shuffled_idx), _p(labels), _p(weights), B, n, _stream())
+    return labels, weights
+
+
+def shuffled_idx(num_shuffle, u_select, u_perm, B, n, offset=16):
+    _chk(num_shuffle, torch.int32, 'num_shuffle'); _chk(u_select, F32, 'u_select'); _chk(u_perm, F32, 'u_perm')
+    out = torch.empty(B * n, device=num_shuffle.device, dtype=torch.int32)
+    call('merlot_shuffled_idx', _p(num_shuffle), _p(u_select), _p(u_perm), _p(out), B, n, offset, _stream())
+    return out
+
+
+def adamw_step(param, grad, m, v, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0):
+    _chk(param, F32, 'param'); _chk(grad, F32, 'grad')
+    state_bf16 = 1 if m.dtype in (BF16, torch.int16, torch.uint16) else 0
+    call('merlot_adamw_step', _p(param), _p(grad), _p(m), _p(v), param.numel(), float(lr), float(beta1), float(beta2),
+         float(eps), float(weight_decay), float(grad_scale), state_bf16, _stream())
+
+
+def probe_mfma32(a, b):
+    d = torch.empty((64, 16), device=a.device, dtype=F32)
+    call('merlot_probe_mfma32', _p(a), _p(b), _p(d), _stream())
+    return d
+
+
+def probe_tr16(tile):
+    out = torch.empty_like(tile)
+    call('merlot_probe_tr16', _p(tile), _p(out), _stream())
+    return out

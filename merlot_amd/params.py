@@ -1,0 +1,270 @@
+"""Parameter arena of the MI355X MERLOT path.
+
+All trainable tensors live in ONE flat fp32 master buffer (and one flat fp32 gradient buffer of the same
+layout) so that the DP gradient all-reduce and the fused AdamW step each run over a few large contiguous
+ranges (RCCL over xGMI is per-link bound: big buckets).  Working copies for the MFMA GEMMs are bf16:
+a straight cast of the whole arena (one launch) plus a transposed copy per Linear (for dgrad).
+
+Names follow the reference's TF variable scopes except that
+  * dense / conv kernels are stored [out, in] (TF: [in, out] / HWIO) and
+  * query/key/value of a layer are fused into `<layer>/qkv/{kernel,bias}` ([3H, H] / [3H]);
+`load_tf_weights` / `export_tf_weights` convert to and from the reference's names and layouts.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import ops
+
+
+class Lin(object):
+    """Handle of one Linear: fp32 master + grad views, bf16 straight ([out,in]) and transposed ([in,out]) copies."""
+    __slots__ = ('name', 'w', 'b', 'gw', 'gb', 'wb', 'wbT', 'ld_wbT')
+
+    def __init__(self, name):
+        self.name = name
+        self.w = self.b = self.gw = self.gb = self.wb = self.wbT = None
+
+
+class LN(object):
+    __slots__ = ('name', 'gamma', 'beta', 'ggamma', 'gbeta')
+
+    def __init__(self, name):
+        self.name = name
+
+
+def _stack_entries(scope, nl, H, I):
+    e = []
+    for l in range(nl):
+        ls = f'{scope}/layer{l:02d}'
+        e += [(f'{ls}/LayerNorm_attn_ln0/gamma', (H,), 'ones'), (f'{ls}/LayerNorm_attn_ln0/beta', (H,), 'zeros'),
+              (f'{ls}/qkv/kernel', (3 * H, H), 'normal'), (f'{ls}/qkv/bias', (3 * H,), 'zeros'),
+              (f'{ls}/context_projection_layer/kernel', (H, H), 'normal'),
+              (f'{ls}/context_projection_layer/bias', (H,), 'zeros'),
+              (f'{ls}/LayerNorm_mlp_ln0/gamma', (H,), 'ones'), (f'{ls}/LayerNorm_mlp_ln0/beta', (H,), 'zeros'),
+              (f'{ls}/intermediate/kernel', (I, H), 'normal'), (f'{ls}/intermediate/bias', (I,), 'zeros'),
+              (f'{ls}/output/kernel', (H, I), 'normal'), (f'{ls}/output/bias', (H,), 'zeros')]
+    e += [(f'{scope}/LayerNorm_ln_final/gamma', (H,), 'ones'), (f'{scope}/LayerNorm_ln_final/beta', (H,), 'zeros')]
+    return e
+
+
+def param_entries(cfg):
+    """[(internal name, shape, init kind)] in arena order."""
+    H, I, V = cfg['hidden_size'], cfg['intermediate_size'], cfg['vocab_size']
+    P = cfg['patch_size']
+    C = cfg.get('contrastive_size', H)
+    ncls = cfg.get('num_cls_emb', 2)
+    vs = 'vision_backbone/vision_transformer'
+    nl_vit = cfg.get('num_vision_transformer_hidden_layers', cfg['num_hidden_layers'])
+    nl_enc = max(cfg['num_hidden_layers'], cfg.get('num_lang_transformer_hidden_layers', 0))
+    e = [(f'{vs}/conv2d/kernel', (H, P * P * 3), 'conv'), (f'{vs}/conv2d/bias', (H,), 'zeros'),
+         (f'{vs}/pos_embs/pos_embs', (1, 64, 64, H), 'normal'), (f'{vs}/pos_embs/cls_emb', (1, ncls, H), 'normal'),
+         (f'{vs}/LayerNorm_ctx_patches_pre_ln/gamma', (H,), 'ones'),
+         (f'{vs}/LayerNorm_ctx_patches_pre_ln/beta', (H,), 'zeros')]
+    e += _stack_entries(vs, nl_vit, H, I)
+    e += [('vision_backbone/img_idx_pe', (cfg.get('max_vision_pos_embeddings', 1024), H), 'normal'),
+          ('vision_backbone/final_pe/pos_embs', (1, 64, 64, H), 'normal'),
+          ('vision_backbone/final_pe/cls_emb', (1, 1, H), 'normal'),
+          ('vision_backbone/LayerNorm_final_ln/gamma', (H,), 'ones'),
+          ('vision_backbone/LayerNorm_final_ln/beta', (H,), 'zeros'),
+          ('word_embeddings/word_embeddings', (V, H), 'normal')]
+    for sc in ['langonly_embeddings', 'position_embeddings']:
+        e += [(f'{sc}/position_embeddings', (cfg['max_position_embeddings'], H), 'normal'),
+              (f'{sc}/LayerNorm_embed_norm/gamma', (H,), 'ones'), (f'{sc}/LayerNorm_embed_norm/beta', (H,), 'zeros')]
+    e += _stack_entries('encoder', nl_enc, H, I)
+    e += [('lm_head/projection/kernel', (H, H), 'normal'), ('lm_head/projection/bias', (H,), 'zeros'),
+          ('lm_head/LayerNorm/gamma', (H,), 'ones'), ('lm_head/LayerNorm/beta', (H,), 'zeros'),
+          ('lm_head/output_bias', (V,), 'zeros')]
+    for nm in ['lang_proj', 'viz_proj']:
+        e += [(f'contrastive/{nm}_intermediate/kernel', (C, H), 'normal'), (f'contrastive/{nm}_intermediate/bias', (C,), 'zeros'),
+              (f'contrastive/LayerNorm_{nm}_ln/gamma', (C,), 'ones'), (f'contrastive/LayerNorm_{nm}_ln/beta', (C,), 'zeros'),
+              (f'contrastive/{nm}/kernel', (C, C), 'normal'), (f'contrastive/{nm}/bias', (C,), 'zeros')]
+    for nm in ['lang_viz_temporal', 'viz_viz_temporal']:
+        e += [(f'{nm}/intermediate/kernel', (H, 2 * H), 'normal'), (f'{nm}/intermediate/bias', (H,), 'zeros'),
+              (f'{nm}/LayerNorm_ln0/gamma', (H,), 'ones'), (f'{nm}/LayerNorm_ln0/beta', (H,), 'zeros'),
+              (f'{nm}/logits/kernel', (4, H), 'normal'), (f'{nm}/logits/bias', (4,), 'zeros')]
+    return e
+
+
+def _align(n, a=64):
+    return (n + a - 1) // a * a
+
+
+class ParamStore(object):
+    def __init__(self, cfg, device, seed=0, init=True):
+        self.cfg = dict(cfg)
+        self.device = torch.device(device)
+        self.entries = param_entries(cfg)
+        self.offsets = OrderedDict()
+        off = 0
+        for name, shape, _ in self.entries:
+            n = int(math.prod(shape))
+            self.offsets[name] = (off, n, tuple(shape))
+            off += _align(n)          # 256-byte aligned starts: every view is 16-B aligned for vector access
+        self.numel = off
+        self.master = torch.zeros(off, device=self.device, dtype=torch.float32)
+        self.grad = torch.zeros(off, device=self.device, dtype=torch.float32)
+        self.bf16 = torch.zeros(off, device=self.device, dtype=torch.bfloat16)
+        self._t = {}            # name -> bf16 transposed copy
+        self._lins = {}
+        self._lns = {}
+        self.version = -1       # bumped by refresh(); compared with master_version
+        self.master_version = 0
+        self.grad_ready_hook = None   # callable(group_name) set by the DP reducer
+        if init:
+            self.reset_parameters(seed)
+
+    # ---- views -------------------------------------------------------------------------------------
+    def p(self, name):
+        o, n, shp = self.offsets[name]
+        return self.master[o:o + n].view(shp)
+
+    def g(self, name):
+        o, n, shp = self.offsets[name]
+        return self.grad[o:o + n].view(shp)
+
+    def b16(self, name):
+        o, n, shp = self.offsets[name]
+        return self.bf16[o:o + n].view(shp)
+
+    def names(self):
+        return list(self.offsets.keys())
+
+    def group_range(self, prefix):
+        """[start, end) of the arena covered by entries whose name starts with `prefix` (must be contiguous)."""
+        idx = [i for i, (n, _, _) in enumerate(self.entries) if n.startswith(prefix)]
+        assert idx and idx == list(range(idx[0], idx[-1] + 1)), f"group {prefix} not contiguous"
+        first = self.offsets[self.entries[idx[0]][0]]
+        last = self.offsets[self.entries[idx[-1]][0]]
+        return first[0], last[0] + _align(last[1])
+
+    def reset_parameters(self, seed=0):
+        g = torch.Generator().manual_seed(seed)
+        std = self.cfg.get('initializer_range', 0.02)
+        for name, shape, kind in self.entries:
+            if kind == 'ones':
+                t = torch.ones(shape)
+            elif kind == 'zeros':
+                t = torch.zeros(shape)
+            elif kind == 'conv':
+                t = torch.randn(shape, generator=g).clamp_(-2, 2) * math.sqrt(1.0 / shape[1])
+            else:
+                t = torch.randn(shape, generator=g).clamp_(-2, 2) * std      # truncated normal, transformer.py:166-168
+            self.p(name).copy_(t)
+        self.master_version += 1
+
+    # ---- bf16 working copies -------------------------------------------------------------------------
+    def refresh(self, force=False):
+        """Re-derive every bf16 working copy from the fp32 masters (call after each optimizer step)."""
+        if self.version == self.master_version and not force:
+            return
+        ops.cast_bf16(self.master, self.bf16)
+        for name, lin in self._lins.items():
+            self._make_transposed(name, lin)
+        self.version = self.master_version
+
+    def _make_transposed(self, name, lin):
+        w = self.p(name)
+        out_dim, in_dim = w.shape
+        if name == 'word_embeddings/word_embeddings':
+            vpad = _align(out_dim, 128)                      # padded reduction dim for the LM-head dgrad
+            t = self._t.get(name)
+            if t is None:
+                t = torch.zeros((in_dim, vpad), device=self.device, dtype=torch.bfloat16)
+                self._t[name] = t
+            ops.cast_transpose_bf16(w, t, ld_dst=vpad)
+        else:
+            t = self._t.get(name)
+            if t is None:
+                t = torch.empty((in_dim, out_dim), device=self.device, dtype=torch.bfloat16)
+                self._t[name] = t
+            ops.cast_transpose_bf16(w, t)
+        lin.wbT = t
+
+    def lin(self, scope, need_T=True, bias=True):
+        """Linear handle for `<scope>/kernel` (+ `<scope>/bias`)."""
+        key = scope + '/kernel' if (scope + '/kernel') in self.offsets else scope
+        h = self._lins.get(key) if need_T else None
+        if h is None:
+            h = Lin(key)
+            h.w, h.gw, h.wb = self.p(key), self.g(key), self.b16(key)
+            bname = scope + '/bias'
+            if bias and bname in self.offsets:
+                h.b, h.gb = self.p(bname), self.g(bname)
+            if need_T:
+                self._lins[key] = h
+                if self.version >= 0:
+                    self._make_transposed(key, h)
+        return h
+
+    def ln(self, scope):
+        h = self._lns.get(scope)
+        if h is None:
+            h = LN(scope)
+            h.gamma, h.beta = self.p(scope + '/gamma'), self.p(scope + '/beta')
+            h.ggamma, h.gbeta = self.g(scope + '/gamma'), self.g(scope + '/beta')
+            self._lns[scope] = h
+        return h
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def notify_ready(self, group):
+        if self.grad_ready_hook is not None:
+            self.grad_ready_hook(group)
+
+    # ---- TF-name interchange ---------------------------------------------------------------------------
+    def load_tf_weights(self, tf_weights):
+        """tf_weights: {TF variable name: tensor in TF layout} (see oracle.merlot_oracle.variable_shapes)."""
+        H = self.cfg['hidden_size']
+        P = self.cfg['patch_size']
+        used = set()
+        for name in self.names():
+            dst = self.p(name)
+            if name.endswith('/qkv/kernel') or name.endswith('/qkv/bias'):
+                base, leaf = name.rsplit('/qkv/', 1)
+                parts = []
+                for nm in ['query_layer', 'key_layer', 'value_layer']:
+                    t = torch.as_tensor(tf_weights[f'{base}/{nm}/{leaf}']).float()
+                    used.add(f'{base}/{nm}/{leaf}')
+                    parts.append(t.t() if leaf == 'kernel' else t)
+                dst.copy_(torch.cat(parts, 0))
+            elif name.endswith('conv2d/kernel'):
+                t = torch.as_tensor(tf_weights[name]).float()            # HWIO [P,P,3,H]
+                used.add(name)
+                dst.copy_(t.reshape(P * P * 3, H).t())
+            elif name.endswith('/kernel'):
+                t = torch.as_tensor(tf_weights[name]).float()            # [in, out]
+                used.add(name)
+                dst.copy_(t.t())
+            else:
+                used.add(name)
+                dst.copy_(torch.as_tensor(tf_weights[name]).float().reshape(dst.shape))
+        self.master_version += 1
+        return sorted(set(tf_weights.keys()) - used)
+
+    def _export(self, getter):
+        H = self.cfg['hidden_size']
+        P = self.cfg['patch_size']
+        out = {}
+        for name in self.names():
+            t = getter(name).detach().float().cpu()
+            if name.endswith('/qkv/kernel') or name.endswith('/qkv/bias'):
+                base, leaf = name.rsplit('/qkv/', 1)
+                for i, nm in enumerate(['query_layer', 'key_layer', 'value_layer']):
+                    part = t[i * H:(i + 1) * H]
+                    out[f'{base}/{nm}/{leaf}'] = part.t().contiguous() if leaf == 'kernel' else part.clone()
+            elif name.endswith('conv2d/kernel'):
+                out[name] = t.t().reshape(P, P, 3, H).contiguous()
+            elif name.endswith('/kernel'):
+                out[name] = t.t().contiguous()
+            else:
+                out[name] = t.clone()
+        return out
+
+    def export_tf_weights(self):
+        return self._export(self.p)
+
+    def export_tf_grads(self):
+        return self._export(self.g)

@@ -1,0 +1,348 @@
+"""TEST-ONLY torch-CPU emulation of merlot_amd.ops (same signatures, same dtype policy).
+
+Lets the CPU test-suite exercise the host logic of merlot_amd (autograd wiring in layers.py, the MerlotModel
+mirror, the parameter arena, the DP reducer) against the oracle without a GPU.  It is NEVER imported by the
+product: merlot_amd.ops has no fallback and raises if libmerlot_hip.so or the GPU is missing.  `install()`
+monkeypatches the functions in merlot_amd.ops for the duration of a test.
+"""
+import math
+
+import numpy as np
+import torch
+
+BF16, F32 = torch.bfloat16, torch.float32
+EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU = 0, 1, 2, 3
+
+
+def _gelu(x):
+    return x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def _gelu_grad(x):
+    return 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+
+
+def gemm_nt(a, bt, *, bias=None, epilogue=EPI_NONE, out=None, out_dtype=BF16, accumulate=False, alpha=1.0,
+            aux_in=None, aux_out=None, dropout_p=0.0, dropout_seed=0, n=None):
+    N = bt.shape[0] if n is None else n
+    v = alpha * (a.float() @ bt[:N].float().t())
+    if bias is not None:
+        v = v + bias[:N]
+    if epilogue == EPI_GELU:
+        if aux_out is not None:
+            aux_out[:, :N] = v.to(BF16)
+        v = _gelu(v)
+    elif epilogue == EPI_DGELU:
+        v = v * _gelu_grad(aux_in[:, :N].float())
+    elif epilogue == EPI_RESIDUAL:
+        assert dropout_p == 0.0, "emulation supports p=0 only"
+        v = v + aux_in[:, :N].float()
+    if out is None:
+        out = torch.empty((a.shape[0], N), dtype=out_dtype)
+        out.copy_(v)
+    elif accumulate:
+        out[:, :N] += v.to(out.dtype)
+    else:
+        out[:, :N] = v.to(out.dtype)
+    return out
+
+
+def gemm_tn(a, b, out, *, accumulate=True, alpha=1.0, m=None, n=None):
+    M = a.shape[1] if m is None else m
+    N = b.shape[1] if n is None else n
+    v = alpha * (a[:, :M].float().t() @ b[:, :N].float())
+    if accumulate:
+        out[:M, :N] += v
+    else:
+        out[:M, :N] = v
+    return out
+
+
+def _patches(image, P):
+    n, H, W, _ = image.shape
+    h1, w1 = H // P, W // P
+    return image.float().reshape(n, h1, P, w1, P, 3).permute(0, 1, 3, 2, 4, 5).reshape(n * h1 * w1, P * P * 3)
+
+
+def patch_embed_fwd(image, wt, bias_folded, patch):
+    return (_patches(image, patch) @ wt.float().t() + bias_folded).to(BF16)
+
+
+def patch_embed_wgrad(image, dy, dwt, patch, accumulate=True):
+    v = dy.float().t() @ _patches(image, patch)
+    if accumulate:
+        dwt += v
+    else:
+        dwt.copy_(v)
+
+
+def ln_fwd(x, gamma, beta, *, out_bf16=True, out_f32=False, save_stats=True, eps=1e-5):
+    xf = x.float()
+    mean = xf.mean(-1, keepdim=True)
+    var = ((xf - mean) ** 2).mean(-1, keepdim=True)
+    rstd = torch.rsqrt(var + eps)
+    sc = rstd * gamma
+    y = xf * sc - mean * sc + beta
+    return (y.to(BF16) if out_bf16 else None, y if out_f32 else None,
+            mean.reshape(-1) if save_stats else None, rstd.reshape(-1) if save_stats else None)
+
+
+def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, dres=None, dx_dtype=None):
+    H = x.shape[-1]
+    xf, dyf = x.float().reshape(-1, H), dy.float().reshape(-1, H)
+    xh = (xf - mean[:, None]) * rstd[:, None]
+    g = dyf * gamma
+    c1 = g.mean(-1, keepdim=True)
+    c2 = (g * xh).mean(-1, keepdim=True)
+    dx = rstd[:, None] * (g - c1 - xh * c2)
+    if dres is not None:
+        dx = dx + dres.float().reshape(-1, H)
+    if dgamma is not None:
+        dgamma += (dyf * xh).sum(0)
+    if dbeta is not None:
+        dbeta += dyf.sum(0)
+    return dx.to(dx_dtype or x.dtype).reshape(x.shape)
+
+
+def _attn_probs(qkv, B, S, heads, valid):
+    H = heads * 64
+    q = qkv[:, :H].float().reshape(B, S, heads, 64).permute(0, 2, 1, 3)
+    k = qkv[:, H:2 * H].float().reshape(B, S, heads, 64).permute(0, 2, 1, 3)
+    v = qkv[:, 2 * H:3 * H].float().reshape(B, S, heads, 64).permute(0, 2, 1, 3)
+    s = (q @ k.transpose(-1, -2)) * 0.125
+    if valid is not None:
+        vb = valid.bool()
+        m = (vb[:, None, :, None] & vb[:, None, None, :]).float()
+        s = s * m - 1e10 * (1 - m)
+        s = torch.where(vb[:, None, :, None], s, torch.zeros_like(s))     # padded query rows: score 0 (uniform)
+    return q, k, v, s
+
+
+def attention_fwd(qkv, B, S, heads, valid=None, need_lse=True):
+    q, k, v, s = _attn_probs(qkv, B, S, heads, valid)
+    lse = torch.logsumexp(s, -1)
+    p = torch.exp(s - lse[..., None])
+    o = (p.to(BF16).float() @ v).permute(0, 2, 1, 3).reshape(B * S, heads * 64)
+    return o.to(BF16), (lse if need_lse else None)
+
+
+def attention_bwd(qkv, out, dout, lse, B, S, heads, valid=None):
+    qkv_f = qkv.float().detach().requires_grad_(True)
+    with torch.enable_grad():
+        q, k, v, s = _attn_probs(qkv_f, B, S, heads, valid)
+        p = torch.softmax(s, -1)
+        o = (p @ v).permute(0, 2, 1, 3).reshape(B * S, heads * 64)
+    (g,) = torch.autograd.grad(o, qkv_f, dout.float())
+    return g.to(BF16)
+
+
+def attention_colsum(qkv, lse, B, S, heads, colsum_lo, colsum_hi=None, *, qsplit=None, valid=None, valid_q_only=False,
+                     weight=1.0):
+    q, k, v, s = _attn_probs(qkv, B, S, heads, valid)
+    p = torch.exp(s - lse[..., None])                      # [B, h, q, key]
+    if valid_q_only and valid is not None:
+        vb = valid.bool()
+        p = p * (vb[:, None, :, None] & vb[:, None, None, :]).float()
+    qs = S if qsplit is None else qsplit
+    if colsum_lo is not None:
+        colsum_lo += weight * p[:, :, :qs].sum((1, 2))
+    if colsum_hi is not None:
+        colsum_hi += weight * p[:, :, qs:].sum((1, 2))
+
+
+def cast_bf16(src, dst=None):
+    if dst is None:
+        return src.to(BF16)
+    dst.copy_(src)
+    return dst
+
+
+def cast_transpose_bf16(src, dst=None, ld_dst=None):
+    if dst is None:
+        return src.t().contiguous().to(BF16)
+    dst[:, :src.shape[0]] = src.t()
+    return dst
+
+
+def colsum_bf16(x, out, accumulate=True, n=None):
+    N = x.shape[1] if n is None else n
+    v = x[:, :N].float().sum(0)
+    if accumulate:
+        out[:N] += v
+    else:
+        out[:N] = v
+
+
+def gather_add4(rows, H, a=None, ia=None, b=None, ib=None, c=None, ic=None, d=None, id_=None):
+    out = torch.zeros((rows, H), dtype=F32)
+    for t, idx in ((a, ia), (b, ib), (c, ic), (d, id_)):
+        if t is None:
+            continue
+        t2 = t.reshape(-1, H).float()
+        if idx is None:
+            out += t2[:rows]
+        else:
+            ok = idx >= 0
+            out[ok] += t2[idx[ok].long()]
+    return out
+
+
+def scatter_add_rows(src, idx, table):
+    H = src.shape[-1]
+    s2 = src.reshape(-1, H)
+    t2 = table.reshape(-1, H)
+    if idx is None:
+        t2[:s2.shape[0]] += s2
+    else:
+        ok = idx >= 0
+        t2.index_add_(0, idx[ok].long(), s2[ok])
+
+
+def dropout_apply(x, p, seed):
+    assert p == 0.0
+    return x.clone()
+
+
+def cls_avgpool_fwd(x, n_img, h1, w1, cls_skip, pool):
+    H = x.shape[-1]
+    x3 = x.float().reshape(n_img, cls_skip + h1 * w1, H)
+    grid = x3[:, cls_skip:].reshape(n_img, h1, w1, H).permute(0, 3, 1, 2)
+    pooled = torch.nn.functional.avg_pool2d(grid, pool, pool).permute(0, 2, 3, 1).reshape(n_img, -1, H)
+    return torch.cat([x3[:, :1], pooled], 1).contiguous()
+
+
+def cls_avgpool_bwd(dout, n_img, h1, w1, cls_skip, pool):
+    H = dout.shape[-1]
+    h2, w2 = h1 // pool, w1 // pool
+    dx = torch.zeros((n_img, cls_skip + h1 * w1, H))
+    dx[:, 0] = dout[:, 0]
+    g = dout[:, 1:].reshape(n_img, h2, w2, H) / (pool * pool)
+    g = g.repeat_interleave(pool, 1).repeat_interleave(pool, 2)
+    dx[:, cls_skip:] = g.reshape(n_img, h1 * w1, H)
+    return dx.to(BF16)
+
+
+def softmax_ce(logits, labels, C, *, rowscale=None, dlogits_dtype=None, ld_dl=None, want_argmax=True):
+    lg = logits[:, :C].float()
+    lse = torch.logsumexp(lg, -1)
+    lab = labels.long()
+    loss = lse - lg.gather(1, lab[:, None])[:, 0]
+    am = lg.argmax(-1).int() if want_argmax else None
+    dl = None
+    if dlogits_dtype is not None:
+        ld_dl = ld_dl or logits.shape[1]
+        g = torch.exp(lg - lse[:, None])
+        g[torch.arange(lg.shape[0]), lab] -= 1.0
+        if rowscale is not None:
+            g = g * rowscale[:, None]
+        dl = torch.zeros((lg.shape[0], ld_dl), dtype=dlogits_dtype)
+        dl[:, :C] = g.to(dlogits_dtype)
+    return loss, am, dl
+
+
+def l2norm_fwd(x):
+    inv = torch.rsqrt(torch.clamp((x * x).sum(-1), min=1e-12))
+    return x * inv[:, None], inv
+
+
+def l2norm_bwd(dy, y, inv):
+    dot = (dy * y).sum(-1, keepdim=True)
+    return inv[:, None] * (dy - y * dot)
+
+
+def gelu_fwd(x):
+    return _gelu(x)
+
+
+def gelu_bwd(dy, x):
+    return dy * _gelu_grad(x)
+
+
+def mask_inputs(ids, summs, gumbel, span_lower, span_upper, random_ids, option, num_topk, num_to_mask, w_nontopk, w_topk,
+                log_nontopk, log_topk, max_weight, mask_token=1):
+    """numpy transcription of csrc/index.hip::mask_inputs_kernel (NOT the oracle) so CPU tests can check the
+    kernel's algorithm (rank-by-counting etc.) against oracle/index_oracle.py."""
+    ids_n = ids.numpy().astype(np.int32)
+    B, L = ids_n.shape
+    nm = num_to_mask
+    out_ids = np.zeros_like(ids_n)
+    out_idx = np.zeros((B, nm), np.int32)
+
+    def desc_rank(v):
+        return np.array([int(np.sum((v > v[l]) | ((v == v[l]) & (np.arange(L) < l)))) for l in range(L)])
+
+    f32 = np.float32
+    for b in range(B):
+        sp = (ids_n[b] < 100).astype(f32)
+        if summs is not None:
+            key = summs[b].numpy().astype(f32) * (f32(1) - sp)
+            important = desc_rank(key) < num_topk
+        else:
+            important = np.zeros(L, bool)
+        weight = np.where(important, f32(w_topk), f32(w_nontopk)).astype(f32)
+        log_mask = np.where(important, f32(log_topk), f32(log_nontopk)).astype(f32) - f32(1e8) * sp
+        key = (log_mask + gumbel[b].numpy().astype(f32)).astype(f32)
+        r = desc_rank(key)
+        sel = np.zeros(nm, np.int64)
+        for l in range(L):
+            if r[l] < nm:
+                sel[nm - 1 - r[l]] = l
+        if span_lower is not None:
+            start = sel - span_lower[b].numpy()
+            end = sel + span_upper[b].numpy()
+            wm = np.zeros(L, f32)
+            for l in range(L):
+                first = 0
+                for k in range(nm):
+                    if start[k] <= l <= end[k]:
+                        first = k
+                        break
+                wm[l] = f32(first) * (f32(1) - sp[l])
+                wm[l] = wm[l] + (f32(0.5) * weight[l]) / f32(max_weight)
+            do = desc_rank(wm) < nm
+        else:
+            do = np.zeros(L, bool)
+            do[sel] = True
+        opt = option[b].numpy() * do.astype(np.int32)
+        out_ids[b] = np.where(opt == 0, ids_n[b], np.where(opt == 1, mask_token, random_ids[b].numpy()))
+        out_idx[b] = np.nonzero(do)[0][:nm]
+    return torch.from_numpy(out_ids), torch.from_numpy(out_idx)
+
+
+def temporal_labels(video_src_ids, shuffled_idx, B, n):
+    v = video_src_ids.reshape(B, n)
+    s = shuffled_idx.reshape(B, n)
+    a = torch.arange(n)[:, None].expand(n, n)
+    c = torch.arange(n)[None].expand(n, n)
+    base = (a == c).int() + 2 * (a < c).int() + 3 * (a > c).int()
+    same = v[:, :, None] == v[:, None]
+    labels = torch.where(same, base[None], torch.zeros_like(base)[None]).reshape(-1).int()
+    easy = (s < 64)
+    e2 = easy[:, :, None] & easy[:, None]
+    w = (~e2).float() * np.float32(0.99) + np.float32(0.01)
+    return labels, w.reshape(-1).float()
+
+
+def shuffled_idx(num_shuffle, u_select, u_perm, B, n, offset=16):
+    us, up = u_select.reshape(B, n), u_perm.reshape(B, n)
+    sel = torch.argsort(us, 1, stable=True)
+    perm = torch.argsort(up, 1, stable=True)
+    do = sel < num_shuffle[:, None]
+    return torch.where(do, offset + perm, torch.arange(n)[None].expand(B, n)).reshape(-1).int()
+
+
+def adamw_step(param, grad, m, v, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0):
+    raise NotImplementedError("adamw emulation lives in tests/test_optimizer.py")
+
+
+_NAMES = ['gemm_nt', 'gemm_tn', 'patch_embed_fwd', 'patch_embed_wgrad', 'ln_fwd', 'ln_bwd', 'attention_fwd',
+          'attention_bwd', 'attention_colsum', 'cast_bf16', 'cast_transpose_bf16', 'colsum_bf16', 'gather_add4',
+          'scatter_add_rows', 'dropout_apply', 'cls_avgpool_fwd', 'cls_avgpool_bwd', 'softmax_ce', 'l2norm_fwd',
+          'l2norm_bwd', 'gelu_fwd', 'gelu_bwd', 'mask_inputs', 'temporal_labels', 'shuffled_idx']
+
+
+def install(monkeypatch):
+    import merlot_amd.ops as real
+    g = globals()
+    for nm in _NAMES:
+        monkeypatch.setattr(real, nm, g[nm])
