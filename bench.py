@@ -1,0 +1,157 @@
+#!/usr/bin/env python
+"""bench.py -- MERLOT pretraining step throughput on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+One "step" = one full training step of BASELINE config #2/#3 on one batch of synthetic frame-caption segments
+already resident in HBM: patch-embed ViT-B/16 (12 L) over every frame, 12-L text-only pass, attention-guided
+masking, 12-L joint encoder, MLM + contrastive + temporal heads, backward, DP gradient all-reduce (RCCL, overlapped),
+fused AdamW.  bf16 MFMA compute / fp32 master weights, dropout 0.1 on (merlot.yaml), nothing skipped.
+Prints ONE JSON line on rank 0; value = whole-job segments/s.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+TRAIN_GFLOP_PER_SEGMENT = 170.4          # 56.79 fwd x 3, num_chunks=16, 224^2, n=4
+PEAK_BF16_TFLOPS = 2500.0                # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(config, seconds_budget=25.0):
+    """The reference's CPU path, timed as the oracle restatement (fp32, unfused, torch-CPU on all host cores) on a
+    bounded sample of the same workload: ONE example of 4 segments at 224^2 with the full 12+12+12-layer model,
+    forward+backward (no optimizer), median of the timed steps."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from common import synth_batch
+    from oracle import merlot_oracle as mo
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = dict(config.model)
+    cfg['hidden_dropout_prob'] = 0.0
+    w = mo.init_weights(cfg, 0, perturb=False)
+    for t in w.values():
+        t.requires_grad_(True)
+    b = synth_batch(cfg, E=1, num_chunks=4, seed=3, two_videos=False)
+    times = []
+    t_start = time.time()
+    for it in range(4):
+        for t in w.values():
+            t.grad = None
+        t0 = time.time()
+        m = mo.MerlotOracle(cfg, w, b['image'], b['input_ids'], mask_input=True, shuffled_idx_img=b['shuffled_idx_img'],
+                            noise=b['noise'])
+        loss, _ = m.total_loss(b['shuffled_idx_img'], b['video_src_ids'])
+        loss.backward()
+        dt = time.time() - t0
+        if it > 0:
+            times.append(dt)
+        if time.time() - t_start > seconds_budget and times:
+            break
+    med = float(np.median(times))
+    return {'value': 4.0 / med, 'unit': 'segments/s', 'cores': cores, 'kind': 'port',
+            'sample': f'oracle (torch-CPU fp32, unfused) fwd+bwd, 1 example x 4 segments @224^2, 12+12+12 layers, '
+                      f'median of {len(times)} steps after 1 warm-up ({med:.2f} s/step)'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--examples', type=int, default=16, help='examples (x16 segments) per GPU per step')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from merlot_amd import NeatConfig, ops
+    from merlot_amd.parallel import DistContext
+    from merlot_amd.train import Trainer, synthetic_batch
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    ctx = None
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+        ctx = DistContext()
+
+    config = NeatConfig.from_yaml(os.path.join(ROOT, 'merlot_amd', 'configs', 'pretrain_4seg_224.yaml'))
+    trainer = Trainer(config, device, ctx, seed=0)
+    batch = synthetic_batch(config, args.examples, device, seed=1234 + rank)
+    seg_per_gpu = args.examples * config.data['num_chunks']
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = trainer.step(batch)
+    timer = None
+    if not args.no_kernel_timing:
+        timer = ops.KernelTimer()
+        ops.TIMER = timer
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = trainer.step(batch)
+    sync()
+    elapsed = time.perf_counter() - t0
+    ops.TIMER = None
+    loss = float(out['loss'])
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        value = world * seg_per_gpu * args.steps / elapsed
+        res = {
+            'metric': 'frame-caption segments/sec/node (4-seg, 224^2, bf16)', 'value': value, 'unit': 'segments/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': 'merlot.yaml 4-segment full ViT-B/16 (patch stem) + 12-layer joint + 12-layer text-only, '
+                                   '224^2 frames, 32-token captions, fwd+bwd+DP all-reduce+AdamW, dropout 0.1',
+                       'segments_per_gpu_per_step': seg_per_gpu, 'examples_per_gpu': args.examples,
+                       'num_chunks': config.data['num_chunks'], 'parallelism': f'dp{world}', 'grad_reduce': 'sum',
+                       'final_loss': loss},
+            'model_flops_utilization': value * TRAIN_GFLOP_PER_SEGMENT / 1e3 / (world * PEAK_BF16_TFLOPS),
+        }
+        if timer is not None:
+            summ = timer.summary()
+            f, t, n = summ.get('gemm_nt', (0.0, 1.0, 0))
+            res['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_nt_kernel (bf16 MFMA 32x32x16, all epilogues)',
+                               'achieved': f / t / 1e12, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+                               'frac': f / t / 1e12 / PEAK_BF16_TFLOPS, 'traffic': None, 'launches': n,
+                               'avg_launch_us': 1e6 * t / max(n, 1), 'gflop_per_launch': f / max(n, 1) / 1e9,
+                               'share_of_step_time': t / elapsed}
+            if 'gemm_tn' in summ:
+                f2, t2, n2 = summ['gemm_tn']
+                res['roofline_wgrad'] = {'kernel': 'gemm_tn_kernel', 'achieved': f2 / t2 / 1e12, 'unit': 'TFLOP/s',
+                                         'frac': f2 / t2 / 1e12 / PEAK_BF16_TFLOPS, 'launches': n2,
+                                         'share_of_step_time': t2 / elapsed}
+        if world == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(config)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -12,6 +12,32 @@ BF16 = torch.bfloat16
 F32 = torch.float32
 
 
+class KernelTimer(object):
+    """Optional per-kernel HIP-event timing (bench.py roofline): set ops.TIMER = KernelTimer() and every gemm_nt
+    launch is bracketed by events on the launch stream; .summary() -> (flops, seconds, launches) per key."""
+
+    def __init__(self):
+        self.records = []
+
+    def time(self, key, flops, fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        self.records.append((key, flops, e0, e1))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for key, flops, e0, e1 in self.records:
+            f, t, n = out.get(key, (0.0, 0.0, 0))
+            out[key] = (f + flops, t + e0.elapsed_time(e1) * 1e-3, n + 1)
+        return out
+
+
+TIMER = None
+
+
 def _p(t):
     return None if t is None else t.data_ptr()
 
@@ -42,10 +68,17 @@ def gemm_nt(a, bt, *, bias=None, epilogue=EPI_NONE, out=None, out_dtype=BF16, ac
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=out_dtype)
     _chk(out, out.dtype, 'out')
-    call('merlot_gemm_bf16_nt', _p(a), a.stride(0), _p(bt), bt.stride(0), _p(out), out.stride(0), M, N, K, float(alpha),
-         int(epilogue), 1 if out.dtype == F32 else 0, 1 if accumulate else 0, _p(bias), _p(aux_in),
-         aux_in.stride(0) if aux_in is not None else 0, _p(aux_out), aux_out.stride(0) if aux_out is not None else 0,
-         float(dropout_p), int(dropout_seed) & 0xFFFFFFFFFFFFFFFF, _stream())
+
+    def launch():
+        call('merlot_gemm_bf16_nt', _p(a), a.stride(0), _p(bt), bt.stride(0), _p(out), out.stride(0), M, N, K,
+             float(alpha), int(epilogue), 1 if out.dtype == F32 else 0, 1 if accumulate else 0, _p(bias), _p(aux_in),
+             aux_in.stride(0) if aux_in is not None else 0, _p(aux_out), aux_out.stride(0) if aux_out is not None else 0,
+             float(dropout_p), int(dropout_seed) & 0xFFFFFFFFFFFFFFFF, _stream())
+
+    if TIMER is not None:
+        TIMER.time('gemm_nt', 2.0 * M * N * K, launch)
+    else:
+        launch()
     return out
 
 
@@ -55,8 +88,14 @@ def gemm_tn(a, b, out, *, accumulate=True, alpha=1.0, m=None, n=None):
     R = a.shape[0]
     M = a.shape[1] if m is None else m
     N = b.shape[1] if n is None else n
-    call('merlot_gemm_bf16_tn', _p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, R, float(alpha),
-         1 if accumulate else 0, _stream())
+    def launch():
+        call('merlot_gemm_bf16_tn', _p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, R,
+             float(alpha), 1 if accumulate else 0, _stream())
+
+    if TIMER is not None:
+        TIMER.time('gemm_tn', 2.0 * M * N * R, launch)
+    else:
+        launch()
     return out
 
 

@@ -1,0 +1,91 @@
+"""Mirror of utils/optimization.py: `build_optimizer_from_config` -> AdamW with bias correction, warm-up + linear
+decay, regex `param_overrides`, and (use_bfloat16_adam) bf16 m / sign-bit-encoded bf16 v -- as ONE fused HBM-bound
+kernel (merlot_adamw_step) per run of identically-configured parameters in the flat arena."""
+import math
+import re
+
+import torch
+
+from . import ops
+
+# internal (fused) names -> the TF names the reference's regexes see
+_TF_ALIASES = {'/qkv/': '/query_layer/'}
+
+
+def learning_rate_scale(step, num_train_steps, num_warmup_steps):
+    """utils/optimization.py:94-115 (note the `+ 1.0` in base_scale, kept)."""
+    base_scale = float(num_train_steps) / (float(num_train_steps) - float(num_warmup_steps) + 1.0) if num_warmup_steps else 1.0
+    s = min(step, num_train_steps)
+    scale = base_scale * (1.0 - s / float(num_train_steps))           # polynomial_decay power=1, end 0
+    if num_warmup_steps and step < num_warmup_steps:
+        scale = float(step) / float(num_warmup_steps)
+    return scale
+
+
+class AdamOptimizer(object):
+    def __init__(self, store, learning_rate, num_train_steps, num_warmup_steps, weight_decay_rate=1e-4,
+                 param_overrides=None, epsilon=1e-6, beta_1=0.9, beta_2=0.98, use_bfloat16_adam=False, clip_norm=0.0,
+                 grad_reduce='sum', world_size=1, **_ignored):
+        if clip_norm and clip_norm > 0.0:
+            raise NotImplementedError("clip_norm > 0 is not implemented (merlot.yaml uses 0.0)")
+        self.store = store
+        self.lr, self.nts, self.nws = learning_rate, num_train_steps, num_warmup_steps
+        self.eps, self.b1, self.b2 = epsilon, beta_1, beta_2
+        self.step_count = 0
+        self.grad_scale = 1.0 / world_size if grad_reduce == 'mean' else 1.0
+        sd = torch.bfloat16 if use_bfloat16_adam else torch.float32
+        self.m = torch.zeros(store.numel, device=store.device, dtype=sd)
+        self.v = torch.zeros(store.numel, device=store.device, dtype=sd)
+        # per-parameter hyper-parameters (utils/optimization.py:125-151), then merge neighbours with equal settings
+        runs = []
+        for name, (off, n, _) in store.offsets.items():
+            tf_name = name
+            for a, b in _TF_ALIASES.items():
+                tf_name = tf_name.replace(a, b)
+            hp = {'learning_rate': learning_rate, 'weight_decay_rate': weight_decay_rate}
+            for regexes, over in (param_overrides or []):
+                if any(re.search(rx, tf_name) is not None for rx in regexes):
+                    for k, v in over.items():
+                        if k not in ('learning_rate', 'weight_decay_rate', 'beta_1', 'beta_2', 'epsilon', 'do_factor'):
+                            raise ValueError(f"Regex rule {regexes} -> {over} isn't OK because {k} isn't a changable optimization parameter")
+                        hp[k] = v
+            key = (float(hp['weight_decay_rate']), float(hp['learning_rate']))      # :347-351
+            end = off + (n + 63) // 64 * 64
+            if runs and runs[-1][2] == key and runs[-1][1] == off:
+                runs[-1][1] = end
+            else:
+                runs.append([off, end, key])
+        self.runs = runs
+
+    def current_lr(self):
+        return self.lr * learning_rate_scale(self.step_count, self.nts, self.nws)
+
+    def step(self):
+        t = self.step_count + 1.0                                    # utils/optimization.py:354-358
+        bc1 = 1.0 - math.pow(self.b1, t)
+        bc2 = 1.0 - math.pow(self.b2, t)
+        mult = learning_rate_scale(self.step_count, self.nts, self.nws) * math.sqrt(bc2) / bc1
+        st = self.store
+        for s, e, (wd, lr_p) in self.runs:
+            if lr_p == 0.0:                                          # frozen parameters (:149-157)
+                continue
+            ops.adamw_step(st.master[s:e], st.grad[s:e], self.m[s:e], self.v[s:e], lr_p * mult, self.b1, self.b2,
+                           self.eps, wd, self.grad_scale)
+        self.step_count += 1
+        st.master_version += 1
+
+
+def build_optimizer_from_config(store, optimizer_config, device_config=None, **extra):
+    """utils/optimization.py:11-30."""
+    kwargs = dict(optimizer_config)
+    if device_config is not None:
+        kwargs.update({k: v for k, v in device_config.items() if k in ('use_tpu',)})
+    typ = kwargs.pop('type')
+    if typ != 'adam_optimizer':
+        raise ValueError("The optimizer type {} isn't supported".format(typ))
+    if kwargs.pop('adafactor', False):
+        raise ValueError("Adafactor not supported rn")
+    kwargs.pop('use_tpu', None)
+    kwargs.pop('verbose', None)
+    kwargs.update(extra)
+    return AdamOptimizer(store, **kwargs)

@@ -1,0 +1,66 @@
+"""Step loop of the MI355X MERLOT path (the role of model/train.py + TPUEstimator.train in the reference):
+forward (ViT, text-only, joint, three heads) -> backward (grads accumulate into the flat arena, per-layer all-reduce
+buckets launched from inside the backward) -> fused AdamW."""
+import numpy as np
+import torch
+
+from .modeling import model_fn_builder, draw_mask_noise
+from .optimization import build_optimizer_from_config
+from .parallel import GradReducer
+from .params import ParamStore
+
+
+def synthetic_batch(config, examples, device, seed=1234, num_chunks=None):
+    """Synthetic inputs of SURVEY.md 8(d): frames U[0,1) bf16, captions START + 8..31 tokens + padding, one video per
+    example, shuffled_idx_img from the model/dataloader.py:224-257 generator, explicit masking noise."""
+    from . import ops
+    m = config.model
+    nc = num_chunks or config.data['num_chunks']
+    Lc = config.data.get('chunk_text_len', 32)
+    n = m['num_chunks_in_group']
+    H, W = m['image_size']
+    g = torch.Generator().manual_seed(seed)
+    N = examples * nc
+    images = torch.rand((N, H, W, 3), generator=g, dtype=torch.float32).to(torch.bfloat16).to(device)
+    lens = torch.randint(8, Lc, (examples, nc), generator=g)
+    ids = torch.randint(100, 50354, (examples, nc, Lc), generator=g)
+    ids[:, :, 0] = 2
+    ids = torch.where(torch.arange(Lc)[None, None] < lens[..., None], ids, torch.zeros_like(ids)).int().to(device)
+    B = N // n
+    p = m.get('image_shuffle_prob', 0.5)
+    probs = torch.tensor([1.0 - p, 1e-6] + [p / (n - 1)] * (n - 1), dtype=torch.float64)
+    num_shuffle = torch.multinomial(probs, B, replacement=True, generator=g).int().to(device)
+    u_sel = torch.rand((B, n), generator=g).to(device)
+    u_perm = torch.rand((B, n), generator=g).to(device)
+    sidx = ops.shuffled_idx(num_shuffle, u_sel, u_perm, B, n, 16)
+    noise = draw_mask_noise(B, Lc * n, m, m['vocab_size'], g)
+    noise = {k: v.to(device) for k, v in noise.items()}
+    return {'images': images, 'input_ids': ids, 'shuffled_idx_img': sidx,
+            'video_src_ids': torch.zeros((examples, nc), dtype=torch.int32, device=device), 'noise': noise}
+
+
+class Trainer(object):
+    def __init__(self, config, device, dist_ctx=None, seed=0, grad_reduce='sum'):
+        self.config = config
+        self.device = torch.device(device)
+        self.dist = dist_ctx
+        self.store = ParamStore(config.model, self.device, seed=seed)
+        world = dist_ctx.world_size if dist_ctx is not None else 1
+        self.opt = build_optimizer_from_config(self.store, config.optimizer, world_size=world, grad_reduce=grad_reduce)
+        self.model_fn = model_fn_builder(config)
+        self.reducer = None
+        if dist_ctx is not None and world > 1:
+            # encoder weights receive gradients from the joint AND the text-only pass before they may be reduced
+            self.reducer = GradReducer(self.store, dist_ctx,
+                                       expected_passes={'encoder': 2, 'encoder/LayerNorm_ln_final': 2, '*': 1})
+        self.step_idx = 0
+
+    def step(self, features):
+        self.store.zero_grad()
+        out = self.model_fn(features, None, 'train', {'store': self.store, 'dist': self.dist, 'seed': self.step_idx + 1})
+        out['loss'].backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        self.opt.step()
+        self.step_idx += 1
+        return out

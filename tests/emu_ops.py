@@ -325,8 +325,8 @@ def temporal_labels(video_src_ids, shuffled_idx, B, n):
 
 def shuffled_idx(num_shuffle, u_select, u_perm, B, n, offset=16):
     us, up = u_select.reshape(B, n), u_perm.reshape(B, n)
-    sel = torch.argsort(us, 1, stable=True)
-    perm = torch.argsort(up, 1, stable=True)
+    sel = torch.argsort(us, dim=1, stable=True)
+    perm = torch.argsort(up, dim=1, stable=True)
     do = sel < num_shuffle[:, None]
     return torch.where(do, offset + perm, torch.arange(n)[None].expand(B, n)).reshape(-1).int()
 

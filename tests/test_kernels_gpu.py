@@ -1,0 +1,292 @@
+"""GPU parity of every HIP kernel (through the C-ABI via merlot_amd.ops) against the plain torch-CPU fp32
+restatement of the same op in tests/emu_ops.py, on seeded inputs.  Tolerances (bf16 in/out, fp32 accumulate):
+rel-L2 <= 6e-3 for bf16 outputs, <= 2e-3 for fp32 outputs of bf16 inputs; integer outputs exact."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import emu_ops as E
+from common import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+@pytest.fixture(scope='module')
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from merlot_amd import ops as o
+    from merlot_amd.lib import LIB
+    LIB.load()          # fail loudly if libmerlot_hip.so is missing
+    return o
+
+
+def rnd(shape, gen, scale=1.0, dtype=BF16):
+    return (torch.randn(shape, generator=gen) * scale).to(dtype)
+
+
+def dev(*ts):
+    return [None if t is None else t.cuda() for t in ts]
+
+
+# ---- hardware layout probes: pin the lane maps the kernels assume ---------------------------------------
+def test_probe_mfma32_layout(ops):
+    g = torch.Generator().manual_seed(0)
+    A = torch.randint(-3, 4, (32, 16), generator=g).float()      # asymmetric small ints: exact in bf16
+    Bm = torch.randint(-3, 4, (16, 32), generator=g).float()
+    lanes = torch.arange(64)
+    a = torch.stack([A[lanes & 31, 8 * (lanes >> 5) + j] for j in range(8)], 1).to(BF16)     # A[l&31][8(l>>5)+j]
+    b = torch.stack([Bm[8 * (lanes >> 5) + j, lanes & 31] for j in range(8)], 1).to(BF16)    # B[8(l>>5)+j][l&31]
+    d = ops.probe_mfma32(a.cuda().contiguous(), b.cuda().contiguous()).cpu()
+    ref = A @ Bm
+    got = torch.zeros(32, 32)
+    for l in range(64):
+        for r in range(16):
+            got[(r & 3) + 8 * (r >> 2) + 4 * (l >> 5), l & 31] = d[l, r]
+    assert torch.equal(got, ref), "MFMA 32x32x16 operand/accumulator lane map differs from the one the kernels assume"
+
+
+def test_probe_tr16_layout(ops):
+    tile = torch.arange(256).to(BF16)          # 0..255 exactly representable
+    out = ops.probe_tr16(tile.cuda()).cpu().float().reshape(64, 4)
+    exp = torch.zeros(64, 4)
+    for l in range(64):
+        gi, i = l >> 4, l & 15
+        for j in range(4):
+            exp[l, j] = gi * 64 + j * 16 + i   # column i of the 4x16 row-major block of lane group gi
+    assert torch.equal(out, exp), f"ds_read_b64_tr_b16 gather differs from the assumed map:\n{out[:20]}"
+
+
+# ---- GEMM ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 768), (200, 130, 128), (4000, 768, 768), (37, 4, 768),
+                                   (1024, 2304, 768), (512, 768, 3072)])
+def test_gemm_nt_plain(ops, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    a, bt = rnd((M, K), g), rnd((N, K), g, 0.05)
+    bias = torch.randn(N, generator=g) * 0.1
+    ref = E.gemm_nt(a, bt, bias=bias, out_dtype=F32)
+    got = ops.gemm_nt(*dev(a, bt), bias=bias.cuda())
+    assert rel_l2(got, ref) < 6e-3
+    got32 = ops.gemm_nt(*dev(a, bt), bias=bias.cuda(), out_dtype=F32, alpha=0.5)
+    assert rel_l2(got32, E.gemm_nt(a, bt, bias=bias, out_dtype=F32, alpha=0.5)) < 2e-5 * math.sqrt(K) + 1e-4
+
+
+def test_gemm_nt_epilogues(ops):
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 300, 768, 768
+    a, bt = rnd((M, K), g), rnd((N, K), g, 0.05)
+    bias = torch.randn(N, generator=g) * 0.1
+    res = rnd((M, N), g)
+    # gelu (+ pre-activation side output)
+    u_ref = torch.empty((M, N), dtype=BF16)
+    ref = E.gemm_nt(a, bt, bias=bias, epilogue=E.EPI_GELU, aux_out=u_ref, out_dtype=F32)
+    u = torch.empty((M, N), dtype=BF16).cuda()
+    got = ops.gemm_nt(*dev(a, bt), bias=bias.cuda(), epilogue=ops.EPI_GELU, aux_out=u)
+    assert rel_l2(got, ref) < 6e-3 and rel_l2(u, u_ref) < 6e-3
+    # residual
+    ref = E.gemm_nt(a, bt, bias=bias, epilogue=E.EPI_RESIDUAL, aux_in=res, out_dtype=F32)
+    got = ops.gemm_nt(*dev(a, bt), bias=bias.cuda(), epilogue=ops.EPI_RESIDUAL, aux_in=res.cuda())
+    assert rel_l2(got, ref) < 6e-3
+    # dgelu
+    ref = E.gemm_nt(a, bt, epilogue=E.EPI_DGELU, aux_in=res, out_dtype=F32)
+    got = ops.gemm_nt(*dev(a, bt), epilogue=ops.EPI_DGELU, aux_in=res.cuda())
+    assert rel_l2(got, ref) < 6e-3
+    # f32 accumulate into a padded-ld output
+    out = torch.ones((M, 772), dtype=F32).cuda()
+    ops.gemm_nt(*dev(a, bt), out=out, accumulate=True, n=N)
+    ref = 1.0 + E.gemm_nt(a, bt, out_dtype=F32)
+    assert rel_l2(out[:, :N], ref) < 1e-3 and torch.all(out[:, N:] == 1.0)
+
+
+def test_gemm_nt_dropout_statistics(ops):
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 512, 768, 64
+    a, bt = rnd((M, K), g), rnd((N, K), g)
+    res = torch.zeros((M, N), dtype=BF16)
+    full = ops.gemm_nt(*dev(a, bt), epilogue=ops.EPI_RESIDUAL, aux_in=res.cuda()).float()
+    d1 = ops.gemm_nt(*dev(a, bt), epilogue=ops.EPI_RESIDUAL, aux_in=res.cuda(), dropout_p=0.1, dropout_seed=77).float()
+    d2 = ops.gemm_nt(*dev(a, bt), epilogue=ops.EPI_RESIDUAL, aux_in=res.cuda(), dropout_p=0.1, dropout_seed=77).float()
+    assert torch.equal(d1, d2)                                     # counter-based: reproducible
+    kept = d1 != 0
+    keep_rate = kept.float().mean().item()
+    assert abs(keep_rate - 0.9) < 5e-3
+    assert rel_l2(d1[kept], full[kept] / 0.9) < 1e-2               # survivors scaled by 1/(1-p)
+    # the standalone mask kernel regenerates the same mask (used by the backward)
+    y = ops.dropout_apply(torch.ones((M, N), dtype=BF16).cuda(), 0.1, 77).float()
+    assert torch.equal(y != 0, kept | (full == 0))
+
+
+@pytest.mark.parametrize("R,M,N", [(64, 128, 128), (1000, 768, 768), (777, 2304, 768), (300, 50370, 768), (5000, 768, 3072),
+                                   (130, 4, 768)])
+def test_gemm_tn(ops, R, M, N):
+    g = torch.Generator().manual_seed(R + M)
+    a, b = rnd((R, M + (M % 8 and 8 - M % 8)), g)[:, :], rnd((R, N), g)
+    ref = E.gemm_tn(a, b, torch.zeros((M, N)), accumulate=False, m=M)
+    out = torch.full((M, N), 7.0).cuda()
+    ops.gemm_tn(*dev(a, b), out, accumulate=False, m=M)
+    assert rel_l2(out, ref) < 2e-3
+    ops.gemm_tn(*dev(a, b), out, accumulate=True, alpha=2.0, m=M)
+    assert rel_l2(out, 3 * ref) < 2e-3
+
+
+def test_patch_embed(ops):
+    g = torch.Generator().manual_seed(11)
+    for (n, H, W) in [(3, 64, 64), (2, 224, 224), (1, 192, 352)]:
+        img = torch.rand((n, H, W, 3), generator=g).to(BF16)
+        wt = rnd((768, 768), g, 0.03)
+        bias = torch.randn(768, generator=g) * 0.1
+        ref = E.patch_embed_fwd(img, wt, bias, 16).float()
+        got = ops.patch_embed_fwd(img.cuda(), wt.cuda(), bias.cuda(), 16)
+        assert rel_l2(got, ref) < 6e-3
+        dy = rnd((ref.shape[0], 768), g)
+        dref = torch.zeros((768, 768))
+        E.patch_embed_wgrad(img, dy, dref, 16, accumulate=False)
+        dw = torch.zeros((768, 768)).cuda()
+        ops.patch_embed_wgrad(img.cuda(), dy.cuda(), dw, 16, accumulate=False)
+        assert rel_l2(dw, dref) < 2e-3
+
+
+# ---- LayerNorm ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,H,xf32", [(1, 768, False), (1000, 768, False), (333, 768, True), (64, 1024, False), (50, 256, True)])
+def test_layernorm(ops, rows, H, xf32):
+    g = torch.Generator().manual_seed(rows)
+    x = (torch.randn((rows, H), generator=g) * 2 + 0.5).to(F32 if xf32 else BF16)
+    gamma, beta = 1 + 0.1 * torch.randn(H, generator=g), 0.1 * torch.randn(H, generator=g)
+    y16, y32, mean, rstd = E.ln_fwd(x, gamma, beta, out_bf16=True, out_f32=True)
+    g16, g32, gm, gr = ops.ln_fwd(x.cuda(), gamma.cuda(), beta.cuda(), out_bf16=True, out_f32=True)
+    assert rel_l2(g32, y32) < 1e-5 and rel_l2(g16, y32) < 4e-3 and rel_l2(gm, mean) < 1e-5 and rel_l2(gr, rstd) < 1e-5
+    dy = torch.randn((rows, H), generator=g).to(x.dtype)
+    dres = torch.randn((rows, H), generator=g).to(x.dtype)
+    dg_r, db_r = torch.zeros(H), torch.zeros(H)
+    dx_r = E.ln_bwd(dy, x, mean, rstd, gamma, dg_r, db_r, dres=dres, dx_dtype=F32)
+    dg, db = torch.zeros(H).cuda(), torch.zeros(H).cuda()
+    dx = ops.ln_bwd(dy.cuda(), x.cuda(), gm, gr, gamma.cuda(), dg, db, dres=dres.cuda())
+    tol = 1e-4 if xf32 else 5e-3
+    assert rel_l2(dx, dx_r) < tol and rel_l2(dg, dg_r) < 1e-4 and rel_l2(db, db_r) < 1e-4
+
+
+# ---- attention ---------------------------------------------------------------------------------------------
+def _attn_inputs(B, S, heads, seed, pad):
+    g = torch.Generator().manual_seed(seed)
+    qkv = rnd((B * S, 3 * heads * 64), g, 1.0)
+    valid = None
+    if pad:
+        valid = torch.ones((B, S), dtype=torch.uint8)
+        for b in range(B):
+            n_pad = int(torch.randint(0, S // 2, (1,), generator=g))
+            idx = torch.randperm(S, generator=g)[:n_pad]
+            valid[b, idx] = 0
+        valid[:, 0] = 1
+    return qkv, valid, g
+
+
+@pytest.mark.parametrize("B,S,heads,pad", [(2, 18, 12, False), (3, 198, 12, False), (2, 148, 12, True), (2, 328, 12, True),
+                                           (1, 512, 12, True), (2, 64, 2, True), (1, 130, 3, True)])
+def test_attention_fwd_bwd(ops, B, S, heads, pad):
+    qkv, valid, g = _attn_inputs(B, S, heads, 100 + S, pad)
+    o_ref, lse_ref = E.attention_fwd(qkv, B, S, heads, valid)
+    o, lse = ops.attention_fwd(qkv.cuda(), B, S, heads, None if valid is None else valid.cuda())
+    assert rel_l2(o, o_ref) < 8e-3
+    assert float((lse.cpu() - lse_ref).abs().max()) < 2e-2
+    do = rnd((B * S, heads * 64), g)
+    if valid is not None:                         # padded query rows carry exactly-zero upstream grads in the model
+        do = do * valid.reshape(B * S, 1).to(BF16)
+    dq_ref = E.attention_bwd(qkv, o_ref, do, lse_ref, B, S, heads, valid).float()
+    dq = ops.attention_bwd(qkv.cuda(), o, do.cuda(), lse, B, S, heads, None if valid is None else valid.cuda()).float().cpu()
+    Hh = heads * 64
+    for name, sl in [('dq', slice(0, Hh)), ('dk', slice(Hh, 2 * Hh)), ('dv', slice(2 * Hh, 3 * Hh))]:
+        assert rel_l2(dq[:, sl], dq_ref[:, sl]) < 1.5e-2, name
+
+
+def test_attention_padded_query_rows_uniform(ops):
+    """utils/transformer.py:109-112: a fully masked query row attends uniformly over ALL keys (-1e10, not -inf)."""
+    B, S, heads = 1, 70, 12
+    qkv, _, g = _attn_inputs(B, S, heads, 5, False)
+    valid = torch.ones((B, S), dtype=torch.uint8)
+    valid[0, 40:] = 0
+    o, _ = ops.attention_fwd(qkv.cuda(), B, S, heads, valid.cuda())
+    v = qkv[:, 2 * heads * 64:].float()
+    assert rel_l2(o[40:].float().cpu(), v.mean(0, keepdim=True).expand(30, -1)) < 1e-2
+
+
+@pytest.mark.parametrize("B,S,pad,vq", [(2, 128, True, False), (2, 148, True, True), (1, 512, True, False), (3, 50, False, False)])
+def test_attention_colsum(ops, B, S, pad, vq):
+    heads = 12
+    qkv, valid, g = _attn_inputs(B, S, heads, 7 + S, pad)
+    _, lse_ref = E.attention_fwd(qkv, B, S, heads, valid)
+    lo_r, hi_r = torch.zeros(B, S), torch.zeros(B, S)
+    split = S // 3
+    E.attention_colsum(qkv, lse_ref, B, S, heads, lo_r, hi_r, qsplit=split, valid=valid, valid_q_only=vq, weight=1 / heads)
+    _, lse = ops.attention_fwd(qkv.cuda(), B, S, heads, None if valid is None else valid.cuda())
+    lo, hi = torch.zeros(B, S).cuda(), torch.zeros(B, S).cuda()
+    ops.attention_colsum(qkv.cuda(), lse, B, S, heads, lo, hi, qsplit=split, valid=None if valid is None else valid.cuda(),
+                         valid_q_only=vq, weight=1 / heads)
+    assert rel_l2(lo, lo_r) < 5e-3 and rel_l2(hi, hi_r) < 5e-3
+
+
+# ---- element-wise / gather / CE ------------------------------------------------------------------------------
+def test_casts_and_colsum(ops):
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn((777, 300), generator=g)
+    assert torch.equal(ops.cast_bf16(x.cuda()).cpu(), x.to(BF16))
+    t = torch.zeros((300, 800), dtype=BF16).cuda()
+    ops.cast_transpose_bf16(x.cuda(), t, ld_dst=800)
+    assert torch.equal(t[:, :777].cpu(), x.t().to(BF16)) and torch.all(t[:, 777:] == 0)
+    xb = rnd((5000, 772), g)
+    out = torch.zeros(770).cuda()
+    ops.colsum_bf16(xb.cuda(), out, accumulate=False, n=770)
+    assert rel_l2(out, xb[:, :770].float().sum(0)) < 1e-4
+
+
+def test_gather_scatter_pool(ops):
+    g = torch.Generator().manual_seed(4)
+    H, rows = 768, 500
+    a = rnd((300, H), g)
+    tb, tc, td = torch.randn((50, H), generator=g), torch.randn((64, H), generator=g), torch.randn((7, H), generator=g)
+    ia = torch.randint(-1, 300, (rows,), generator=g).int()
+    ib = torch.randint(0, 50, (rows,), generator=g).int()
+    ic = torch.randint(-1, 64, (rows,), generator=g).int()
+    id_ = torch.randint(-1, 7, (rows,), generator=g).int()
+    ref = E.gather_add4(rows, H, a, ia, tb, ib, tc, ic, td, id_)
+    got = ops.gather_add4(rows, H, *dev(a, ia, tb, ib, tc, ic, td, id_))
+    assert rel_l2(got, ref) < 1e-6
+    src = torch.randn((rows, H), generator=g)
+    tab_r = torch.zeros((64, H))
+    E.scatter_add_rows(src, ic, tab_r)
+    tab = torch.zeros((64, H)).cuda()
+    ops.scatter_add_rows(src.cuda(), ic.cuda(), tab)
+    assert rel_l2(tab, tab_r) < 1e-5
+    x = rnd((6, 2 + 14 * 14, H), g)
+    pr = E.cls_avgpool_fwd(x, 6, 14, 14, 2, 2)
+    pg = ops.cls_avgpool_fwd(x.cuda(), 6, 14, 14, 2, 2)
+    assert rel_l2(pg, pr) < 1e-6
+    dout = torch.randn(pr.shape, generator=g)
+    assert rel_l2(ops.cls_avgpool_bwd(dout.cuda(), 6, 14, 14, 2, 2), E.cls_avgpool_bwd(dout, 6, 14, 14, 2, 2).float()) < 4e-3
+
+
+@pytest.mark.parametrize("rows,C,ld", [(40, 4, 4), (64, 128, 128), (25, 50370, 50432)])
+def test_softmax_ce(ops, rows, C, ld):
+    g = torch.Generator().manual_seed(C)
+    logits = torch.randn((rows, ld), generator=g) * 3
+    labels = torch.randint(0, C, (rows,), generator=g).int()
+    rs = torch.rand(rows, generator=g)
+    loss_r, am_r, dl_r = E.softmax_ce(logits, labels, C, rowscale=rs, dlogits_dtype=F32, ld_dl=ld)
+    loss, am, dl = ops.softmax_ce(logits.cuda(), labels.cuda(), C, rowscale=rs.cuda(), dlogits_dtype=F32, ld_dl=ld)
+    assert rel_l2(loss, loss_r) < 1e-5 and torch.equal(am.cpu(), am_r) and rel_l2(dl, dl_r) < 1e-4
+    _, _, dl16 = ops.softmax_ce(logits.cuda(), labels.cuda(), C, rowscale=rs.cuda(), dlogits_dtype=BF16, ld_dl=ld)
+    assert rel_l2(dl16, dl_r) < 5e-3 and torch.all(dl16[:, C:] == 0)
+
+
+def test_small_head_ops(ops):
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn((100, 768), generator=g)
+    y_r, inv_r = E.l2norm_fwd(x)
+    y, inv = ops.l2norm_fwd(x.cuda())
+    assert rel_l2(y, y_r) < 1e-6
+    dy = torch.randn((100, 768), generator=g)
+    assert rel_l2(ops.l2norm_bwd(dy.cuda(), y, inv), E.l2norm_bwd(dy, y_r, inv_r)) < 1e-5
+    assert rel_l2(ops.gelu_fwd(x.cuda()), E.gelu_fwd(x)) < 1e-6
+    assert rel_l2(ops.gelu_bwd(dy.cuda(), x.cuda()), E.gelu_bwd(dy, x)) < 1e-5

@@ -1,0 +1,175 @@
+"""GPU: the full HIP MerlotModel path against the CPU oracle (fp32) on BASELINE config #1 and a 224^2 slice of
+config #2, plus the committed golden pins.  Tolerances (bf16 compute vs fp32 oracle): hidden states
+rel-L2 <= 2e-2, scalar losses <= 1e-2 abs, gradients rel-L2 <= 0.12 per tensor (median <= 3e-2), integer outputs
+exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from common import tiny_config, synth_batch, rel_l2
+from oracle import merlot_oracle as mo
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def _run_both(cfg, b, with_grads=True):
+    from merlot_amd import MerlotModel, ParamStore
+    w = mo.init_weights(cfg, 0)
+    for t in w.values():
+        t.requires_grad_(with_grads)
+    m = mo.MerlotOracle(cfg, w, b['image'], b['input_ids'], mask_input=True, shuffled_idx_img=b['shuffled_idx_img'],
+                        noise=b['noise'])
+    loss, info = m.total_loss(b['shuffled_idx_img'], b['video_src_ids'])
+    if with_grads:
+        loss.backward()
+    st = ParamStore(cfg, 'cuda', seed=0)
+    st.load_tf_weights({k: v.detach() for k, v in w.items()})
+    pm = MerlotModel(cfg, True, False, b['image'].cuda(), b['input_ids'].cuda(), mask_input=True,
+                     shuffled_idx_img=torch.from_numpy(b['shuffled_idx_img']).cuda(), params=st,
+                     noise={k: torch.from_numpy(v) for k, v in b['noise'].items()})
+    return w, m, loss, info, st, pm
+
+
+def _check(cfg, b, w, m, info, st, pm, with_grads=True):
+    assert np.array_equal(pm.lang_mask_info['masked_idx'].cpu().numpy(), m.lang_mask_info['masked_idx'].numpy())
+    assert np.array_equal(pm.lang_mask_info['masked_ids'].cpu().numpy(), m.lang_mask_info['masked_ids'].numpy())
+    assert rel_l2(pm.lang_transformer_info['attention_summs'].reshape(pm.B, pm.L), m.attention_summs()) < 1e-2
+    for k in ['viz', 'lang']:
+        assert rel_l2(pm.encoder_hidden_states[k], m.encoder_hidden_states[k]) < 2e-2, k
+    assert rel_l2(pm.img_trg_h, m.img_trg_h) < 2e-2 and rel_l2(pm.lang_trg_h, m.lang_trg_h) < 2e-2
+    l1, i1 = pm.mask_loss()
+    l2, i2 = pm.contrastive_loss()
+    l3, i3 = pm.temporal_loss(torch.from_numpy(b['shuffled_idx_img']).cuda(), torch.from_numpy(b['video_src_ids']).cuda())
+    assert abs(float(l1) - float(info['lang']['loss'])) < 1e-2
+    assert abs(float(i2['lang_to_viz']) - float(info['contr']['lang_to_viz'])) < 1e-2
+    assert abs(float(i2['viz_to_lang']) - float(info['contr']['viz_to_lang'])) < 1e-2
+    assert abs(float(l3) - float(info['temporal']['loss'])) < 1e-2
+    for k, v in m.attention_log.items():
+        assert abs(float(pm.attention_log[k]) - float(v)) < 2e-3, k
+    if with_grads:
+        st.zero_grad()
+        (l1 + l2 + l3).backward()
+        torch.cuda.synchronize()
+        gt = st.export_tf_grads()
+        rels = {}
+        for k, v in w.items():
+            if v.grad is None or k.endswith('key_layer/bias'):
+                continue
+            rels[k] = rel_l2(gt[k], v.grad)
+        bad = {k: r for k, r in rels.items() if r > 0.12}
+        assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
+        assert np.median(list(rels.values())) < 3e-2
+    return float(l1 + l2 + l3)
+
+
+def test_config1_matches_oracle_forward_backward():
+    cfg = tiny_config()
+    b = synth_batch(cfg)
+    w, m, loss, info, st, pm = _run_both(cfg, b)
+    total = _check(cfg, b, w, m, info, st, pm)
+    assert abs(total - float(loss)) < 2e-2
+    # committed pins of the oracle (tests/golden/config1_expected.npz)
+    e = np.load(os.path.join(G, 'config1_expected.npz'))
+    assert np.array_equal(pm.lang_mask_info['masked_idx'].cpu().numpy(), e['masked_idx'])
+    assert abs(total - float(e['loss'])) < 2e-2
+    assert rel_l2(pm.img_trg_h[:, :16], torch.from_numpy(e['img_trg_h'])) < 3e-2
+
+
+def test_config2_shapes_224_small_batch():
+    """224^2 frames (Sv=198, joint S=328, text-only S=128): the non-multiple-of-64 tails, 2 layers to keep the oracle fast."""
+    cfg = tiny_config(image_size=[224, 224])
+    b = synth_batch(cfg, E=1, num_chunks=4, seed=5)
+    w, m, loss, info, st, pm = _run_both(cfg, b)
+    assert (pm.P, pm.L) == (200, 128)
+    _check(cfg, b, w, m, info, st, pm)
+
+
+def test_five_segment_sort_story_inference():
+    """BASELINE config #4 shape: n=5 segments, inference, dup x2, argsort(u)+64 (get_zero_shot_logits.py:45-86)."""
+    from merlot_amd import MerlotModel, ParamStore
+    from oracle import index_oracle as ix
+    cfg = tiny_config(num_chunks_in_group=5, image_shuffle_prob=0.5)
+    bs, n, dup = 2, 5, 2
+    g = torch.Generator().manual_seed(9)
+    image = torch.rand(bs, n, 64, 64, 3, generator=g).to(torch.bfloat16).float()
+    ids = torch.randint(100, 50354, (bs, n, 32), generator=g)
+    ids[:, :, 0] = 2
+    ids[:, :, 20:] = 0
+    u = np.random.RandomState(1).uniform(size=bs * dup * n)
+    w = mo.init_weights(cfg, 0)
+    with torch.no_grad():
+        ref = mo.sort_story_probs(cfg, w, image, ids, u, dup)
+        st = ParamStore(cfg, 'cuda', seed=0)
+        st.load_tf_weights(w)
+        images = image.repeat(dup, 1, 1, 1, 1).reshape(bs * dup * n, 64, 64, 3)
+        sents = ids.repeat(dup, 1, 1)
+        sidx = ix.sort_story_shuffled_idx(u, n)
+        pm = MerlotModel(cfg, False, False, images.cuda(), sents.cuda(), mask_input=False,
+                         shuffled_idx_img=torch.from_numpy(sidx.reshape(-1)).cuda(), params=st, log_attention_probs=False)
+        h_lang, h_viz = pm.pooled_segments()
+        logits = pm.allpairs_temporal_logits(h_lang, h_viz, 'lang_viz_temporal')
+        probs = torch.softmax(logits, -1)[:, 1:].reshape(bs, dup, n, n, 3).mean(1).cpu()
+    assert float((probs - ref['lang_viz_probs']).abs().max()) < 2e-2
+    for s in range(bs):                                               # permutation search agrees with the oracle's
+        assert ix.best_permutation(probs[s].numpy())[0] == ix.best_permutation(ref['lang_viz_probs'][s].numpy())[0]
+
+
+def test_dropout_training_step_is_finite_and_seeded():
+    from merlot_amd import MerlotModel, ParamStore
+    cfg = tiny_config(hidden_dropout_prob=0.1)
+    b = synth_batch(cfg)
+    st = ParamStore(cfg, 'cuda', seed=0)
+    losses = []
+    for seed in (3, 3, 4):
+        st.zero_grad()
+        pm = MerlotModel(cfg, True, False, b['image'].cuda(), b['input_ids'].cuda(), mask_input=True,
+                         shuffled_idx_img=torch.from_numpy(b['shuffled_idx_img']).cuda(), params=st,
+                         noise={k: torch.from_numpy(v) for k, v in b['noise'].items()}, seed=seed)
+        l = pm.mask_loss()[0] + pm.contrastive_loss()[0]
+        l.backward()
+        assert torch.isfinite(l) and torch.isfinite(st.grad).all()
+        losses.append(float(l))
+    assert losses[0] == losses[1] and losses[0] != losses[2]
+
+
+def test_adamw_matches_reference_update_rule():
+    """utils/optimization.py:339-416 incl. the bf16 m / sign-encoded v state (:267-288), against a numpy restatement."""
+    from merlot_amd import ops
+    rng = np.random.RandomState(0)
+    n = 4096 + 37
+    p0 = rng.randn(n).astype(np.float32)
+    lr, b1, b2, eps, wd = 3e-4, 0.9, 0.98, 1e-6, 0.1
+    for state_bf16 in (False, True):
+        p = torch.from_numpy(p0.copy()).cuda()
+        sd = torch.bfloat16 if state_bf16 else torch.float32
+        m, v = torch.zeros(n, dtype=sd).cuda(), torch.zeros(n, dtype=sd).cuda()
+        pr, mr, vr = p0.astype(np.float32).copy(), np.zeros(n, np.float32), np.zeros(n, np.float32)
+
+        def to_bf16(x):
+            return torch.from_numpy(x).to(torch.bfloat16).float().numpy()
+
+        for it in range(3):
+            gnp = (rng.randn(n) * 0.01).astype(np.float32)
+            ops.adamw_step(p, torch.from_numpy(gnp).cuda(), m, v, lr, b1, b2, eps, wd)
+            g2 = gnp * gnp + np.float32(1e-30)
+            if state_bf16:
+                v_dec = np.where(vr > 0, np.abs(vr), np.abs(vr) * np.float32(1.00390625)).astype(np.float32)
+            else:
+                v_dec = vr
+            nm_ = (np.float32(b1) * mr + np.float32(1 - b1) * gnp).astype(np.float32)
+            nv_ = (np.float32(b2) * v_dec + np.float32(1 - b2) * g2).astype(np.float32)
+            upd = nm_ / (np.sqrt(nv_) + np.float32(eps)) + np.float32(wd) * pr
+            pr = (pr - np.float32(lr) * upd).astype(np.float32)
+            if state_bf16:
+                mr = to_bf16(nm_)
+                enc = to_bf16(nv_)
+                e0, e1 = np.abs(enc - nv_), np.abs(enc * np.float32(1.00390625) - nv_)
+                vr = np.where(e0 <= e1, enc, -enc).astype(np.float32)
+            else:
+                mr, vr = nm_, nv_
+        assert np.allclose(p.cpu().numpy(), pr, rtol=2e-6, atol=1e-7)
+        assert np.allclose(m.float().cpu().numpy(), mr, rtol=1e-6, atol=1e-9)
+        assert np.allclose(v.float().cpu().numpy(), vr, rtol=1e-6, atol=1e-12)
