@@ -56,9 +56,13 @@ int merlot_gemm_bf16_nt(const void* A, int64_t lda, const void* Bt, int64_t ldb,
                         int64_t ld_aux_out, float dropout_p, uint64_t dropout_seed, merlot_stream_t stream);
 
 /* Weight gradient: C[M,N] (f32) (+)= alpha * sum_r A[r,M] * B[r,N].  A, B bf16 row-major with the
- * reduction index r as the SLOW dim (activations / output grads as stored).  M, N even. */
+ * reduction index r as the SLOW dim (activations / output grads as stored).  M, N even.
+ * The reduction is split over the grid; partial tiles go through the caller-owned `workspace` (f32, at least
+ * merlot_gemm_bf16_tn_workspace_bytes(M, N, R) bytes; may be NULL when that is 0) -- no atomics. */
+int64_t merlot_gemm_bf16_tn_workspace_bytes(int64_t M, int64_t N, int64_t R);
 int merlot_gemm_bf16_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
-                        int64_t M, int64_t N, int64_t R, float alpha, int accumulate, merlot_stream_t stream);
+                        int64_t M, int64_t N, int64_t R, float alpha, int accumulate, void* workspace,
+                        int64_t workspace_bytes, merlot_stream_t stream);
 
 /* Patch-embed 16x16/16 conv as an implicit-im2col GEMM (utils/vision_transformer.py:193-205).
  * image: bf16 NHWC [n_img, H, W, 3] in [0,1]; Wt: bf16 [hidden, P*P*3] with k=(py,px,c);
@@ -180,10 +184,11 @@ int merlot_shuffled_idx(const int32_t* num_shuffle, const float* u_select, const
 /* ------------------------------------------------------------------------------------------------
  * AdamW with bias correction and bf16 m / sign-encoded bf16 v (utils/optimization.py:267-288,339-416).
  * param/grad f32 [n]; m, v bf16 bit patterns (state_bf16=1) or f32.  lr already includes the schedule
- * scale and sqrt(bc2)/bc1.  grad_scale multiplies the gradient first (1/world for mean reduce).
+ * scale and sqrt(bc2)/bc1.  beta1/beta2 are doubles so that (1 - beta) is rounded to f32 from the double value,
+ * as the reference's python-side `1.0 - beta_1` is.  grad_scale multiplies the gradient first (1/world for mean).
  * ---------------------------------------------------------------------------------------------- */
-int merlot_adamw_step(float* param, const float* grad, void* m, void* v, int64_t n, float lr, float beta1,
-                      float beta2, float eps, float weight_decay, float grad_scale, int state_bf16,
+int merlot_adamw_step(float* param, const float* grad, void* m, void* v, int64_t n, float lr, double beta1,
+                      double beta2, float eps, float weight_decay, float grad_scale, int state_bf16,
                       merlot_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------

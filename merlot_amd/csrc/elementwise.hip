@@ -331,7 +331,9 @@ constexpr float MISSING_PRECISION = 1.00390625f;  // optimization.py:268
 template <bool STATE_BF16>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ param, const float* __restrict__ grad,
                                                     void* __restrict__ m_, void* __restrict__ v_, int64_t n, float lr,
-                                                    float beta1, float beta2, float eps, float wd, float gscale) {
+                                                    float beta1, float beta2, float omb1, float omb2, float eps,
+                                                    float wd, float gscale) {
+#pragma clang fp contract(off)   // one IEEE op per reference op: the bf16 state encoding is sensitive to the last ulp
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float g = grad[i] * gscale;
         float m, v;
@@ -347,8 +349,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ param, c
             v = ((const float*)v_)[i];
         }
         const float g2 = g * g + 1e-30f;                         // :360
-        const float nm = beta1 * m + (1.0f - beta1) * g;         // :390
-        const float nv = beta2 * v + (1.0f - beta2) * g2;        // :391
+        const float nm = beta1 * m + omb1 * g;                   // :390  (1 - beta evaluated in double, as python does)
+        const float nv = beta2 * v + omb2 * g2;                  // :391
         float upd = nm / (sqrtf(nv) + eps);                      // :393
         const float pw = param[i];
         if (wd > 0.f) upd += wd * pw;                            // :402-403
@@ -490,16 +492,18 @@ extern "C" int merlot_gelu_bwd(const float* dy, const float* x, float* dx, int64
     return merlot_launch_status("merlot_gelu_bwd");
 }
 
-extern "C" int merlot_adamw_step(float* param, const float* grad, void* m, void* v, int64_t n, float lr, float beta1,
-                                 float beta2, float eps, float weight_decay, float grad_scale, int state_bf16,
+extern "C" int merlot_adamw_step(float* param, const float* grad, void* m, void* v, int64_t n, float lr, double beta1d,
+                                 double beta2d, float eps, float weight_decay, float grad_scale, int state_bf16,
                                  merlot_stream_t stream) {
+    const float beta1 = (float)beta1d, beta2 = (float)beta2d;
+    const float omb1 = (float)(1.0 - beta1d), omb2 = (float)(1.0 - beta2d);
     MERLOT_CHECK(param && grad && m && v && n > 0, MERLOT_ESHAPE, "merlot_adamw_step: bad args");
     const int g = grid_for(n, 256, 8192);
     if (state_bf16)
-        hipLaunchKernelGGL((adamw_kernel<true>), dim3(g), dim3(256), 0, STREAM, param, grad, m, v, n, lr, beta1, beta2, eps,
-                           weight_decay, grad_scale);
+        hipLaunchKernelGGL((adamw_kernel<true>), dim3(g), dim3(256), 0, STREAM, param, grad, m, v, n, lr, beta1, beta2, omb1,
+                           omb2, eps, weight_decay, grad_scale);
     else
-        hipLaunchKernelGGL((adamw_kernel<false>), dim3(g), dim3(256), 0, STREAM, param, grad, m, v, n, lr, beta1, beta2, eps,
-                           weight_decay, grad_scale);
+        hipLaunchKernelGGL((adamw_kernel<false>), dim3(g), dim3(256), 0, STREAM, param, grad, m, v, n, lr, beta1, beta2, omb1,
+                           omb2, eps, weight_decay, grad_scale);
     return merlot_launch_status("merlot_adamw_step");
 }

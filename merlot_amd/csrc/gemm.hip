@@ -16,7 +16,10 @@
 //     the grid with fp32 atomics fills the 256 CUs when M*N is only a few dozen tiles.
 //   * block -> tile map is XCD-aware: the 8 XCDs each walk a contiguous band of row tiles, all column
 //     tiles of a row tile adjacent, so an A row band is fetched from HBM once per XCD L2.
+#include <cstdlib>
+
 #include "common.h"
+#include "gemm_ring.h"
 
 namespace {
 
@@ -46,6 +49,7 @@ struct GemmNTArgs {
     uint64_t drop_seed;
     int accumulate;
     int ntm, ntn;
+    int dbg;              // experiments only: 1 = skip epilogue, 2 = skip main loop
     PatchGeom pg;
 };
 
@@ -58,6 +62,7 @@ struct GemmTNArgs {
     float alpha;
     int use_atomics;
     int ntm, ntn, splits, rchunk;
+    int dbg;
     PatchGeom pg;
 };
 
@@ -101,6 +106,92 @@ __device__ __forceinline__ void compute_tile(const char* la, const char* lb, con
             for (int fj = 0; fj < 2; ++fj)
                 acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[fj], af[fi], acc[fi][fj], 0, 0, 0);
     }
+}
+
+// epilogue for 4 consecutive output columns n..n+3 of row m (v = alpha * accumulator)
+template <int EPI, bool OUT_F32>
+__device__ __forceinline__ void nt_epilogue_quad(const GemmNTArgs& p, int m, int n, float (&v)[4], bool vec_ok) {
+        const bool full = vec_ok && (n + 3 < p.N);
+        const int ne = full ? 4 : min(4, p.N - n);
+        if (p.bias) {
+            if (full) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += b4[e];
+            } else {
+                for (int e = 0; e < ne; ++e) v[e] += p.bias[n + e];
+            }
+        }
+        if (EPI == MERLOT_EPI_GELU) {
+            if (p.aux_out) {
+                bf16* ao = p.aux_out + (int64_t)m * p.ld_aux_out + n;
+                if (full) {
+                    bf16x4 u4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) u4[e] = (bf16)v[e];
+                    *reinterpret_cast<bf16x4*>(ao) = u4;
+                } else {
+                    for (int e = 0; e < ne; ++e) ao[e] = (bf16)v[e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+        } else if (EPI == MERLOT_EPI_DGELU) {
+            const bf16* ai = p.aux_in + (int64_t)m * p.ld_aux_in + n;
+            float u[4] = {0.f, 0.f, 0.f, 0.f};
+            if (full) {
+                const bf16x4 u4 = *reinterpret_cast<const bf16x4*>(ai);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) u[e] = (float)u4[e];
+            } else {
+                for (int e = 0; e < ne; ++e) u[e] = (float)ai[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(u[e]);
+        } else if (EPI == MERLOT_EPI_RESIDUAL) {
+            if (p.drop_thresh) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint64_t idx = (uint64_t)m * (uint64_t)p.N + (uint64_t)(n + e);
+                    v[e] = dropout_keep(p.drop_seed, idx, p.drop_thresh) ? v[e] * p.drop_scale : 0.f;
+                }
+            }
+            const bf16* ai = p.aux_in + (int64_t)m * p.ld_aux_in + n;
+            if (full) {
+                const bf16x4 r4 = *reinterpret_cast<const bf16x4*>(ai);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
+            } else {
+                for (int e = 0; e < ne; ++e) v[e] += (float)ai[e];
+            }
+        }
+        if (OUT_F32) {
+            float* c = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n;
+            if (full) {
+                f32x4 o;
+                if (p.accumulate) {
+                    o = *reinterpret_cast<const f32x4*>(c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += v[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = v[e];
+                }
+                *reinterpret_cast<f32x4*>(c) = o;
+            } else {
+                for (int e = 0; e < ne; ++e) c[e] = p.accumulate ? c[e] + v[e] : v[e];
+            }
+        } else {
+            bf16* c = reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + n;
+            if (full) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+                *reinterpret_cast<bf16x4*>(c) = o;
+            } else {
+                for (int e = 0; e < ne; ++e) c[e] = (bf16)v[e];
+            }
+        }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -193,87 +284,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNTArgs p) {
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[fi][fj][4 * q + e] * p.alpha;
-                const bool full = vec_ok && (n + 3 < p.N);
-                const int ne = full ? 4 : min(4, p.N - n);
-                if (p.bias) {
-                    if (full) {
-                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += b4[e];
-                    } else {
-                        for (int e = 0; e < ne; ++e) v[e] += p.bias[n + e];
-                    }
-                }
-                if (EPI == MERLOT_EPI_GELU) {
-                    if (p.aux_out) {
-                        bf16* ao = p.aux_out + (int64_t)m * p.ld_aux_out + n;
-                        if (full) {
-                            bf16x4 u4;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) u4[e] = (bf16)v[e];
-                            *reinterpret_cast<bf16x4*>(ao) = u4;
-                        } else {
-                            for (int e = 0; e < ne; ++e) ao[e] = (bf16)v[e];
-                        }
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
-                } else if (EPI == MERLOT_EPI_DGELU) {
-                    const bf16* ai = p.aux_in + (int64_t)m * p.ld_aux_in + n;
-                    float u[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (full) {
-                        const bf16x4 u4 = *reinterpret_cast<const bf16x4*>(ai);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) u[e] = (float)u4[e];
-                    } else {
-                        for (int e = 0; e < ne; ++e) u[e] = (float)ai[e];
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(u[e]);
-                } else if (EPI == MERLOT_EPI_RESIDUAL) {
-                    if (p.drop_thresh) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const uint64_t idx = (uint64_t)m * (uint64_t)p.N + (uint64_t)(n + e);
-                            v[e] = dropout_keep(p.drop_seed, idx, p.drop_thresh) ? v[e] * p.drop_scale : 0.f;
-                        }
-                    }
-                    const bf16* ai = p.aux_in + (int64_t)m * p.ld_aux_in + n;
-                    if (full) {
-                        const bf16x4 r4 = *reinterpret_cast<const bf16x4*>(ai);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
-                    } else {
-                        for (int e = 0; e < ne; ++e) v[e] += (float)ai[e];
-                    }
-                }
-                if (OUT_F32) {
-                    float* c = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n;
-                    if (full) {
-                        f32x4 o;
-                        if (p.accumulate) {
-                            o = *reinterpret_cast<const f32x4*>(c);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] += v[e];
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = v[e];
-                        }
-                        *reinterpret_cast<f32x4*>(c) = o;
-                    } else {
-                        for (int e = 0; e < ne; ++e) c[e] = p.accumulate ? c[e] + v[e] : v[e];
-                    }
-                } else {
-                    bf16* c = reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + n;
-                    if (full) {
-                        bf16x4 o;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
-                        *reinterpret_cast<bf16x4*>(c) = o;
-                    } else {
-                        for (int e = 0; e < ne; ++e) c[e] = (bf16)v[e];
-                    }
-                }
+                nt_epilogue_quad<EPI, OUT_F32>(p, m, n, v, vec_ok);
             }
         }
     }
@@ -399,6 +410,402 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTNArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Row-contiguous epilogue.  The MFMA accumulator layout gives a lane 4 consecutive columns of ONE row per quad, so
+// direct stores touch 32 rows x 16 B per wave-instruction (measured: ~30 us to write a [50688, 768] bf16 output,
+// a third of a K=768 GEMM).  Instead each wave transposes its 32 x (FN*32) fp32 slab through a private LDS buffer
+// and then works on whole row segments: a lane owns 8 consecutive columns, so the output store, the residual /
+// pre-activation loads and the bias loads are all 16-32 B per lane and 128-512 contiguous bytes per row.
+// ------------------------------------------------------------------------------------------------
+template <int EPI, bool OUT_F32>
+__device__ __forceinline__ void epilogue_row8(const GemmNTArgs& p, int m, int n, float (&v)[8]) {
+    // v = alpha * acc for columns n..n+7 of row m; n + 7 < N guaranteed, 16-B alignment guaranteed by the caller
+    if (p.bias) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] += b0[e];
+            v[4 + e] += b1[e];
+        }
+    }
+    if (EPI == MERLOT_EPI_GELU) {
+        if (p.aux_out) {
+            bf16x8 u8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) u8[e] = (bf16)v[e];
+            *reinterpret_cast<bf16x8*>(p.aux_out + (int64_t)m * p.ld_aux_out + n) = u8;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+    } else if (EPI == MERLOT_EPI_DGELU) {
+        const bf16x8 u8 = *reinterpret_cast<const bf16x8*>(p.aux_in + (int64_t)m * p.ld_aux_in + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f((float)u8[e]);
+    } else if (EPI == MERLOT_EPI_RESIDUAL) {
+        if (p.drop_thresh) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const uint64_t idx = (uint64_t)m * (uint64_t)p.N + (uint64_t)(n + e);
+                v[e] = dropout_keep(p.drop_seed, idx, p.drop_thresh) ? v[e] * p.drop_scale : 0.f;
+            }
+        }
+        const bf16x8 r8 = *reinterpret_cast<const bf16x8*>(p.aux_in + (int64_t)m * p.ld_aux_in + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
+    }
+    if (OUT_F32) {
+        float* c = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n;
+        f32x4 o0, o1;
+        if (p.accumulate) {
+            o0 = *reinterpret_cast<const f32x4*>(c);
+            o1 = *reinterpret_cast<const f32x4*>(c + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o0[e] += v[e];
+                o1[e] += v[4 + e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o0[e] = v[e];
+                o1[e] = v[4 + e];
+            }
+        }
+        *reinterpret_cast<f32x4*>(c) = o0;
+        *reinterpret_cast<f32x4*>(c + 4) = o1;
+    } else {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+        *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + n) = o;
+    }
+}
+
+// whole-workgroup epilogue: `stage` = this wave's private LDS buffer of 32 * (FN*32*4 + 16) bytes
+template <typename C, int EPI, bool OUT_F32>
+__device__ __forceinline__ void staged_epilogue(const GemmNTArgs& p, f32x16 (&acc)[C::FM][C::FN], char* stage, int m_base,
+                                                int n_base, int lane) {
+    constexpr int COLS = C::FN * 32;
+    constexpr int RSTRIDE = COLS * 4 + 16;           // +16 B: the 8 rows of a ds_write_b128 lane group tile all 32 banks
+    constexpr int LPR = COLS / 8;                    // lanes per row in the row-contiguous phase
+    constexpr int RPP = 64 / LPR;                    // rows per pass
+    const int hi = lane >> 5;
+    const bool aligned = ((p.ldc & 7) == 0) && ((p.ld_aux_in & 7) == 0) && ((p.ld_aux_out & 7) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0);
+#pragma unroll
+    for (int fi = 0; fi < C::FM; ++fi) {
+        // phase 1: accumulators -> LDS slab [32 rows][COLS] fp32
+#pragma unroll
+        for (int fj = 0; fj < C::FN; ++fj)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 t;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = acc[fi][fj][4 * q + e] * p.alpha;
+                *reinterpret_cast<f32x4*>(stage + (lane & 31) * RSTRIDE + (fj * 32 + 8 * q + 4 * hi) * 4) = t;
+            }
+        // same wave writes and reads: only the LDS queue has to drain (no workgroup barrier)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        // phase 2: row segments
+#pragma unroll
+        for (int ps = 0; ps < 32 / RPP; ++ps) {
+            const int r = ps * RPP + lane / LPR;
+            const int c0 = (lane % LPR) * 8;
+            const int m = m_base + fi * 32 + r;
+            const int n = n_base + c0;
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(stage + r * RSTRIDE + c0 * 4);
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(stage + r * RSTRIDE + c0 * 4 + 16);
+            if (m >= p.M || n >= p.N) continue;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = x0[e];
+                v[4 + e] = x1[e];
+            }
+            if (aligned && n + 7 < p.N) {
+                epilogue_row8<EPI, OUT_F32>(p, m, n, v);
+            } else {                                  // ragged right edge / unaligned leading dims: per-quad path
+                float q0[4] = {v[0] / p.alpha, v[1] / p.alpha, v[2] / p.alpha, v[3] / p.alpha};
+                float q1[4] = {v[4] / p.alpha, v[5] / p.alpha, v[6] / p.alpha, v[7] / p.alpha};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    q0[e] = x0[e];
+                    q1[e] = x1[e];
+                }
+                const bool vec_ok = ((p.ldc & 3) == 0) && ((p.ld_aux_in & 3) == 0) && ((p.ld_aux_out & 3) == 0);
+                nt_epilogue_quad<EPI, OUT_F32>(p, m, n, q0, vec_ok);
+                if (n + 4 < p.N) nt_epilogue_quad<EPI, OUT_F32>(p, m, n + 4, q1, vec_ok);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// NT kernel, ring-pipelined (production path; the 2-buffer kernel above is kept as the small-shape fallback)
+// ------------------------------------------------------------------------------------------------
+template <typename C, int EPI, bool OUT_F32>
+__global__ __launch_bounds__(C::NT) void gemm_nt_ring_kernel(const GemmNTArgs p) {
+    extern __shared__ __attribute__((aligned(1024))) char dsm[];
+    constexpr int BK = C::BK, S = C::STAGES;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wgid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = wgid / p.ntn;
+    const int tile_n = wgid - tile_m * p.ntn;
+    const int m0 = tile_m * C::BM, n0 = tile_n * C::BN;
+
+    // ---- per-lane LDS-DMA sources
+    constexpr int CH = BK / 8;                       // 16-B chunks per row
+    const int prow = lane / CH;                      // row inside a piece
+    const int pch = lane % CH;                       // physical chunk slot
+    const bf16* a_src[C::A_PIECES];
+    const bf16* b_src[C::B_PIECES];
+#pragma unroll
+    for (int i = 0; i < C::A_PIECES; ++i) {
+        const int row = (wave * C::A_PIECES + i) * C::RP + prow;
+        const int chunk = BK == 64 ? ((pch ^ (row >> 1)) & 7) : ((pch ^ (row >> 2)) & 3);
+        a_src[i] = p.A + (int64_t)min(m0 + row, p.M - 1) * p.lda + chunk * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < C::B_PIECES; ++i) {
+        const int row = (wave * C::B_PIECES + i) * C::RP + prow;
+        const int chunk = BK == 64 ? ((pch ^ (row >> 1)) & 7) : ((pch ^ (row >> 2)) & 3);
+        b_src[i] = p.B + (int64_t)min(n0 + row, p.N - 1) * p.ldb + chunk * 8;
+    }
+    auto stage = [&](int kt) {
+        char* la = dsm + (kt % S) * C::STAGE_BYTES + wave * C::A_PIECES * 1024;
+        char* lb = dsm + (kt % S) * C::STAGE_BYTES + C::A_BYTES + wave * C::B_PIECES * 1024;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < C::A_PIECES; ++i)
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(a_src[i] + k0), LDS_PTR(la + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < C::B_PIECES; ++i)
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(b_src[i] + k0), LDS_PTR(lb + i * 1024), 16, 0, 0);
+    };
+
+    const int wm = wave / C::WN, wn = wave % C::WN;
+    const int hi = lane >> 5;
+    int a_row[C::FM], b_row[C::FN];
+#pragma unroll
+    for (int f = 0; f < C::FM; ++f) a_row[f] = (wm * C::FM + f) * 32 + (lane & 31);
+#pragma unroll
+    for (int f = 0; f < C::FN; ++f) b_row[f] = (wn * C::FN + f) * 32 + (lane & 31);
+
+    f32x16 acc[C::FM][C::FN];
+#pragma unroll
+    for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+        for (int j = 0; j < C::FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&](int kt) {
+        const char* la = dsm + (kt % S) * C::STAGE_BYTES;
+        const char* lb = la + C::A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            bf16x8 af[C::FM], bfr[C::FN];
+#pragma unroll
+            for (int f = 0; f < C::FM; ++f) af[f] = *reinterpret_cast<const bf16x8*>(la + ring::kc_off<BK>(a_row[f], 2 * kk + hi));
+#pragma unroll
+            for (int f = 0; f < C::FN; ++f) bfr[f] = *reinterpret_cast<const bf16x8*>(lb + ring::kc_off<BK>(b_row[f], 2 * kk + hi));
+#pragma unroll
+            for (int fi = 0; fi < C::FM; ++fi)
+#pragma unroll
+                for (int fj = 0; fj < C::FN; ++fj)
+                    acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[fj], af[fi], acc[fi][fj], 0, 0, 0);
+        }
+    };
+
+    const int nk = (p.dbg & 2) ? 0 : p.K / BK;
+    // prologue: S-1 stages in flight
+#pragma unroll
+    for (int t = 0; t < S - 1; ++t)
+        if (t < nk) stage(t);
+    const int steady = nk - (S - 1);                 // steps whose prefetch target exists
+    int kt = 0;
+    for (; kt < steady; ++kt) {
+        ring::wait_vmcnt<(S - 2) * C::LOADS>();      // stage kt landed; the newer S-2 stages stay in flight
+        __builtin_amdgcn_s_barrier();
+        stage(kt + S - 1);
+        compute(kt);
+    }
+    for (; kt < nk; ++kt) {                          // drain
+        ring::wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        compute(kt);
+    }
+
+    // ---- epilogue (row-contiguous, staged through this wave's slice of the now idle ring)
+    if ((p.dbg & 1) && acc[0][0][0] != 12345.678f) return;
+    __builtin_amdgcn_s_barrier();                    // every wave is done reading the last ring stage
+    staged_epilogue<C, EPI, OUT_F32>(p, acc, dsm + wave * C::EPI_BYTES, m0 + wm * C::FM * 32, n0 + wn * C::FN * 32, lane);
+}
+
+// LDS transpose-read of one 8-deep MFMA operand fragment (rows r..r+3 and r+4..r+7 of a 64-B-stride panel)
+__device__ __forceinline__ bf16x8 tr_pair(const char* p) {
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p));
+    const bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p + 4 * 64));
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        r[e] = lo[e];
+        r[4 + e] = hi4[e];
+    }
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// TN ring kernel (production weight-gradient path): ring-pipelined, big tiles, NO atomics.
+// Split-R partial tiles go to a caller-owned fp32 workspace [splits][M][N] with row-contiguous stores and a small
+// reduce kernel folds them into C (fp32 atomics measured ~41 G/s on this chip: 175-200 us per wgrad launch).
+// ------------------------------------------------------------------------------------------------
+template <typename C>
+__global__ __launch_bounds__(C::NT) void gemm_tn_ring_kernel(const GemmTNArgs p, float* __restrict__ ws) {
+    extern __shared__ __attribute__((aligned(1024))) char dsm[];
+    constexpr int BK = C::BK, S = C::STAGES;
+    constexpr int PPP = BK / 16;                         // 1 KiB pieces per 32-column panel
+    constexpr int PANEL_BYTES = BK * 64;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntiles = p.ntm * p.ntn;
+    const int ksteps = p.R / BK;
+    const int wgid = xcd_remap(blockIdx.x, gridDim.x);  // split-major: an XCD owns (nearly) all tiles of one R chunk
+    const int split = wgid / ntiles;
+    const int tile = wgid - split * ntiles;
+    const int tile_m = tile / p.ntn;
+    const int tile_n = tile - tile_m * p.ntn;
+    const int m0 = tile_m * C::BM, n0 = tile_n * C::BN;
+    const int ks = split * p.rchunk;                     // rchunk in K-steps
+    const int ke = (p.dbg & 2) ? ks : min(ksteps, ks + p.rchunk);
+    const int nk = ke - ks;
+
+    const bf16* a_src[C::A_PIECES];
+    const bf16* b_src[C::B_PIECES];
+#pragma unroll
+    for (int i = 0; i < C::A_PIECES; ++i) {
+        const int j = wave * C::A_PIECES + i;
+        const int panel = j / PPP, rb = j % PPP;
+        const int col = min(m0 + panel * 32 + (lane & 3) * 8, (int)p.lda - 8);
+        a_src[i] = p.A + (int64_t)(ks * BK + rb * 16 + (lane >> 2)) * p.lda + col;
+    }
+#pragma unroll
+    for (int i = 0; i < C::B_PIECES; ++i) {
+        const int j = wave * C::B_PIECES + i;
+        const int panel = j / PPP, rb = j % PPP;
+        const int col = min(n0 + panel * 32 + (lane & 3) * 8, (int)p.ldb - 8);
+        b_src[i] = p.B + (int64_t)(ks * BK + rb * 16 + (lane >> 2)) * p.ldb + col;
+    }
+    auto stage = [&](int t) {
+        char* la = dsm + (t % S) * C::STAGE_BYTES + wave * C::A_PIECES * 1024;
+        char* lb = dsm + (t % S) * C::STAGE_BYTES + C::A_BYTES + wave * C::B_PIECES * 1024;
+        const int64_t r0 = (int64_t)t * BK;
+#pragma unroll
+        for (int i = 0; i < C::A_PIECES; ++i)
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(a_src[i] + r0 * p.lda), LDS_PTR(la + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < C::B_PIECES; ++i)
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(b_src[i] + r0 * p.ldb), LDS_PTR(lb + i * 1024), 16, 0, 0);
+    };
+
+    const int wm = wave / C::WN, wn = wave % C::WN;
+    const int hi = lane >> 5;
+    const int i16 = lane & 15;
+    const int frag_off = (8 * hi + (i16 >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (i16 & 3)) * 2;
+    const int a_off = wm * C::FM * PANEL_BYTES + frag_off;
+    const int b_off = C::A_BYTES + wn * C::FN * PANEL_BYTES + frag_off;
+
+    f32x16 acc[C::FM][C::FN];
+#pragma unroll
+    for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+        for (int j = 0; j < C::FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&](int t) {
+        const char* base = dsm + (t % S) * C::STAGE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            bf16x8 af[C::FM], bfr[C::FN];
+#pragma unroll
+            for (int f = 0; f < C::FM; ++f) af[f] = tr_pair(base + a_off + f * PANEL_BYTES + kk * 16 * 64);
+#pragma unroll
+            for (int f = 0; f < C::FN; ++f) bfr[f] = tr_pair(base + b_off + f * PANEL_BYTES + kk * 16 * 64);
+#pragma unroll
+            for (int fi = 0; fi < C::FM; ++fi)
+#pragma unroll
+                for (int fj = 0; fj < C::FN; ++fj)
+                    acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[fj], af[fi], acc[fi][fj], 0, 0, 0);
+        }
+    };
+
+#pragma unroll
+    for (int t = 0; t < S - 1; ++t)
+        if (t < nk) stage(t);
+    const int steady = nk - (S - 1);
+    int t = 0;
+    for (; t < steady; ++t) {
+        ring::wait_vmcnt<(S - 2) * C::LOADS>();
+        __builtin_amdgcn_s_barrier();
+        stage(t + S - 1);
+        compute(t);
+    }
+    for (; t < nk; ++t) {
+        ring::wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        compute(t);
+    }
+
+    if ((p.dbg & 1) && acc[0][0][0] != 12345.678f) return;
+    __builtin_amdgcn_s_barrier();
+    GemmNTArgs e{};                                      // reuse the row-contiguous NT epilogue (EPI_NONE, fp32 out)
+    e.M = p.M; e.N = p.N; e.alpha = p.alpha;
+    if (p.splits > 1) {
+        e.C = ws + (int64_t)split * p.M * p.N;
+        e.ldc = p.N;
+        e.accumulate = 0;
+    } else {
+        e.C = p.C;
+        e.ldc = p.ldc;
+        e.accumulate = p.use_atomics;                    // == caller's accumulate flag when splits == 1
+    }
+    staged_epilogue<C, MERLOT_EPI_NONE, true>(e, acc, dsm + wave * C::EPI_BYTES, m0 + wm * C::FM * 32, n0 + wn * C::FN * 32,
+                                              lane);
+}
+
+// C[m][n] = (accumulate ? C : 0) + sum_s ws[s][m][n]
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ ws, int splits, float* __restrict__ c,
+                                                        int64_t ldc, int M, int N, int accumulate) {
+    const int n4 = N >> 2;
+    const int64_t total = (int64_t)M * n4;
+    const int64_t plane = (int64_t)M * N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / n4;
+        const int n = (int)(i - m * n4) * 4;
+        f32x4 acc = *reinterpret_cast<const f32x4*>(ws + m * N + n);
+        for (int s = 1; s < splits; ++s) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ws + s * plane + m * N + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += v[e];
+        }
+        float* cp = c + m * ldc + n;
+        if (accumulate) {
+            const f32x4 o = *reinterpret_cast<const f32x4*>(cp);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += o[e];
+        }
+        *reinterpret_cast<f32x4*>(cp) = acc;
+    }
+}
+
 template <int EPI, bool PATCH>
 int launch_nt(const GemmNTArgs& a, int out_f32, hipStream_t s) {
     const int grid = a.ntm * a.ntn;
@@ -409,13 +816,92 @@ int launch_nt(const GemmNTArgs& a, int out_f32, hipStream_t s) {
     return merlot_launch_status("merlot_gemm_bf16_nt");
 }
 
+template <typename C, int EPI, bool OUT_F32>
+int launch_ring_one(GemmNTArgs& a, hipStream_t s) {
+    auto kern = gemm_nt_ring_kernel<C, EPI, OUT_F32>;
+    static bool attr_set = false;                    // per instantiation
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           C::LDS_BYTES);
+        MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipFuncSetAttribute(LDS=%d) failed: %s", C::LDS_BYTES,
+                     hipGetErrorString(e));
+        attr_set = true;
+    }
+    a.ntm = cdiv(a.M, C::BM);
+    a.ntn = cdiv(a.N, C::BN);
+    hipLaunchKernelGGL(kern, dim3(a.ntm * a.ntn), dim3(C::NT), C::LDS_BYTES, s, a);
+    return merlot_launch_status("merlot_gemm_bf16_nt(ring)");
+}
+
+template <typename C>
+int launch_ring(GemmNTArgs& a, int epilogue, int out_f32, hipStream_t s) {
+#define RING_CASE(E)                                                            \
+    case E:                                                                     \
+        return out_f32 ? launch_ring_one<C, E, true>(a, s) : launch_ring_one<C, E, false>(a, s);
+    switch (epilogue) {
+        RING_CASE(MERLOT_EPI_NONE)
+        RING_CASE(MERLOT_EPI_GELU)
+        RING_CASE(MERLOT_EPI_RESIDUAL)
+        RING_CASE(MERLOT_EPI_DGELU)
+    }
+#undef RING_CASE
+    merlot_set_error("merlot_gemm_bf16_nt: unknown epilogue %d", epilogue);
+    return MERLOT_ESHAPE;
+}
+
+using RingA = ring::Cfg<2, 2, 2, 2, 64, 3>;   // 128x128, BK 64, 3 stages,  96 KB, 4 waves
+using RingB = ring::Cfg<4, 2, 2, 2, 64, 3>;   // 256x128, BK 64, 3 stages, 144 KB, 8 waves
+using RingC = ring::Cfg<4, 2, 2, 4, 32, 4>;   // 256x256, BK 32, 4 stages, 128 KB, 8 waves
+using RingD = ring::Cfg<2, 2, 2, 2, 32, 4>;   // 128x128, BK 32, 4 stages,  64 KB, 4 waves (2 blocks/CU)
+using RingE = ring::Cfg<4, 2, 2, 4, 64, 2>;   // 256x256, BK 64, 2 stages, 128 KB
+using RingF = ring::Cfg<2, 4, 4, 2, 64, 2>;   // 256x256 (wave 128x64), BK 64, 2 stages
+using RingG = ring::Cfg<4, 2, 2, 4, 32, 3>;   // 256x256, BK 32, 3 stages, 96 KB
+using RingH = ring::Cfg<2, 2, 2, 2, 64, 2>;   // 128x128, BK 64, 2 stages, 64 KB (2 blocks/CU)
+
+int nt_config_override() {
+    static int v = -2;
+    if (v == -2) {
+        const char* e = getenv("MERLOT_NT_CFG");
+        v = e ? atoi(e) : -1;
+    }
+    return v;
+}
+
 int gemm_nt_dispatch(GemmNTArgs& a, int epilogue, int out_f32, bool patch, hipStream_t s) {
-    a.ntm = cdiv(a.M, BM);
-    a.ntn = cdiv(a.N, BN);
     if (patch) {
+        a.ntm = cdiv(a.M, BM);
+        a.ntn = cdiv(a.N, BN);
         MERLOT_CHECK(epilogue == MERLOT_EPI_NONE, MERLOT_ESHAPE, "patch embed supports EPI_NONE only");
         return launch_nt<MERLOT_EPI_NONE, true>(a, out_f32, s);
     }
+    if (const char* e = getenv("MERLOT_DBG")) a.dbg = atoi(e);
+    int cfg = nt_config_override();
+    if (const char* e = getenv("MERLOT_NT_CFG_DYN")) cfg = atoi(e);     // re-read every call (experiments only)
+    if (cfg < 0) {
+        // Pick the tile shape by a wave-quantisation model calibrated on MI355X (profiles/r01_gemm_tile_sweep.txt):
+        // cost = ceil(tiles / resident slots) * tile area / relative per-slot throughput.
+        struct Cand { int id, bm, bn, slots; float eff; };
+        const Cand cands[3] = {{3, 256, 256, 256, 1.0f}, {2, 256, 128, 256, 0.843f}, {8, 128, 128, 512, 0.4315f}};
+        float best = 3.4e38f;
+        for (const Cand& c : cands) {
+            const int64_t tiles = (int64_t)cdiv(a.M, c.bm) * cdiv(a.N, c.bn);
+            const float cost = (float)((tiles + c.slots - 1) / c.slots) * (float)(c.bm * c.bn) / c.eff;
+            if (cost < best) { best = cost; cfg = c.id; }
+        }
+    }
+    switch (cfg) {
+        case 1: return launch_ring<RingA>(a, epilogue, out_f32, s);
+        case 2: return launch_ring<RingB>(a, epilogue, out_f32, s);
+        case 3: return launch_ring<RingC>(a, epilogue, out_f32, s);
+        case 4: return launch_ring<RingD>(a, epilogue, out_f32, s);
+        case 5: return launch_ring<RingE>(a, epilogue, out_f32, s);
+        case 6: return launch_ring<RingF>(a, epilogue, out_f32, s);
+        case 7: return launch_ring<RingG>(a, epilogue, out_f32, s);
+        case 8: return launch_ring<RingH>(a, epilogue, out_f32, s);
+        default: break;
+    }
+    a.ntm = cdiv(a.M, BM);
+    a.ntn = cdiv(a.N, BN);
     switch (epilogue) {
         case MERLOT_EPI_NONE: return launch_nt<MERLOT_EPI_NONE, false>(a, out_f32, s);
         case MERLOT_EPI_GELU: return launch_nt<MERLOT_EPI_GELU, false>(a, out_f32, s);
@@ -426,12 +912,12 @@ int gemm_nt_dispatch(GemmNTArgs& a, int epilogue, int out_f32, bool patch, hipSt
     return MERLOT_ESHAPE;
 }
 
-int gemm_tn_dispatch(GemmTNArgs& a, int accumulate, bool patch_b, hipStream_t s) {
+int tn_launch(GemmTNArgs& a, int accumulate, bool patch_b, bool v2, hipStream_t s) {
     a.ntm = cdiv(a.M, BM);
     a.ntn = cdiv(a.N, BN);
     const int tiles = a.ntm * a.ntn;
-    int splits = cdiv(768, tiles);
-    const int max_splits = (a.R + 255) / 256;
+    int splits = cdiv(512, tiles);
+    const int max_splits = (a.R + 511) / 512;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     int rchunk = (int)(((a.R + splits - 1) / splits + BK - 1) / BK) * BK;
@@ -449,6 +935,82 @@ int gemm_tn_dispatch(GemmTNArgs& a, int accumulate, bool patch_b, hipStream_t s)
     else
         hipLaunchKernelGGL((gemm_tn_kernel<false>), dim3(grid), dim3(256), 0, s, a);
     return merlot_launch_status("merlot_gemm_bf16_tn");
+}
+
+using TnRingC = ring::Cfg<4, 2, 2, 4, 32, 4>;   // 256x256, BK 32, 4 stages, 8 waves, 1 workgroup / CU
+
+// split plan of the ring TN kernel (shared with the workspace-size query)
+struct TnPlan {
+    int ntm, ntn, splits, chunk;
+};
+TnPlan tn_plan(int64_t M, int64_t N, int64_t R) {
+    TnPlan pl;
+    pl.ntm = cdiv(M, TnRingC::BM);
+    pl.ntn = cdiv(N, TnRingC::BN);
+    const int tiles = pl.ntm * pl.ntn;
+    const int ksteps = (int)(R / TnRingC::BK);
+    int splits = 256 / tiles;                            // one round of 256 CUs
+    if (splits < 1) splits = 1;
+    if (splits > ksteps / 8) splits = ksteps / 8 > 0 ? ksteps / 8 : 1;
+    if (const char* env = getenv("MERLOT_TN_SPLITS")) {   // tuning / experiments only
+        const int v = atoi(env);
+        if (v > 0) splits = v > ksteps ? ksteps : v;
+    }
+    pl.chunk = (ksteps + splits - 1) / splits;
+    pl.splits = (ksteps + pl.chunk - 1) / pl.chunk;
+    return pl;
+}
+
+int tn_ring_launch(GemmTNArgs& a, int accumulate, float* ws, int64_t ws_bytes, hipStream_t s) {
+    using C = TnRingC;
+    const TnPlan pl = tn_plan(a.M, a.N, a.R);
+    a.ntm = pl.ntm; a.ntn = pl.ntn; a.splits = pl.splits; a.rchunk = pl.chunk;
+    a.use_atomics = accumulate;                          // meaning here: accumulate into C when splits == 1
+    if (const char* e = getenv("MERLOT_DBG")) a.dbg = atoi(e);
+    if (pl.splits > 1) {
+        const int64_t need = (int64_t)pl.splits * a.M * a.N * 4;
+        MERLOT_CHECK(ws != nullptr && ws_bytes >= need, MERLOT_ESHAPE,
+                     "merlot_gemm_bf16_tn: workspace too small (%lld < %lld bytes)", (long long)ws_bytes, (long long)need);
+    }
+    auto kern = gemm_tn_ring_kernel<C>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           C::LDS_BYTES);
+        MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(pl.ntm * pl.ntn * pl.splits), dim3(C::NT), C::LDS_BYTES, s, a, ws);
+    if (pl.splits > 1) {
+        int64_t total = (int64_t)a.M * (a.N / 4);
+        int grid = (int)((total + 255) / 256);
+        if (grid > 2048) grid = 2048;
+        hipLaunchKernelGGL(tn_reduce_kernel, dim3(grid), dim3(256), 0, s, ws, pl.splits, a.C, a.ldc, a.M, a.N, accumulate);
+    }
+    return merlot_launch_status("merlot_gemm_bf16_tn(ring)");
+}
+
+bool tn_ring_ok(const GemmTNArgs& a) {
+    const auto pad8 = [](int64_t x) { return (x + 7) / 8 * 8; };
+    return a.R >= 8 * TnRingC::BK && (a.lda % 8 == 0) && (a.ldb % 8 == 0) && a.lda >= pad8(a.M) && a.ldb >= pad8(a.N) &&
+           (a.N % 8 == 0) && (a.ldc % 4 == 0) && (((uintptr_t)a.A | (uintptr_t)a.B | (uintptr_t)a.C) & 15) == 0;
+}
+
+int gemm_tn_dispatch(GemmTNArgs& a, int accumulate, bool patch_b, float* ws, int64_t ws_bytes, hipStream_t s) {
+    if (patch_b || !tn_ring_ok(a)) return tn_launch(a, accumulate, patch_b, false, s);
+    // main part: the first floor(R/32)*32 reduction rows through the ring kernel; the (< 32 row) tail, if any,
+    // through the register-staged kernel accumulating on top.
+    const int R = a.R;
+    const int r_main = R / TnRingC::BK * TnRingC::BK;
+    GemmTNArgs m = a;
+    m.R = r_main;
+    int rc = tn_ring_launch(m, accumulate, ws, ws_bytes, s);
+    if (rc != MERLOT_OK || r_main == R) return rc;
+    GemmTNArgs t = a;
+    t.A = a.A + (int64_t)r_main * a.lda;
+    t.B = a.B + (int64_t)r_main * a.ldb;
+    t.R = R - r_main;
+    return tn_launch(t, 1, false, false, s);
 }
 
 }  // namespace
@@ -483,9 +1045,15 @@ extern "C" int merlot_gemm_bf16_nt(const void* A, int64_t lda, const void* Bt, i
     return gemm_nt_dispatch(a, epilogue, out_f32, false, (hipStream_t)stream);
 }
 
+extern "C" int64_t merlot_gemm_bf16_tn_workspace_bytes(int64_t M, int64_t N, int64_t R) {
+    if (M <= 0 || N <= 0 || R < 8 * TnRingC::BK) return 0;
+    const TnPlan pl = tn_plan(M, N, R / TnRingC::BK * TnRingC::BK);
+    return pl.splits > 1 ? (int64_t)pl.splits * M * N * 4 : 0;
+}
+
 extern "C" int merlot_gemm_bf16_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
-                                   int64_t M, int64_t N, int64_t R, float alpha, int accumulate,
-                                   merlot_stream_t stream) {
+                                   int64_t M, int64_t N, int64_t R, float alpha, int accumulate, void* workspace,
+                                   int64_t workspace_bytes, merlot_stream_t stream) {
     MERLOT_CHECK(A && B && C, MERLOT_ESHAPE, "merlot_gemm_bf16_tn: null operand");
     MERLOT_CHECK(M > 1 && N > 1 && R > 0 && R < (1LL << 31), MERLOT_ESHAPE, "merlot_gemm_bf16_tn: bad dims");
     MERLOT_CHECK(M % 2 == 0 && N % 2 == 0 && lda % 2 == 0 && ldb % 2 == 0, MERLOT_EALIGN,
@@ -494,7 +1062,7 @@ extern "C" int merlot_gemm_bf16_tn(const void* A, int64_t lda, const void* B, in
     a.A = (const bf16*)A; a.B = (const bf16*)B; a.C = C;
     a.lda = lda; a.ldb = ldb; a.ldc = ldc;
     a.M = (int)M; a.N = (int)N; a.R = (int)R; a.alpha = alpha;
-    return gemm_tn_dispatch(a, accumulate, false, (hipStream_t)stream);
+    return gemm_tn_dispatch(a, accumulate, false, (float*)workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 static int check_patch(int n_img, int H, int W, int P, int hidden) {
@@ -529,5 +1097,5 @@ extern "C" int merlot_patch_embed_wgrad(const void* image, int n_img, int H, int
     a.lda = hidden; a.ldb = 0; a.ldc = P * P * 3;
     a.M = hidden; a.N = P * P * 3; a.R = n_img * (H / P) * (W / P); a.alpha = 1.f;
     a.pg = PatchGeom{H, W, P, H / P, W / P};
-    return gemm_tn_dispatch(a, accumulate, true, (hipStream_t)stream);
+    return gemm_tn_dispatch(a, accumulate, true, nullptr, 0, (hipStream_t)stream);
 }

@@ -17,6 +17,7 @@ _CTYPES = {
     'const int32_t*': ctypes.c_void_p, 'int32_t*': ctypes.c_void_p,
     'const uint8_t*': ctypes.c_void_p,
     'int64_t': ctypes.c_int64, 'uint64_t': ctypes.c_uint64, 'int': ctypes.c_int, 'float': ctypes.c_float,
+    'double': ctypes.c_double,
     'merlot_stream_t': ctypes.c_void_p,
 }
 
@@ -30,7 +31,7 @@ def parse_header(path=HEADER):
     src = open(path).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
     protos = {}
-    for m in re.finditer(r'\b(int|const char\*)\s+(merlot_\w+)\s*\(([^)]*)\)\s*;', src):
+    for m in re.finditer(r'\b(int64_t|int|const char\*)\s+(merlot_\w+)\s*\(([^)]*)\)\s*;', src):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         arglist = []
         if args and args != 'void':
@@ -58,10 +59,14 @@ class _Lib(object):
         dll = ctypes.CDLL(LIB_PATH)
         for name, (ret, args) in self.protos.items():
             fn = getattr(dll, name)
-            fn.restype = ctypes.c_char_p if ret != 'int' else ctypes.c_int
+            fn.restype = {'int': ctypes.c_int, 'int64_t': ctypes.c_int64}.get(ret, ctypes.c_char_p)
             fn.argtypes = [_CTYPES[t] for t, _ in args]
         self._dll = dll
         return dll
+
+    def query(self, name, *args):
+        """call a function whose return value is data, not a status (e.g. *_workspace_bytes)."""
+        return getattr(self.load(), name)(*args)
 
     def call(self, name, *args):
         dll = self.load()

@@ -5,7 +5,7 @@ hand-written gfx950 kernels in libmerlot_hip.so.  There is no eager / CPU fallba
 """
 import torch
 
-from .lib import call
+from .lib import call, LIB
 
 EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU = 0, 1, 2, 3
 BF16 = torch.bfloat16
@@ -88,9 +88,12 @@ def gemm_tn(a, b, out, *, accumulate=True, alpha=1.0, m=None, n=None):
     R = a.shape[0]
     M = a.shape[1] if m is None else m
     N = b.shape[1] if n is None else n
+    nbytes = LIB.query('merlot_gemm_bf16_tn_workspace_bytes', M, N, R)
+    ws = torch.empty(nbytes // 4, device=a.device, dtype=F32) if nbytes else None   # caller-owned split-R partials
+
     def launch():
         call('merlot_gemm_bf16_tn', _p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, R,
-             float(alpha), 1 if accumulate else 0, _stream())
+             float(alpha), 1 if accumulate else 0, _p(ws), nbytes, _stream())
 
     if TIMER is not None:
         TIMER.time('gemm_tn', 2.0 * M * N * R, launch)

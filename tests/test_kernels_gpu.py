@@ -120,16 +120,27 @@ def test_gemm_nt_dropout_statistics(ops):
 
 
 @pytest.mark.parametrize("R,M,N", [(64, 128, 128), (1000, 768, 768), (777, 2304, 768), (300, 50370, 768), (5000, 768, 3072),
-                                   (130, 4, 768)])
+                                   (130, 4, 768), (4096, 3072, 768), (50, 768, 768)])
 def test_gemm_tn(ops, R, M, N):
     g = torch.Generator().manual_seed(R + M)
-    a, b = rnd((R, M + (M % 8 and 8 - M % 8)), g)[:, :], rnd((R, N), g)
-    ref = E.gemm_tn(a, b, torch.zeros((M, N)), accumulate=False, m=M)
+    a, b = rnd((R, M), g), rnd((R, N), g)
+    ref = E.gemm_tn(a, b, torch.zeros((M, N)), accumulate=False)
     out = torch.full((M, N), 7.0).cuda()
-    ops.gemm_tn(*dev(a, b), out, accumulate=False, m=M)
+    ops.gemm_tn(*dev(a, b), out, accumulate=False)
     assert rel_l2(out, ref) < 2e-3
-    ops.gemm_tn(*dev(a, b), out, accumulate=True, alpha=2.0, m=M)
+    ops.gemm_tn(*dev(a, b), out, accumulate=True, alpha=2.0)
     assert rel_l2(out, 3 * ref) < 2e-3
+
+
+def test_gemm_tn_padded_leading_dims(ops):
+    """the LM-head shape: A = dlogits [T, V] living in a [T, Vpad] buffer, output rows limited to V."""
+    g = torch.Generator().manual_seed(9)
+    R, V, Vpad, N = 200, 1002, 1024, 768
+    abuf, b = rnd((R, Vpad), g), rnd((R, N), g)
+    ref = E.gemm_tn(abuf, b, torch.zeros((V, N)), accumulate=False, m=V)
+    out = torch.zeros((V, N)).cuda()
+    ops.gemm_tn(abuf.cuda(), b.cuda(), out, accumulate=False, m=V)
+    assert rel_l2(out, ref) < 2e-3
 
 
 def test_patch_embed(ops):
