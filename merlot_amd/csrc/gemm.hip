@@ -857,6 +857,9 @@ using RingE = ring::Cfg<4, 2, 2, 4, 64, 2>;   // 256x256, BK 64, 2 stages, 128 K
 using RingF = ring::Cfg<2, 4, 4, 2, 64, 2>;   // 256x256 (wave 128x64), BK 64, 2 stages
 using RingG = ring::Cfg<4, 2, 2, 4, 32, 3>;   // 256x256, BK 32, 3 stages, 96 KB
 using RingH = ring::Cfg<2, 2, 2, 2, 64, 2>;   // 128x128, BK 64, 2 stages, 64 KB (2 blocks/CU)
+using RingI = ring::Cfg<4, 2, 2, 2, 32, 3>;   // 256x128, BK 32, 3 stages, 72 KB (2 blocks/CU, 16 waves)
+using RingJ = ring::Cfg<4, 2, 2, 4, 32, 5>;   // 256x256, BK 32, 5 stages, 160 KB
+using RingK = ring::Cfg<2, 4, 2, 2, 32, 3>;   // 128x256, BK 32, 3 stages, 72 KB (2 blocks/CU)
 
 int nt_config_override() {
     static int v = -2;
@@ -881,7 +884,7 @@ int gemm_nt_dispatch(GemmNTArgs& a, int epilogue, int out_f32, bool patch, hipSt
         // Pick the tile shape by a wave-quantisation model calibrated on MI355X (profiles/r01_gemm_tile_sweep.txt):
         // cost = ceil(tiles / resident slots) * tile area / relative per-slot throughput.
         struct Cand { int id, bm, bn, slots; float eff; };
-        const Cand cands[3] = {{3, 256, 256, 256, 1.0f}, {2, 256, 128, 256, 0.843f}, {8, 128, 128, 512, 0.4315f}};
+        const Cand cands[2] = {{3, 256, 256, 256, 1.0f}, {11, 128, 256, 512, 0.54f}};
         float best = 3.4e38f;
         for (const Cand& c : cands) {
             const int64_t tiles = (int64_t)cdiv(a.M, c.bm) * cdiv(a.N, c.bn);
@@ -898,6 +901,9 @@ int gemm_nt_dispatch(GemmNTArgs& a, int epilogue, int out_f32, bool patch, hipSt
         case 6: return launch_ring<RingF>(a, epilogue, out_f32, s);
         case 7: return launch_ring<RingG>(a, epilogue, out_f32, s);
         case 8: return launch_ring<RingH>(a, epilogue, out_f32, s);
+        case 9: return launch_ring<RingI>(a, epilogue, out_f32, s);
+        case 10: return launch_ring<RingJ>(a, epilogue, out_f32, s);
+        case 11: return launch_ring<RingK>(a, epilogue, out_f32, s);
         default: break;
     }
     a.ntm = cdiv(a.M, BM);
