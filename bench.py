@@ -117,7 +117,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--examples', type=int, default=16, help='examples (x16 segments) per GPU per step')
+    ap.add_argument('--examples', type=int, default=32, help='examples (x16 segments) per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--cpu-baseline-worker', type=int, default=0, help=argparse.SUPPRESS)

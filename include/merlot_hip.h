@@ -83,10 +83,15 @@ int merlot_patch_embed_wgrad(const void* image, int n_img, int H, int W, int P, 
 int merlot_ln_fwd(const void* x, int x_f32, const float* gamma, const float* beta, void* y_bf16, float* y_f32,
                   float* mean, float* rstd, int64_t rows, int H, float eps, merlot_stream_t stream);
 /* dx = LN'(dy) (+ dres) ; dgamma/dbeta (f32 [H]) are ACCUMULATED with atomics.  dy, x, dres, dx each bf16
- * or f32 per flag; dres may be NULL. */
+ * or f32 per flag; dres may be NULL.
+ * Optional fused tail for the residual stream (all NULL/0 to disable): dcolsum[H] += column sums of d_branch, where
+ * d_branch = dx when drop_p == 0, else d_branch = dropout'(dx) with the (drop_seed, row*H+col) mask of the forward
+ * MERLOT_EPI_RESIDUAL epilogue, also written to dx_drop (bf16 [rows, H]).  d_branch is the gradient of the previous
+ * sub-layer's branch output and dcolsum its bias gradient (utils/transformer.py:136,162,214,220). */
 int merlot_ln_bwd(const void* dy, int dy_f32, const void* x, int x_f32, const float* mean, const float* rstd,
                   const float* gamma, const void* dres, int dres_f32, void* dx, int dx_f32, float* dgamma,
-                  float* dbeta, int64_t rows, int H, merlot_stream_t stream);
+                  float* dbeta, int64_t rows, int H, void* dx_drop, float drop_p, uint64_t drop_seed,
+                  float* dcolsum, merlot_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused scaled-dot-product attention (utils/transformer.py:98-127), head_dim = 64.

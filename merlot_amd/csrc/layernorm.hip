@@ -82,21 +82,27 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
 
 // backward: grid-stride over rows; each wave keeps per-lane partial dgamma/dbeta for its 4*NS columns,
 // reduced across the 4 waves through LDS and pushed with one atomicAdd per column per block.
+// Optional fused tail (transformer layers): the residual-stream gradient dx that this kernel produces is exactly the
+// gradient of the PREVIOUS sub-layer's `h + dropout(branch)`; so the kernel can also emit d_branch = dropout'(dx)
+// (same counter-based mask as the forward GEMM epilogue) and accumulate its column sums = that sub-layer's bias
+// gradient, saving one dropout pass and one column-sum pass over [T, H] per sub-layer.
 template <int NS, typename TDY, typename TX, typename TR, typename TDX>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const TR* __restrict__ dres,
                                                      TDX* __restrict__ dx, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int64_t rows) {
+                                                     float* __restrict__ dbeta, int64_t rows, bf16* __restrict__ dx_drop,
+                                                     uint32_t drop_thresh, float drop_scale, uint64_t drop_seed,
+                                                     float* __restrict__ dcolsum) {
     constexpr int H = NS * 256;
-    __shared__ float red[2][4][H];
+    __shared__ float red[3][4][H];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float g[NS][4], dg[NS][4], db[NS][4];
+    float g[NS][4], dg[NS][4], db[NS][4], dc[NS][4];
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         load4<float>(gamma + i * 256 + lane * 4, g[i]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dg[i][e] = db[i][e] = 0.f;
+        for (int e = 0; e < 4; ++e) dg[i][e] = db[i][e] = dc[i][e] = 0.f;
     }
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
         const float mu = mean[row], rs = rstd[row];
@@ -131,6 +137,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
                 for (int e = 0; e < 4; ++e) o[e] += r[e];
             }
             store4(dx + row * H + i * 256 + lane * 4, o);
+            if (dcolsum) {
+                if (drop_thresh) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const uint64_t idx = (uint64_t)row * H + (uint64_t)(i * 256 + lane * 4 + e);
+                        // the branch gradient is taken from the value as the next kernels will read it (bf16)
+                        const float ob = sizeof(TDX) == 2 ? (float)(bf16)o[e] : o[e];
+                        o[e] = dropout_keep(drop_seed, idx, drop_thresh) ? ob * drop_scale : 0.f;
+                    }
+                    store4(dx_drop + row * H + i * 256 + lane * 4, o);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dc[i][e] += sizeof(TDX) == 2 ? (float)(bf16)o[e] : o[e];
+            }
         }
     }
 #pragma unroll
@@ -139,6 +159,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
         for (int e = 0; e < 4; ++e) {
             red[0][wave][i * 256 + lane * 4 + e] = dg[i][e];
             red[1][wave][i * 256 + lane * 4 + e] = db[i][e];
+            red[2][wave][i * 256 + lane * 4 + e] = dc[i][e];
         }
     __syncthreads();
     for (int c = threadIdx.x; c < H; c += 256) {
@@ -146,6 +167,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
         const float sb = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
         if (dgamma) atomicAdd(dgamma + c, sg);
         if (dbeta) atomicAdd(dbeta + c, sb);
+        if (dcolsum) atomicAdd(dcolsum + c, red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c]);
     }
 }
 
@@ -169,13 +191,17 @@ int ln_fwd_launch(const void* x, int x_f32, const float* gamma, const float* bet
 //   3: f32  bf16 bf16 bf16
 template <int NS>
 int ln_bwd_launch(int combo, const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
-                  const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, hipStream_t s) {
+                  const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, void* dx_drop, float drop_p,
+                  uint64_t drop_seed, float* dcolsum, hipStream_t s) {
+    const uint32_t thresh = (dx_drop && drop_p > 0.f) ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
+    const float dscale = 1.0f / (1.0f - drop_p);
     int nblk = cdiv(rows, 4);
     if (nblk > 2048) nblk = 2048;
     const dim3 grid(nblk), block(256);
 #define LN_BWD(TDY, TX, TR, TDX)                                                                                      \
     hipLaunchKernelGGL((ln_bwd_kernel<NS, TDY, TX, TR, TDX>), grid, block, 0, s, (const TDY*)dy, (const TX*)x, mean,  \
-                       rstd, gamma, (const TR*)dres, (TDX*)dx, dgamma, dbeta, rows)
+                       rstd, gamma, (const TR*)dres, (TDX*)dx, dgamma, dbeta, rows, (bf16*)dx_drop, thresh,     \
+                       dscale, drop_seed, dcolsum)
     switch (combo) {
         case 0: LN_BWD(bf16, bf16, bf16, bf16); break;
         case 1: LN_BWD(float, float, float, float); break;
@@ -208,8 +234,11 @@ extern "C" int merlot_ln_fwd(const void* x, int x_f32, const float* gamma, const
 
 extern "C" int merlot_ln_bwd(const void* dy, int dy_f32, const void* x, int x_f32, const float* mean, const float* rstd,
                              const float* gamma, const void* dres, int dres_f32, void* dx, int dx_f32, float* dgamma,
-                             float* dbeta, int64_t rows, int H, merlot_stream_t stream) {
+                             float* dbeta, int64_t rows, int H, void* dx_drop, float drop_p, uint64_t drop_seed,
+                             float* dcolsum, merlot_stream_t stream) {
     MERLOT_CHECK(dy && x && mean && rstd && gamma && dx, MERLOT_ESHAPE, "merlot_ln_bwd: null operand");
+    MERLOT_CHECK(drop_p >= 0.f && drop_p < 1.f, MERLOT_ESHAPE, "merlot_ln_bwd: drop_p out of range");
+    MERLOT_CHECK(!(drop_p > 0.f && dx_drop) || dcolsum, MERLOT_ESHAPE, "merlot_ln_bwd: dx_drop needs dcolsum");
     MERLOT_CHECK(rows > 0, MERLOT_ESHAPE, "merlot_ln_bwd: rows must be > 0");
     if (!dres) dres_f32 = dx_f32;
     int combo = -1;
@@ -218,5 +247,6 @@ extern "C" int merlot_ln_bwd(const void* dy, int dy_f32, const void* x, int x_f3
     else if (!dy_f32 && x_f32 && dres_f32 && dx_f32) combo = 2;
     else if (dy_f32 && !x_f32 && !dres_f32 && !dx_f32) combo = 3;
     hipStream_t s = (hipStream_t)stream;
-    LN_DISPATCH_H(H, (ln_bwd_launch<NS>(combo, dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, rows, s)));
+    LN_DISPATCH_H(H, (ln_bwd_launch<NS>(combo, dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, rows, dx_drop, drop_p,
+                                        drop_seed, dcolsum, s)));
 }

@@ -95,30 +95,36 @@ class TransformerStackFn(torch.autograd.Function):
         store = stack.store
         hL, meanf, rstdf = ctx.final
         dy = dy.contiguous()
-        dh = ops.ln_bwd(dy, hL, meanf, rstdf, stack.ln_final.gamma, stack.ln_final.ggamma, stack.ln_final.gbeta)
-        for l in range(ctx.nl - 1, -1, -1):
+        nl = ctx.nl
+        # every ln_bwd also emits the branch gradient of the sub-layer BELOW it (dropout mask regenerated from the
+        # counter hash) and accumulates that sub-layer's bias gradient -- no separate dropout / column-sum passes.
+        dh, db2 = ops.ln_bwd(dy, hL, meanf, rstdf, stack.ln_final.gamma, stack.ln_final.ggamma, stack.ln_final.gbeta,
+                             branch_bias_grad=stack.layers[nl - 1].fc2.gb, drop_p=p, drop_seed=_site_seed(seed, nl - 1, 1))
+        for l in range(nl - 1, -1, -1):
             w = stack.layers[l]
             h, mean1, rstd1, x1, qkv, ctx_, lse, h_mid, mean2, rstd2, x2, u, a = ctx.saved[l]
             ctx.saved[l] = None
-            # ---- MLP branch: h_out = h_mid + drop(fc2(gelu(fc1(LN2(h_mid)))))
-            db2 = ops.dropout_apply(dh, p, _site_seed(seed, l, 1)) if p > 0 else dh
-            ops.colsum_bf16(db2, w.fc2.gb)
+            # ---- MLP branch: h_out = h_mid + drop(fc2(gelu(fc1(LN2(h_mid)))))          db2 = d(fc2 output)
             ops.gemm_tn(db2, a, w.fc2.gw)                                       # dW2[H, I]
             du = ops.gemm_nt(db2, w.fc2.wbT, epilogue=EPI_DGELU, aux_in=u)      # [T, I]
             ops.colsum_bf16(du, w.fc1.gb)
             ops.gemm_tn(du, x2, w.fc1.gw)                                       # dW1[I, H]
             dx2 = ops.gemm_nt(du, w.fc1.wbT)
-            dh_mid = ops.ln_bwd(dx2, h_mid, mean2, rstd2, w.ln2.gamma, w.ln2.ggamma, w.ln2.gbeta, dres=dh)
-            # ---- attention branch: h_mid = h + drop(proj(attn(qkv(LN1(h)))))
-            db1 = ops.dropout_apply(dh_mid, p, _site_seed(seed, l, 0)) if p > 0 else dh_mid
-            ops.colsum_bf16(db1, w.proj.gb)
+            dh_mid, db1 = ops.ln_bwd(dx2, h_mid, mean2, rstd2, w.ln2.gamma, w.ln2.ggamma, w.ln2.gbeta, dres=dh,
+                                     branch_bias_grad=w.proj.gb, drop_p=p, drop_seed=_site_seed(seed, l, 0))
+            # ---- attention branch: h_mid = h + drop(proj(attn(qkv(LN1(h)))))             db1 = d(proj output)
             ops.gemm_tn(db1, ctx_, w.proj.gw)
             dctx = ops.gemm_nt(db1, w.proj.wbT)
             dqkv = ops.attention_bwd(qkv, ctx_, dctx, lse, B, S, heads, valid)
             ops.colsum_bf16(dqkv, w.qkv.gb)
             ops.gemm_tn(dqkv, x1, w.qkv.gw)
             dx1 = ops.gemm_nt(dqkv, w.qkv.wbT)
-            dh = ops.ln_bwd(dx1, h, mean1, rstd1, w.ln1.gamma, w.ln1.ggamma, w.ln1.gbeta, dres=dh_mid)
+            if l > 0:
+                dh, db2 = ops.ln_bwd(dx1, h, mean1, rstd1, w.ln1.gamma, w.ln1.ggamma, w.ln1.gbeta, dres=dh_mid,
+                                     branch_bias_grad=stack.layers[l - 1].fc2.gb, drop_p=p,
+                                     drop_seed=_site_seed(seed, l - 1, 1))
+            else:
+                dh = ops.ln_bwd(dx1, h, mean1, rstd1, w.ln1.gamma, w.ln1.ggamma, w.ln1.gbeta, dres=dh_mid)
             store.notify_ready(w.name)
         store.notify_ready(stack.scope + '/LayerNorm_ln_final')
         ctx.saved = None

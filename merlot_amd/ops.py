@@ -134,17 +134,26 @@ def ln_fwd(x, gamma, beta, *, out_bf16=True, out_f32=False, save_stats=True, eps
     return y16, y32, mean, rstd
 
 
-def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, dres=None, dx_dtype=None):
-    """dx = LN'(dy) (+dres); dgamma/dbeta accumulated in place."""
+def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, dres=None, dx_dtype=None, branch_bias_grad=None, drop_p=0.0,
+           drop_seed=0):
+    """dx = LN'(dy) (+dres); dgamma/dbeta accumulated in place.  With `branch_bias_grad` (f32 [H]) the kernel also
+    accumulates the column sums of d_branch = dropout'(dx) into it and returns (dx, d_branch) (d_branch is dx when
+    drop_p == 0)."""
     assert dy.is_contiguous() and x.is_contiguous()
     H = x.shape[-1]
     rows = x.numel() // H
     dx_dtype = dx_dtype or x.dtype
     dx = torch.empty(x.shape, device=x.device, dtype=dx_dtype)
+    dx_drop = None
+    if branch_bias_grad is not None and drop_p > 0:
+        dx_drop = torch.empty(x.shape, device=x.device, dtype=BF16)
     call('merlot_ln_bwd', _p(dy), 1 if dy.dtype == F32 else 0, _p(x), 1 if x.dtype == F32 else 0, _p(mean), _p(rstd),
          _p(gamma), _p(dres), 1 if (dres is not None and dres.dtype == F32) else 0, _p(dx), 1 if dx_dtype == F32 else 0,
-         _p(dgamma), _p(dbeta), rows, H, _stream())
-    return dx
+         _p(dgamma), _p(dbeta), rows, H, _p(dx_drop), float(drop_p), int(drop_seed) & 0xFFFFFFFFFFFFFFFF,
+         _p(branch_bias_grad), _stream())
+    if branch_bias_grad is None:
+        return dx
+    return dx, (dx_drop if dx_drop is not None else dx)
 
 
 def attention_fwd(qkv, B, S, heads, valid=None, need_lse=True):

@@ -87,7 +87,8 @@ def ln_fwd(x, gamma, beta, *, out_bf16=True, out_f32=False, save_stats=True, eps
             mean.reshape(-1) if save_stats else None, rstd.reshape(-1) if save_stats else None)
 
 
-def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, dres=None, dx_dtype=None):
+def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, dres=None, dx_dtype=None, branch_bias_grad=None, drop_p=0.0,
+           drop_seed=0):
     H = x.shape[-1]
     xf, dyf = x.float().reshape(-1, H), dy.float().reshape(-1, H)
     xh = (xf - mean[:, None]) * rstd[:, None]
@@ -101,7 +102,12 @@ def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, dres=None, dx_dtype=None)
         dgamma += (dyf * xh).sum(0)
     if dbeta is not None:
         dbeta += dyf.sum(0)
-    return dx.to(dx_dtype or x.dtype).reshape(x.shape)
+    out = dx.to(dx_dtype or x.dtype).reshape(x.shape)
+    if branch_bias_grad is None:
+        return out
+    assert drop_p == 0.0, "emulation supports p=0 only"
+    branch_bias_grad += out.float().reshape(-1, H).sum(0)
+    return out, out
 
 
 def _attn_probs(qkv, B, S, heads, valid):

@@ -179,6 +179,27 @@ def test_layernorm(ops, rows, H, xf32):
     assert rel_l2(dx, dx_r) < tol and rel_l2(dg, dg_r) < 1e-4 and rel_l2(db, db_r) < 1e-4
 
 
+def test_layernorm_bwd_fused_branch_gradient(ops):
+    """the fused tail of ln_bwd == separate dropout_apply + colsum passes on its dx output (same counter mask)."""
+    g = torch.Generator().manual_seed(21)
+    rows, H = 3000, 768
+    x, dy, dres = rnd((rows, H), g), rnd((rows, H), g), rnd((rows, H), g)
+    gamma, beta = 1 + 0.1 * torch.randn(H, generator=g), torch.zeros(H)
+    _, _, mean, rstd = ops.ln_fwd(x.cuda(), gamma.cuda(), beta.cuda())
+    for p_drop in (0.0, 0.1):
+        dg, db, dbias = torch.zeros(H).cuda(), torch.zeros(H).cuda(), torch.zeros(H).cuda()
+        dx, dbr = ops.ln_bwd(dy.cuda(), x.cuda(), mean, rstd, gamma.cuda(), dg, db, dres=dres.cuda(),
+                             branch_bias_grad=dbias, drop_p=p_drop, drop_seed=1234)
+        dg2, db2 = torch.zeros(H).cuda(), torch.zeros(H).cuda()
+        dx_ref = ops.ln_bwd(dy.cuda(), x.cuda(), mean, rstd, gamma.cuda(), dg2, db2, dres=dres.cuda())
+        assert torch.equal(dx, dx_ref) and rel_l2(dg, dg2) < 1e-5
+        br_ref = ops.dropout_apply(dx_ref, p_drop, 1234) if p_drop > 0 else dx_ref
+        assert torch.equal(dbr, br_ref)
+        cs = torch.zeros(H).cuda()
+        ops.colsum_bf16(br_ref, cs, accumulate=False)
+        assert rel_l2(dbias, cs) < 1e-4
+
+
 # ---- attention ---------------------------------------------------------------------------------------------
 def _attn_inputs(B, S, heads, seed, pad):
     g = torch.Generator().manual_seed(seed)
