@@ -116,10 +116,22 @@ __device__ __forceinline__ constexpr int acc_row(int r) { return (r & 3) + 8 * (
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
-    __shared__ __attribute__((aligned(1024))) char smem[2 * 8192];
+// Mask handling without per-element selects: per key tile, 64 threads write two additive bias vectors (log2 units)
+//   biasA[key] = 0 (valid key) | -1e10*log2e (masked key) | -inf (beyond S)      -- view of a VALID query row
+//   biasB[key] = 0 (any key in range)                     | -inf (beyond S)      -- view of a PADDED query row
+// and every lane reads its 32 key slots as 8 x 16 B from the array matching its own query row, with
+// score' = fma(score, sc_lane, bias), sc_lane = scale*log2e for a valid row and 0 for a padded one (-> uniform).
+constexpr float RESCALE_THR = 8.0f;   // defer-max: rescale O only when a row's running max grows by > 2^8
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+template <bool MASKED>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
+    __shared__ __attribute__((aligned(1024))) char smem[2 * 8192 + 512];
     char* ldsK = smem;
     char* ldsV = smem + 8192;
+    float* biasA = reinterpret_cast<float*>(smem + 16384);
+    float* biasB = biasA + 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5;
@@ -130,10 +142,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     const bf16* base = p.qkv + (int64_t)b * S * p.ld + h * 64;
     const bf16* kbase = base + p.heads * 64;
     const bf16* vbase = base + 2 * p.heads * 64;
-    const uint8_t* vrow = p.valid ? p.valid + (int64_t)b * S : nullptr;
+    const uint8_t* vrow = MASKED ? p.valid + (int64_t)b * S : nullptr;
 
     const int q = min(qw0 + (lane & 31), S - 1);
-    const bool qv = vrow ? (vrow[q] != 0) : true;
+    const bool qv = MASKED ? (vrow[q] != 0) : true;
     bf16x8 qf[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
@@ -141,7 +153,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
 
     f32x16 o[2] = {zero16(), zero16()};
     float m_run = -INFINITY, l_run = 0.f;
-    const float sc = p.scale * LOG2E;
+    const float sc = qv ? p.scale * LOG2E : 0.f;
+    const float* bias = (qv ? biasA : biasB) + 4 * hi;
 
     const int nkt = (S + 63) / 64;
     u32x4 kreg[2], vreg[2];
@@ -151,19 +164,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
         __syncthreads();
         tile_store_lds<64>(ldsK, kreg, tid);
         tile_store_lds<64>(ldsV, vreg, tid);
+        const bool ragged = MASKED || (kt * 64 + 64 > S);        // wave-uniform: this tile needs the bias vectors
+        if (ragged && tid < 64) {
+            const int kidx = kt * 64 + tid;
+            const bool in = kidx < S;
+            const bool kval = in && (MASKED ? vrow[min(kidx, S - 1)] != 0 : true);
+            biasA[tid] = in ? (kval ? 0.f : MASKED_T) : -INFINITY;
+            biasB[tid] = in ? 0.f : -INFINITY;
+        }
         __syncthreads();
         if (kt + 1 < nkt) {
             tile_load_regs<64>(kbase, p.ld, (kt + 1) * 64, S - 1, kreg, tid);
             tile_load_regs<64>(vbase, p.ld, (kt + 1) * 64, S - 1, vreg, tid);
         }
         if (!wave_active) continue;
-
-        // key validity / range masks for this tile (bit = key index inside the tile)
-        const int kidx = kt * 64 + lane;
-        const bool in_range = kidx < S;
-        const bool kval = in_range && (vrow ? vrow[min(kidx, S - 1)] != 0 : true);
-        const uint64_t rmask = __ballot(in_range) >> (4 * hi);
-        const uint64_t vmask = __ballot(kval) >> (4 * hi);
 
         f32x16 st[2];
 #pragma unroll
@@ -176,38 +190,54 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
             }
         }
         float mloc = -INFINITY;
+        if (ragged) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int bit = kb * 32 + acc_row(r);
-                float t = st[kb][r] * sc;
-                t = ((vmask >> bit) & 1) ? t : MASKED_T;
-                t = qv ? t : 0.f;                       // padded query row: uniform over all keys (see header note)
-                t = ((rmask >> bit) & 1) ? t : -INFINITY;
-                st[kb][r] = t;
-                mloc = fmaxf(mloc, t);
-            }
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + kb * 32 + 8 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = fmaf(st[kb][4 * g + e], sc, b4[e]);
+                        st[kb][4 * g + e] = t;
+                        mloc = fmaxf(mloc, t);
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float t = st[kb][r] * sc;
+                    st[kb][r] = t;
+                    mloc = fmaxf(mloc, t);
+                }
+        }
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float m_new = fmaxf(m_run, mloc);
-        const float alpha = exp2f(m_run - m_new);
+        if (__any(mloc > m_run + RESCALE_THR)) {       // wave-uniform; always taken on the first tile (m_run = -inf)
+            const float m_new = fmaxf(m_run, mloc);
+            const float alpha = fast_exp2(m_run - m_new);
+            l_run *= alpha;
+            m_run = m_new;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        }
         float lsum = 0.f;
         bf16x8 pf[2][2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = exp2f(st[kb][r] - m_new);
+                const float pv = fast_exp2(st[kb][r] - m_run);
                 lsum += pv;
                 pf[kb][r >> 3][r & 7] = (bf16)pv;
             }
         lsum += __shfl_xor(lsum, 32, 64);
-        l_run = l_run * alpha + lsum;
-        m_run = m_new;
+        l_run += lsum;
 #pragma unroll
-        for (int db = 0; db < 2; ++db) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        for (int db = 0; db < 2; ++db)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -215,7 +245,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
                     const bf16x8 vf = tr_frag<64>(ldsV, kb * 32 + hf * 16 + 4 * hi, db * 32, lane);
                     o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][hf], o[db], 0, 0, 0);
                 }
-        }
     }
 
     if (wave_active && qw0 + (lane & 31) < S) {
@@ -262,12 +291,15 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs p, float
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward dQ: one wave per 32 query rows, loop over key tiles (same lane<->query layout as forward)
+// backward dQ: one wave per 32 query rows, loop over key tiles (same lane<->query layout and bias vectors as forward)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
-    __shared__ __attribute__((aligned(1024))) char smem[2 * 8192];
+template <bool MASKED>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
+    __shared__ __attribute__((aligned(1024))) char smem[2 * 8192 + 512];
     char* ldsK = smem;
     char* ldsV = smem + 8192;
+    float* biasA = reinterpret_cast<float*>(smem + 16384);
+    float* biasB = biasA + 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5;
@@ -278,10 +310,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
     const bf16* base = p.qkv + (int64_t)b * S * p.ld + h * 64;
     const bf16* kbase = base + p.heads * 64;
     const bf16* vbase = base + 2 * p.heads * 64;
-    const uint8_t* vrow = p.valid ? p.valid + (int64_t)b * S : nullptr;
+    const uint8_t* vrow = MASKED ? p.valid + (int64_t)b * S : nullptr;
 
     const int q = min(qw0 + (lane & 31), S - 1);
-    const bool qv = vrow ? (vrow[q] != 0) : true;
+    const bool qv = MASKED ? (vrow[q] != 0) : true;
     bf16x8 qf[4], dof[4];
     const bf16* dorow = p.dout + ((int64_t)b * S + q) * p.lddo + h * 64;
 #pragma unroll
@@ -292,7 +324,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
     const int64_t stat = ((int64_t)b * p.heads + h) * S + q;
     const float lse2 = p.lse[stat] * LOG2E;
     const float dl = p.delta[stat];
-    const float sc = p.scale * LOG2E;
+    const float sc = qv ? p.scale * LOG2E : 0.f;
+    const float dsc = qv ? p.scale : 0.f;             // masked pairs have p == 0 exactly; padded query rows get ds = 0
+    const float* bias = (qv ? biasA : biasB) + 4 * hi;
 
     f32x16 dq[2] = {zero16(), zero16()};
     const int nkt = (S + 63) / 64;
@@ -303,17 +337,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
         __syncthreads();
         tile_store_lds<64>(ldsK, kreg, tid);
         tile_store_lds<64>(ldsV, vreg, tid);
+        const bool ragged = MASKED || (kt * 64 + 64 > S);
+        if (ragged && tid < 64) {
+            const int kidx = kt * 64 + tid;
+            const bool in = kidx < S;
+            const bool kval = in && (MASKED ? vrow[min(kidx, S - 1)] != 0 : true);
+            biasA[tid] = in ? (kval ? 0.f : MASKED_T) : -INFINITY;
+            biasB[tid] = in ? 0.f : -INFINITY;
+        }
         __syncthreads();
         if (kt + 1 < nkt) {
             tile_load_regs<64>(kbase, p.ld, (kt + 1) * 64, S - 1, kreg, tid);
             tile_load_regs<64>(vbase, p.ld, (kt + 1) * 64, S - 1, vreg, tid);
         }
         if (!wave_active) continue;
-        const int kidx = kt * 64 + lane;
-        const bool in_range = kidx < S;
-        const bool kval = in_range && (vrow ? vrow[min(kidx, S - 1)] != 0 : true);
-        const uint64_t rmask = __ballot(in_range) >> (4 * hi);
-        const uint64_t vmask = __ballot(kval) >> (4 * hi);
 
         bf16x8 dsf[2][2];
 #pragma unroll
@@ -328,15 +365,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[kk], dp, 0, 0, 0);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int bit = kb * 32 + acc_row(r);
-                const bool live = qv && ((vmask >> bit) & 1);
-                float t = ((vmask >> bit) & 1) ? st[r] * sc : MASKED_T;
-                t = qv ? t : 0.f;
-                t = ((rmask >> bit) & 1) ? t : -INFINITY;
-                const float pv = exp2f(t - lse2);
-                const float ds = live ? pv * (dp[r] - dl) * p.scale : 0.f;
-                dsf[kb][r >> 3][r & 7] = (bf16)ds;
+            for (int g = 0; g < 4; ++g) {
+                f32x4 b4 = {-lse2, -lse2, -lse2, -lse2};
+                if (ragged) {
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(bias + kb * 32 + 8 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b4[e] += t4[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    const float pv = fast_exp2(fmaf(st[r], sc, b4[e]));
+                    dsf[kb][r >> 3][r & 7] = (bf16)(pv * (dp[r] - dl) * dsc);
+                }
             }
         }
 #pragma unroll
@@ -364,16 +405,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward dK/dV: one wave per 32 keys, loop over 64-row query tiles (lane <-> key layout)
+// backward dK/dV: one wave per 32 keys, loop over 64-row query tiles (lane <-> key layout).  Per query tile the
+// first wave publishes per-ROW vectors in LDS: lse2 (+inf beyond S => p = 0), delta, scq = scale*log2e (0 for a
+// padded row) and mq = -1e10*log2e (0 for a padded row); a lane with a masked key adds mq, others add 0.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnArgs p) {
-    // Q tile 8 KB | dO tile 8 KB | lse2[64] | delta[64] | qvalid mask (2 dwords) + qrange mask (2 dwords)
-    __shared__ __attribute__((aligned(1024))) char smem[2 * 8192 + 64 * 4 * 2 + 32];
+template <bool MASKED>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) {
+    __shared__ __attribute__((aligned(1024))) char smem[2 * 8192 + 4 * 256];
     char* ldsQ = smem;
     char* ldsO = smem + 8192;
     float* lds_lse = reinterpret_cast<float*>(smem + 16384);
     float* lds_dl = lds_lse + 64;
-    uint64_t* lds_mask = reinterpret_cast<uint64_t*>(smem + 16384 + 512);
+    float* lds_sc = lds_lse + 128;
+    float* lds_mq = lds_lse + 192;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5;
@@ -385,20 +429,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnArgs p) {
     const bf16* kbase = base + p.heads * 64;
     const bf16* vbase = base + 2 * p.heads * 64;
     const bf16* dobase = p.dout + (int64_t)b * S * p.lddo + h * 64;
-    const uint8_t* vrow = p.valid ? p.valid + (int64_t)b * S : nullptr;
+    const uint8_t* vrow = MASKED ? p.valid + (int64_t)b * S : nullptr;
     const float* lse_b = p.lse + ((int64_t)b * p.heads + h) * S;
     const float* dl_b = p.delta + ((int64_t)b * p.heads + h) * S;
 
     const int key = min(kw0 + (lane & 31), S - 1);
     const bool key_in = kw0 + (lane & 31) < S;
-    const bool kv = key_in && (vrow ? vrow[key] != 0 : true);
+    const float kmul = (MASKED && !(vrow[key] != 0)) ? 1.f : 0.f;     // 1 for a masked key
     bf16x8 kf[4], vf[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
         kf[kk] = *reinterpret_cast<const bf16x8*>(kbase + (int64_t)key * p.ld + kk * 16 + hi * 8);
         vf[kk] = *reinterpret_cast<const bf16x8*>(vbase + (int64_t)key * p.ld + kk * 16 + hi * 8);
     }
-    const float sc = p.scale * LOG2E;
+    const float sc_const = p.scale * LOG2E;
     f32x16 dk[2] = {zero16(), zero16()};
     f32x16 dv[2] = {zero16(), zero16()};
 
@@ -413,11 +457,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnArgs p) {
         if (tid < 64) {
             const int qi = qt * 64 + tid;
             const bool in = qi < S;
-            lds_lse[tid] = in ? lse_b[qi] * LOG2E : INFINITY;  // +inf => p = 0 for padded query rows
+            lds_lse[tid] = in ? lse_b[qi] * LOG2E : INFINITY;  // +inf => p = 0 for rows beyond S
             lds_dl[tid] = in ? dl_b[qi] : 0.f;
-            const bool qvl = in && (vrow ? vrow[min(qi, S - 1)] != 0 : true);
-            const uint64_t m = __ballot(qvl);
-            if (tid == 0) lds_mask[0] = m;
+            if (MASKED) {
+                const bool qvl = in && (vrow[min(qi, S - 1)] != 0);
+                lds_sc[tid] = qvl ? sc_const : 0.f;
+                lds_mq[tid] = qvl ? MASKED_T : 0.f;
+            }
         }
         __syncthreads();
         if (qt + 1 < nqt) {
@@ -425,7 +471,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnArgs p) {
             tile_load_regs<64>(dobase, p.lddo, (qt + 1) * 64, S - 1, oreg, tid);
         }
         if (!wave_active) continue;
-        const uint64_t qmask = lds_mask[0] >> (4 * hi);
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             f32x16 st = zero16(), dp = zero16();
@@ -440,18 +485,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnArgs p) {
             bf16x8 pf[2], dsf[2];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lds_lse + qb * 32 + 8 * g + 4 * hi);
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(lds_dl + qb * 32 + 8 * g + 4 * hi);
+                const int ro = qb * 32 + 8 * g + 4 * hi;
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lds_lse + ro);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(lds_dl + ro);
+                f32x4 s4 = {sc_const, sc_const, sc_const, sc_const};
+                f32x4 b4 = {-l4[0], -l4[1], -l4[2], -l4[3]};
+                if (MASKED) {
+                    s4 = *reinterpret_cast<const f32x4*>(lds_sc + ro);
+                    const f32x4 m4 = *reinterpret_cast<const f32x4*>(lds_mq + ro);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b4[e] = fmaf(m4[e], kmul, b4[e]);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g + e;
-                    const int bit = qb * 32 + acc_row(r);
-                    const bool qvb = (qmask >> bit) & 1;
-                    const bool live = kv && qvb;
-                    const float t = qvb ? (kv ? st[r] * sc : MASKED_T) : 0.f;
-                    float pv = exp2f(t - l4[e]);
-                    pv = key_in ? pv : 0.f;
-                    const float ds = live ? pv * (dp[r] - d4[e]) * p.scale : 0.f;
+                    const float pv = fast_exp2(fmaf(st[r], s4[e], b4[e]));
+                    const float ds = pv * (dp[r] - d4[e]) * (s4[e] * LN2);
                     pf[r >> 3][r & 7] = (bf16)pv;
                     dsf[r >> 3][r & 7] = (bf16)ds;
                 }
@@ -566,7 +615,10 @@ extern "C" int merlot_attention_fwd(const void* qkv, int64_t ld, void* out, int6
     AttnArgs a{};
     a.qkv = (const bf16*)qkv; a.ld = ld; a.out = (bf16*)out; a.ldo = ldo; a.lse = lse; a.valid = valid;
     a.B = B; a.S = S; a.heads = heads; a.scale = scale;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(cdiv(S, 128), heads, B), dim3(256), 0, (hipStream_t)stream, a);
+    if (valid)
+        hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, (hipStream_t)stream, a);
     return merlot_launch_status("merlot_attention_fwd");
 }
 
@@ -584,8 +636,13 @@ extern "C" int merlot_attention_bwd(const void* qkv, int64_t ld, const void* out
     a.B = B; a.S = S; a.heads = heads; a.scale = scale;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv((int64_t)B * S, 4)), dim3(256), 0, s, a, delta);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);
+    if (valid) {
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);
+    }
     return merlot_launch_status("merlot_attention_bwd");
 }
 

@@ -578,6 +578,7 @@ __global__ __launch_bounds__(C::NT) void gemm_nt_ring_kernel(const GemmNTArgs p)
         b_src[i] = p.B + (int64_t)min(n0 + row, p.N - 1) * p.ldb + chunk * 8;
     }
     auto stage = [&](int kt) {
+        if (p.dbg & 4) return;                       // experiments: no global->LDS traffic at all
         char* la = dsm + (kt % S) * C::STAGE_BYTES + wave * C::A_PIECES * 1024;
         char* lb = dsm + (kt % S) * C::STAGE_BYTES + C::A_BYTES + wave * C::B_PIECES * 1024;
         const int k0 = kt * BK;
@@ -608,19 +609,27 @@ __global__ __launch_bounds__(C::NT) void gemm_nt_ring_kernel(const GemmNTArgs p)
     auto compute = [&](int kt) {
         const char* la = dsm + (kt % S) * C::STAGE_BYTES;
         const char* lb = la + C::A_BYTES;
+        // all fragment reads of the step first, into DISTINCT registers: otherwise the compiler re-uses one register
+        // set per k-substep and every MFMA group waits (lgkmcnt(0)) for reads issued after the previous group.
+        constexpr int KK = BK / 16;
+        bf16x8 af[KK][C::FM], bfr[KK][C::FN];
 #pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-            bf16x8 af[C::FM], bfr[C::FN];
+        for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
-            for (int f = 0; f < C::FM; ++f) af[f] = *reinterpret_cast<const bf16x8*>(la + ring::kc_off<BK>(a_row[f], 2 * kk + hi));
+            for (int f = 0; f < C::FM; ++f)
+                af[kk][f] = *reinterpret_cast<const bf16x8*>(la + ring::kc_off<BK>(a_row[f], 2 * kk + hi));
 #pragma unroll
-            for (int f = 0; f < C::FN; ++f) bfr[f] = *reinterpret_cast<const bf16x8*>(lb + ring::kc_off<BK>(b_row[f], 2 * kk + hi));
+            for (int f = 0; f < C::FN; ++f)
+                bfr[kk][f] = *reinterpret_cast<const bf16x8*>(lb + ring::kc_off<BK>(b_row[f], 2 * kk + hi));
+        }
+        __builtin_amdgcn_sched_barrier(0);           // keep the reads above the MFMAs (the scheduler sinks them back)
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
             for (int fi = 0; fi < C::FM; ++fi)
 #pragma unroll
                 for (int fj = 0; fj < C::FN; ++fj)
-                    acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[fj], af[fi], acc[fi][fj], 0, 0, 0);
-        }
+                    acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[kk][fj], af[kk][fi], acc[fi][fj], 0, 0, 0);
     };
 
     const int nk = (p.dbg & 2) ? 0 : p.K / BK;
@@ -732,19 +741,23 @@ __global__ __launch_bounds__(C::NT) void gemm_tn_ring_kernel(const GemmTNArgs p,
 
     auto compute = [&](int t) {
         const char* base = dsm + (t % S) * C::STAGE_BYTES;
+        constexpr int KK = BK / 16;
+        bf16x8 af[KK][C::FM], bfr[KK][C::FN];
 #pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-            bf16x8 af[C::FM], bfr[C::FN];
+        for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
-            for (int f = 0; f < C::FM; ++f) af[f] = tr_pair(base + a_off + f * PANEL_BYTES + kk * 16 * 64);
+            for (int f = 0; f < C::FM; ++f) af[kk][f] = tr_pair(base + a_off + f * PANEL_BYTES + kk * 16 * 64);
 #pragma unroll
-            for (int f = 0; f < C::FN; ++f) bfr[f] = tr_pair(base + b_off + f * PANEL_BYTES + kk * 16 * 64);
+            for (int f = 0; f < C::FN; ++f) bfr[kk][f] = tr_pair(base + b_off + f * PANEL_BYTES + kk * 16 * 64);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
             for (int fi = 0; fi < C::FM; ++fi)
 #pragma unroll
                 for (int fj = 0; fj < C::FN; ++fj)
-                    acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[fj], af[fi], acc[fi][fj], 0, 0, 0);
-        }
+                    acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[kk][fj], af[kk][fi], acc[fi][fj], 0, 0, 0);
     };
 
 #pragma unroll
