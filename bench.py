@@ -192,15 +192,15 @@ def main():
             summ = timer.summary()
             f, t, n = summ.get('gemm_nt', (0.0, 1.0, 0))
             res['roofline'] = {'bound': 'mfma',
-                               'kernel': 'gemm_nt_ring_kernel<*> (merlot_gemm_bf16_nt: bf16 MFMA 32x32x16, all tile configs '
-                                         'and epilogues; the dominant kernel family of the step)',
+                               'kernel': 'merlot_gemm_bf16_nt = gemm_nt_persist_kernel<EPI,OUT> + gemm_nt_ring_kernel<Cfg,EPI,OUT> '
+                                         '(bf16 MFMA 32x32x16, all epilogues; the dominant kernel family of the step)',
                                'achieved': f / t / 1e12, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                                'frac': f / t / 1e12 / PEAK_BF16_TFLOPS, 'traffic': measured_traffic(), 'launches': n,
                                'avg_launch_us': 1e6 * t / max(n, 1), 'gflop_per_launch': f / max(n, 1) / 1e9,
                                'share_of_step_time': t / elapsed}
             if 'gemm_tn' in summ:
                 f2, t2, n2 = summ['gemm_tn']
-                res['roofline_wgrad'] = {'kernel': 'gemm_tn_kernel', 'achieved': f2 / t2 / 1e12, 'unit': 'TFLOP/s',
+                res['roofline_wgrad'] = {'kernel': 'merlot_gemm_bf16_tn = gemm_tn_ring_kernel + tn_reduce_kernel', 'achieved': f2 / t2 / 1e12, 'unit': 'TFLOP/s',
                                          'frac': f2 / t2 / 1e12 / PEAK_BF16_TFLOPS, 'launches': n2,
                                          'share_of_step_time': t2 / elapsed}
         if world == 1 and not args.no_cpu_baseline:

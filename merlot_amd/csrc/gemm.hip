@@ -657,6 +657,181 @@ __global__ __launch_bounds__(C::NT) void gemm_nt_ring_kernel(const GemmNTArgs p)
     staged_epilogue<C, EPI, OUT_F32>(p, acc, dsm + wave * C::EPI_BYTES, m0 + wm * C::FM * 32, n0 + wn * C::FN * 32, lane);
 }
 
+// ------------------------------------------------------------------------------------------------
+// NT kernel, PERSISTENT variant for large problems: one workgroup per CU walks its tiles and the LDS-DMA ring never
+// drains between tiles -- while a tile's epilogue runs, the first STAGES-1 K-steps of the next tile are already in
+// flight, so the ~20 us prologue + epilogue of a short-K (768) tile overlaps with memory traffic instead of adding
+// to it.  Epilogue staging has its own LDS region (XOR-swizzled 32x64 fp32 slab per wave), ring + staging = 160 KiB.
+// Counted vmcnt stays valid across the epilogue's own loads/stores: loads complete in order, so "<= (S-2)*LOADS
+// outstanding" still implies stage t has landed; stores only make the wait more conservative.
+// ------------------------------------------------------------------------------------------------
+template <int EPI, bool OUT_F32>
+__device__ __forceinline__ void slab_epilogue(const GemmNTArgs& p, const f32x16& acc0, const f32x16& acc1, char* slab,
+                                              int m_base, int n_base, int lane) {
+    // slab: [32 rows][64 cols] fp32, 16-B chunk index XOR (row & 15); acc0 = columns 0..31, acc1 = columns 32..63
+    const int hi = lane >> 5;
+    const int row = lane & 31;
+#pragma unroll
+    for (int fj = 0; fj < 2; ++fj)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 t;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] = (fj ? acc1[4 * q + e] : acc0[4 * q + e]) * p.alpha;
+            const int chunk = fj * 8 + 2 * q + hi;
+            *reinterpret_cast<f32x4*>(slab + row * 256 + ((chunk ^ (row & 15)) << 4)) = t;
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const bool aligned = ((p.ldc & 7) == 0) && ((p.ld_aux_in & 7) == 0) && ((p.ld_aux_out & 7) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0);
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int r = ps * 8 + (lane >> 3);
+        const int c0 = (lane & 7) * 8;
+        const int ch = 2 * (lane & 7);
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(slab + r * 256 + ((ch ^ (r & 15)) << 4));
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(slab + r * 256 + (((ch + 1) ^ (r & 15)) << 4));
+        const int m = m_base + r, n = n_base + c0;
+        if (m >= p.M || n >= p.N) continue;
+        if (aligned && n + 7 < p.N) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = x0[e];
+                v[4 + e] = x1[e];
+            }
+            epilogue_row8<EPI, OUT_F32>(p, m, n, v);
+        } else {
+            float q0[4] = {x0[0], x0[1], x0[2], x0[3]}, q1[4] = {x1[0], x1[1], x1[2], x1[3]};
+            const bool vec_ok = ((p.ldc & 3) == 0) && ((p.ld_aux_in & 3) == 0) && ((p.ld_aux_out & 3) == 0);
+            nt_epilogue_quad<EPI, OUT_F32>(p, m, n, q0, vec_ok);
+            if (n + 4 < p.N) nt_epilogue_quad<EPI, OUT_F32>(p, m, n + 4, q1, vec_ok);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+using RingP = ring::Cfg<4, 2, 2, 4, 32, 3>;          // 256x256, BK 32, 3 stages (96 KB) + 64 KB epilogue staging
+constexpr int PERSIST_LDS = RingP::RING_BYTES + 8 * 8192;
+
+template <int EPI, bool OUT_F32>
+__global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const GemmNTArgs p) {
+    using C = RingP;
+    extern __shared__ __attribute__((aligned(1024))) char dsm[];
+    constexpr int BK = C::BK, S = C::STAGES;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntiles = p.ntm * p.ntn;
+    const int nk = p.K / BK;
+    // tile order: round j hands 32 consecutive tiles to each XCD (block b sits on XCD b % 8)
+    const int slot = xcd_remap(blockIdx.x, gridDim.x);
+    const int my_tiles = slot < ntiles ? (ntiles - slot + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    const int total_steps = my_tiles * nk;
+
+    constexpr int CH = BK / 8;
+    const int prow = lane / CH, pch = lane % CH;
+    int a_rowoff[C::A_PIECES], b_rowoff[C::B_PIECES], a_chunk[C::A_PIECES], b_chunk[C::B_PIECES];
+#pragma unroll
+    for (int i = 0; i < C::A_PIECES; ++i) {
+        a_rowoff[i] = (wave * C::A_PIECES + i) * C::RP + prow;
+        a_chunk[i] = ((pch ^ (a_rowoff[i] >> 2)) & 3) * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < C::B_PIECES; ++i) {
+        b_rowoff[i] = (wave * C::B_PIECES + i) * C::RP + prow;
+        b_chunk[i] = ((pch ^ (b_rowoff[i] >> 2)) & 3) * 8;
+    }
+    // load stream state
+    const bf16* a_src[C::A_PIECES];
+    const bf16* b_src[C::B_PIECES];
+    int ld_tile = slot, ld_kt = 0, ld_step = 0;
+    auto set_tile = [&](int tile) {
+        const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
+#pragma unroll
+        for (int i = 0; i < C::A_PIECES; ++i)
+            a_src[i] = p.A + (int64_t)min(tm * C::BM + a_rowoff[i], p.M - 1) * p.lda + a_chunk[i];
+#pragma unroll
+        for (int i = 0; i < C::B_PIECES; ++i)
+            b_src[i] = p.B + (int64_t)min(tn * C::BN + b_rowoff[i], p.N - 1) * p.ldb + b_chunk[i];
+    };
+    auto stage_next = [&]() {
+        if (ld_step >= total_steps) return;
+        char* la = dsm + (ld_step % S) * C::STAGE_BYTES + wave * C::A_PIECES * 1024;
+        char* lb = dsm + (ld_step % S) * C::STAGE_BYTES + C::A_BYTES + wave * C::B_PIECES * 1024;
+        const int k0 = ld_kt * BK;
+#pragma unroll
+        for (int i = 0; i < C::A_PIECES; ++i)
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(a_src[i] + k0), LDS_PTR(la + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < C::B_PIECES; ++i)
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(b_src[i] + k0), LDS_PTR(lb + i * 1024), 16, 0, 0);
+        ++ld_step;
+        if (++ld_kt == nk) {
+            ld_kt = 0;
+            ld_tile += gridDim.x;
+            if (ld_tile < ntiles) set_tile(ld_tile);
+        }
+    };
+
+    const int wm = wave / C::WN, wn = wave % C::WN;
+    const int hi = lane >> 5;
+    int a_row[C::FM], b_row[C::FN];
+#pragma unroll
+    for (int f = 0; f < C::FM; ++f) a_row[f] = (wm * C::FM + f) * 32 + (lane & 31);
+#pragma unroll
+    for (int f = 0; f < C::FN; ++f) b_row[f] = (wn * C::FN + f) * 32 + (lane & 31);
+    char* slab = dsm + C::RING_BYTES + wave * 8192;
+
+    if (my_tiles > 0) set_tile(slot);
+#pragma unroll
+    for (int t = 0; t < S - 1; ++t) stage_next();
+
+    int g = 0;
+    for (int tile = slot; tile < ntiles; tile += gridDim.x) {
+        f32x16 acc[C::FM][C::FN];
+#pragma unroll
+        for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+            for (int j = 0; j < C::FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int kt = 0; kt < nk; ++kt, ++g) {
+            if (g + S - 1 <= total_steps)
+                ring::wait_vmcnt<(S - 2) * C::LOADS>();
+            else
+                ring::wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            stage_next();
+            const char* la = dsm + (g % S) * C::STAGE_BYTES;
+            const char* lb = la + C::A_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                bf16x8 af[C::FM], bfr[C::FN];
+#pragma unroll
+                for (int f = 0; f < C::FM; ++f) af[f] = *reinterpret_cast<const bf16x8*>(la + ring::kc_off<BK>(a_row[f], 2 * kk + hi));
+#pragma unroll
+                for (int f = 0; f < C::FN; ++f) bfr[f] = *reinterpret_cast<const bf16x8*>(lb + ring::kc_off<BK>(b_row[f], 2 * kk + hi));
+#pragma unroll
+                for (int fi = 0; fi < C::FM; ++fi)
+#pragma unroll
+                    for (int fj = 0; fj < C::FN; ++fj)
+                        acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[fj], af[fi], acc[fi][fj], 0, 0, 0);
+            }
+        }
+        if ((p.dbg & 1) && acc[0][0][0] != 12345.678f) continue;
+        const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
+        const int m_base = tm * C::BM + wm * C::FM * 32, n_base = tn * C::BN + wn * C::FN * 32;
+#pragma unroll
+        for (int fi = 0; fi < C::FM; ++fi)
+#pragma unroll
+            for (int fp = 0; fp < C::FN / 2; ++fp)
+                slab_epilogue<EPI, OUT_F32>(p, acc[fi][2 * fp], acc[fi][2 * fp + 1], slab, m_base + fi * 32, n_base + fp * 64, lane);
+    }
+}
+
 // LDS transpose-read of one 8-deep MFMA operand fragment (rows r..r+3 and r+4..r+7 of a 64-B-stride panel)
 __device__ __forceinline__ bf16x8 tr_pair(const char* p) {
     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p));
@@ -713,6 +888,7 @@ __global__ __launch_bounds__(C::NT) void gemm_tn_ring_kernel(const GemmTNArgs p,
         b_src[i] = p.B + (int64_t)(ks * BK + rb * 16 + (lane >> 2)) * p.ldb + col;
     }
     auto stage = [&](int t) {
+        if (p.dbg & 4) return;
         char* la = dsm + (t % S) * C::STAGE_BYTES + wave * C::A_PIECES * 1024;
         char* lb = dsm + (t % S) * C::STAGE_BYTES + C::A_BYTES + wave * C::B_PIECES * 1024;
         const int64_t r0 = (int64_t)t * BK;
@@ -862,6 +1038,38 @@ int launch_ring(GemmNTArgs& a, int epilogue, int out_f32, hipStream_t s) {
     return MERLOT_ESHAPE;
 }
 
+template <int EPI, bool OUT_F32>
+int launch_persist_one(GemmNTArgs& a, hipStream_t s) {
+    auto kern = gemm_nt_persist_kernel<EPI, OUT_F32>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           PERSIST_LDS);
+        MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipFuncSetAttribute(LDS=%d) failed: %s", PERSIST_LDS, hipGetErrorString(e));
+        attr_set = true;
+    }
+    a.ntm = cdiv(a.M, RingP::BM);
+    a.ntn = cdiv(a.N, RingP::BN);
+    int grid = a.ntm * a.ntn;
+    if (grid > 256) grid = 256;                      // one workgroup per CU (gridDim.x % 8 == 0 keeps the XCD bands even)
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), PERSIST_LDS, s, a);
+    return merlot_launch_status("merlot_gemm_bf16_nt(persistent)");
+}
+
+int launch_persist(GemmNTArgs& a, int epilogue, int out_f32, hipStream_t s) {
+#define PERSIST_CASE(E) \
+    case E: return out_f32 ? launch_persist_one<E, true>(a, s) : launch_persist_one<E, false>(a, s);
+    switch (epilogue) {
+        PERSIST_CASE(MERLOT_EPI_NONE)
+        PERSIST_CASE(MERLOT_EPI_GELU)
+        PERSIST_CASE(MERLOT_EPI_RESIDUAL)
+        PERSIST_CASE(MERLOT_EPI_DGELU)
+    }
+#undef PERSIST_CASE
+    merlot_set_error("merlot_gemm_bf16_nt: unknown epilogue %d", epilogue);
+    return MERLOT_ESHAPE;
+}
+
 using RingA = ring::Cfg<2, 2, 2, 2, 64, 3>;   // 128x128, BK 64, 3 stages,  96 KB, 4 waves
 using RingB = ring::Cfg<4, 2, 2, 2, 64, 3>;   // 256x128, BK 64, 3 stages, 144 KB, 8 waves
 using RingC = ring::Cfg<4, 2, 2, 4, 32, 4>;   // 256x256, BK 32, 4 stages, 128 KB, 8 waves
@@ -894,16 +1102,12 @@ int gemm_nt_dispatch(GemmNTArgs& a, int epilogue, int out_f32, bool patch, hipSt
     int cfg = nt_config_override();
     if (const char* e = getenv("MERLOT_NT_CFG_DYN")) cfg = atoi(e);     // re-read every call (experiments only)
     if (cfg < 0) {
-        // Pick the tile shape by a wave-quantisation model calibrated on MI355X (profiles/r01_gemm_tile_sweep.txt):
-        // cost = ceil(tiles / resident slots) * tile area / relative per-slot throughput.
-        struct Cand { int id, bm, bn, slots; float eff; };
-        const Cand cands[2] = {{3, 256, 256, 256, 1.0f}, {11, 128, 256, 512, 0.54f}};
-        float best = 3.4e38f;
-        for (const Cand& c : cands) {
-            const int64_t tiles = (int64_t)cdiv(a.M, c.bm) * cdiv(a.N, c.bn);
-            const float cost = (float)((tiles + c.slots - 1) / c.slots) * (float)(c.bm * c.bn) / c.eff;
-            if (cost < best) { best = cost; cfg = c.id; }
-        }
+        // Tile choice, from the sweeps in profiles/r01_gemm_tile_sweep.txt: the persistent 256x256 kernel (id 20) wins
+        // whenever its rounds of 256 workgroups are well filled (>= 85 % of the slots of its last round included);
+        // otherwise 128x256 tiles with two co-resident workgroups per CU (id 11) absorb the ragged tail better.
+        const int64_t tiles = (int64_t)cdiv(a.M, 256) * cdiv(a.N, 256);
+        const int64_t rounds = (tiles + 255) / 256;
+        cfg = (tiles * 100 >= rounds * 256 * 85) ? 20 : 11;
     }
     switch (cfg) {
         case 1: return launch_ring<RingA>(a, epilogue, out_f32, s);
@@ -917,6 +1121,7 @@ int gemm_nt_dispatch(GemmNTArgs& a, int epilogue, int out_f32, bool patch, hipSt
         case 9: return launch_ring<RingI>(a, epilogue, out_f32, s);
         case 10: return launch_ring<RingJ>(a, epilogue, out_f32, s);
         case 11: return launch_ring<RingK>(a, epilogue, out_f32, s);
+        case 20: return launch_persist(a, epilogue, out_f32, s);
         default: break;
     }
     a.ntm = cdiv(a.M, BM);
