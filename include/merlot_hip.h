@@ -191,10 +191,13 @@ int merlot_shuffled_idx(const int32_t* num_shuffle, const float* u_select, const
  * param/grad f32 [n]; m, v bf16 bit patterns (state_bf16=1) or f32.  lr already includes the schedule
  * scale and sqrt(bc2)/bc1.  beta1/beta2 are doubles so that (1 - beta) is rounded to f32 from the double value,
  * as the reference's python-side `1.0 - beta_1` is.  grad_scale multiplies the gradient first (1/world for mean).
+ * wd_flags: NULL (decay everywhere) or one byte per 64 consecutive elements, 0 = no weight decay for that chunk --
+ * the regex `param_overrides` of utils/optimization.py:125-151 flattened onto the 64-element-aligned arena, so the
+ * whole model updates in ONE launch.
  * ---------------------------------------------------------------------------------------------- */
 int merlot_adamw_step(float* param, const float* grad, void* m, void* v, int64_t n, float lr, double beta1,
-                      double beta2, float eps, float weight_decay, float grad_scale, int state_bf16,
-                      merlot_stream_t stream);
+                      double beta2, float eps, float weight_decay, float grad_scale, const uint8_t* wd_flags,
+                      int state_bf16, merlot_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Hardware-layout probes (diagnostics; used by tests to pin the MFMA / LDS-transpose lane maps the

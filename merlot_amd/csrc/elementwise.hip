@@ -332,10 +332,11 @@ template <bool STATE_BF16>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ param, const float* __restrict__ grad,
                                                     void* __restrict__ m_, void* __restrict__ v_, int64_t n, float lr,
                                                     float beta1, float beta2, float omb1, float omb2, float eps,
-                                                    float wd, float gscale) {
+                                                    float wd_rate, float gscale, const uint8_t* __restrict__ wd_flags) {
 #pragma clang fp contract(off)   // one IEEE op per reference op: the bf16 state encoding is sensitive to the last ulp
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float g = grad[i] * gscale;
+        const float wd = (wd_flags == nullptr || wd_flags[i >> 6]) ? wd_rate : 0.f;
         float m, v;
         if (STATE_BF16) {
             m = bf16_bits_to_f32(((const uint16_t*)m_)[i]);
@@ -493,17 +494,17 @@ extern "C" int merlot_gelu_bwd(const float* dy, const float* x, float* dx, int64
 }
 
 extern "C" int merlot_adamw_step(float* param, const float* grad, void* m, void* v, int64_t n, float lr, double beta1d,
-                                 double beta2d, float eps, float weight_decay, float grad_scale, int state_bf16,
-                                 merlot_stream_t stream) {
+                                 double beta2d, float eps, float weight_decay, float grad_scale, const uint8_t* wd_flags,
+                                 int state_bf16, merlot_stream_t stream) {
     const float beta1 = (float)beta1d, beta2 = (float)beta2d;
     const float omb1 = (float)(1.0 - beta1d), omb2 = (float)(1.0 - beta2d);
     MERLOT_CHECK(param && grad && m && v && n > 0, MERLOT_ESHAPE, "merlot_adamw_step: bad args");
     const int g = grid_for(n, 256, 8192);
     if (state_bf16)
         hipLaunchKernelGGL((adamw_kernel<true>), dim3(g), dim3(256), 0, STREAM, param, grad, m, v, n, lr, beta1, beta2, omb1,
-                           omb2, eps, weight_decay, grad_scale);
+                           omb2, eps, weight_decay, grad_scale, wd_flags);
     else
         hipLaunchKernelGGL((adamw_kernel<false>), dim3(g), dim3(256), 0, STREAM, param, grad, m, v, n, lr, beta1, beta2, omb1,
-                           omb2, eps, weight_decay, grad_scale);
+                           omb2, eps, weight_decay, grad_scale, wd_flags);
     return merlot_launch_status("merlot_adamw_step");
 }

@@ -206,15 +206,16 @@ def layer_norm(x, ln, out_bf16=False):
 
 class GatherAddFn(torch.autograd.Function):
     """out[r] = sum_k table_k[idx_k[r]]   (f32).  `act` (optional) is an activation tensor source (bf16 or f32,
-    differentiable through autograd); tables are (param, grad) pairs from the store, gradients scatter-added."""
+    differentiable through autograd); tables are (param, grad, idx[, period]) tuples from the store, gradients
+    scatter-added (`period`: idx repeats with that period -> the backward reduces over the repeats first)."""
 
     @staticmethod
-    def forward(ctx, act, act_idx, tables, rows, H, anchor):
+    def forward(ctx, act, act_idx, tables, rows, H, anchor, act_inv=None):
         srcs = []
         if act is not None:
             srcs.append((act.contiguous().view(-1, H), act_idx))
-        for (tab, _g, idx) in tables:
-            srcs.append((tab.view(-1, H), idx))
+        for ent in tables:
+            srcs.append((ent[0].view(-1, H), ent[2]))
         while len(srcs) < 4:
             srcs.append((None, None))
         # slot `a` is the only one that may be bf16: put the activation there
@@ -222,19 +223,30 @@ class GatherAddFn(torch.autograd.Function):
         out = ops.gather_add4(rows, H, a=a, ia=ia, b=b, ib=ib, c=c, ic=ic, d=d, id_=id_)
         ctx.act_shape = None if act is None else act.shape
         ctx.act_dtype = None if act is None else act.dtype
-        ctx.act_idx, ctx.tables, ctx.H = act_idx, tables, H
+        ctx.act_idx, ctx.tables, ctx.H, ctx.act_inv = act_idx, tables, H, act_inv
         return out
 
     @staticmethod
     def backward(ctx, dout):
         dout = dout.contiguous()
         H = ctx.H
-        for (tab, gtab, idx) in ctx.tables:
-            ops.scatter_add_rows(dout, idx, gtab.view(-1, H))
+        for ent in ctx.tables:
+            tab, gtab, idx = ent[0], ent[1], ent[2]
+            period = ent[3] if len(ent) > 3 else None
+            if period is not None and dout.shape[0] > period:
+                # the index pattern repeats every `period` rows (position tables): reduce over the repeats first, so
+                # the scatter issues `period` rows of atomics instead of one per token (fp32 atomics are slow here)
+                red = dout.view(-1, period, H).sum(0)
+                ops.scatter_add_rows(red, idx[:period].contiguous(), gtab.view(-1, H))
+            else:
+                ops.scatter_add_rows(dout, idx, gtab.view(-1, H))
         dact = None
         if ctx.act_shape is not None and ctx.needs_input_grad[0]:
             if ctx.act_idx is None:
                 dact = dout.view(ctx.act_shape).to(ctx.act_dtype)
+            elif ctx.act_inv is not None:
+                # injective placement (every source row lands in exactly one output row): the gradient is a GATHER
+                dact = dout.index_select(0, ctx.act_inv).view(ctx.act_shape).to(ctx.act_dtype)
             else:
                 n_src = 1
                 for s in ctx.act_shape[:-1]:
@@ -242,12 +254,13 @@ class GatherAddFn(torch.autograd.Function):
                 buf = torch.zeros((n_src, H), device=dout.device, dtype=F32)
                 ops.scatter_add_rows(dout, ctx.act_idx, buf)
                 dact = buf.view(ctx.act_shape).to(ctx.act_dtype)
-        return dact, None, None, None, None, None
+        return dact, None, None, None, None, None, None
 
 
-def gather_add(act, act_idx, tables, rows, H, anchor):
-    """`anchor`: the store's dummy requires-grad tensor, so a gather of parameters only is still a graph root."""
-    return GatherAddFn.apply(act, act_idx, tables, rows, H, anchor)
+def gather_add(act, act_idx, tables, rows, H, anchor, act_inv=None):
+    """`anchor`: the store's dummy requires-grad tensor, so a gather of parameters only is still a graph root.
+    `act_inv` (optional, int64): for an injective act_idx, the output row each source row was placed in."""
+    return GatherAddFn.apply(act, act_idx, tables, rows, H, anchor, act_inv)
 
 
 class ClsAvgPoolFn(torch.autograd.Function):

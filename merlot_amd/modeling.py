@@ -166,10 +166,11 @@ class MerlotModel(object):
         vs = 'vision_backbone/vision_transformer'
         conv = L.PatchEmbedFn.apply(image, st.lin(f'{vs}/conv2d', need_T=False), Pz, self._anchor)
         idx_conv, idx_cls, idx_pos = self._vit_prologue_indices(N, h1, w1, ncls)
+        conv_inv = (torch.arange(N, device=dev)[:, None] * Sv + ncls + torch.arange(h1 * w1, device=dev)[None]).reshape(-1)
         x = L.gather_add(conv, idx_conv,
-                         [(st.p(f'{vs}/pos_embs/cls_emb'), st.g(f'{vs}/pos_embs/cls_emb'), idx_cls),
-                          (st.p(f'{vs}/pos_embs/pos_embs'), st.g(f'{vs}/pos_embs/pos_embs'), idx_pos)],
-                         N * Sv, H, self._anchor)                                  # vision_transformer.py:229-233
+                         [(st.p(f'{vs}/pos_embs/cls_emb'), st.g(f'{vs}/pos_embs/cls_emb'), idx_cls, Sv),
+                          (st.p(f'{vs}/pos_embs/pos_embs'), st.g(f'{vs}/pos_embs/pos_embs'), idx_pos, Sv)],
+                         N * Sv, H, self._anchor, act_inv=conv_inv)                # vision_transformer.py:229-233
         x = L.layer_norm(x, st.ln(f'{vs}/LayerNorm_ctx_patches_pre_ln'), out_bf16=True)
         vit_p = cfg.get('vit_hidden_dropout_prob', cfg['hidden_dropout_prob']) if is_training else 0.0
         hs = L.transformer_stack(x, self._vit, N, Sv, None,
@@ -185,8 +186,8 @@ class MerlotModel(object):
         idx_img, idx_fcls, idx_fpos = self._final_pe_indices(N, h2, w2, shuffled_idx_img)
         image_feats = L.gather_add(feats, None,
                                    [(st.p('vision_backbone/img_idx_pe'), st.g('vision_backbone/img_idx_pe'), idx_img),
-                                    (st.p('vision_backbone/final_pe/cls_emb'), st.g('vision_backbone/final_pe/cls_emb'), idx_fcls),
-                                    (st.p('vision_backbone/final_pe/pos_embs'), st.g('vision_backbone/final_pe/pos_embs'), idx_fpos)],
+                                    (st.p('vision_backbone/final_pe/cls_emb'), st.g('vision_backbone/final_pe/cls_emb'), idx_fcls, vl),
+                                    (st.p('vision_backbone/final_pe/pos_embs'), st.g('vision_backbone/final_pe/pos_embs'), idx_fpos, vl)],
                                    N * vl, H, self._anchor)                        # :125 + :299-337
         image_feats = L.layer_norm(image_feats, st.ln('vision_backbone/LayerNorm_final_ln'), out_bf16=True)   # :126-128
         self.encoder_pieces = [{'name': 'viz', 'x': image_feats.view(self.B, self.P, H),
@@ -315,7 +316,7 @@ class MerlotModel(object):
         idx_p = torch.arange(Lq, device=self.device).repeat(R).int().contiguous()
         emb = L.gather_add(None, None,
                            [(st.p('word_embeddings/word_embeddings'), st.g('word_embeddings/word_embeddings'), idx_w),
-                            (st.p(f'{norm_scope_name}/position_embeddings'), st.g(f'{norm_scope_name}/position_embeddings'), idx_p)],
+                            (st.p(f'{norm_scope_name}/position_embeddings'), st.g(f'{norm_scope_name}/position_embeddings'), idx_p, Lq)],
                            R * Lq, H, self._anchor)
         out = L.layer_norm(emb, st.ln(f'{norm_scope_name}/LayerNorm_embed_norm'), out_bf16=True)
         p = self.dropout_prob if self.is_training else 0.0

@@ -324,11 +324,11 @@ def shuffled_idx(num_shuffle, u_select, u_perm, B, n, offset=16):
     return out
 
 
-def adamw_step(param, grad, m, v, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0):
-    _chk(param, F32, 'param'); _chk(grad, F32, 'grad')
+def adamw_step(param, grad, m, v, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0, wd_flags=None):
+    _chk(param, F32, 'param'); _chk(grad, F32, 'grad'); _chk(wd_flags, torch.uint8, 'wd_flags')
     state_bf16 = 1 if m.dtype in (BF16, torch.int16, torch.uint16) else 0
     call('merlot_adamw_step', _p(param), _p(grad), _p(m), _p(v), param.numel(), float(lr), float(beta1), float(beta2),
-         float(eps), float(weight_decay), float(grad_scale), state_bf16, _stream())
+         float(eps), float(weight_decay), float(grad_scale), _p(wd_flags), state_bf16, _stream())
 
 
 def probe_mfma32(a, b):

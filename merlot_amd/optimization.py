@@ -56,6 +56,21 @@ class AdamOptimizer(object):
             else:
                 runs.append([off, end, key])
         self.runs = runs
+        # when only the weight decay differs between parameters (the merlot.yaml case) the whole arena updates in ONE
+        # launch driven by a per-64-element flag table; otherwise one launch per run.
+        lrs = {k[1] for _, _, k in runs}
+        self.single_launch = len(lrs) == 1 and next(iter(lrs)) != 0.0
+        if self.single_launch:
+            flags = torch.zeros(store.numel // 64, dtype=torch.uint8)
+            wds = {k[0] for _, _, k in runs if k[0] > 0}
+            if len(wds) > 1:
+                self.single_launch = False
+            else:
+                self._wd = next(iter(wds)) if wds else 0.0
+                for s_, e_, k in runs:
+                    if k[0] > 0:
+                        flags[s_ // 64:e_ // 64] = 1
+                self._wd_flags = flags.to(store.device)
 
     def current_lr(self):
         return self.lr * learning_rate_scale(self.step_count, self.nts, self.nws)
@@ -66,6 +81,12 @@ class AdamOptimizer(object):
         bc2 = 1.0 - math.pow(self.b2, t)
         mult = learning_rate_scale(self.step_count, self.nts, self.nws) * math.sqrt(bc2) / bc1
         st = self.store
+        if self.single_launch:
+            ops.adamw_step(st.master, st.grad, self.m, self.v, self.lr * mult, self.b1, self.b2, self.eps, self._wd,
+                           self.grad_scale, wd_flags=self._wd_flags)
+            self.step_count += 1
+            st.master_version += 1
+            return
         for s, e, (wd, lr_p) in self.runs:
             if lr_p == 0.0:                                          # frozen parameters (:149-157)
                 continue

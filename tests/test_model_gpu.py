@@ -144,6 +144,9 @@ def test_adamw_matches_reference_update_rule():
     n = 4096 + 37
     p0 = rng.randn(n).astype(np.float32)
     lr, b1, b2, eps, wd = 3e-4, 0.9, 0.98, 1e-6, 0.1
+    fl = (np.arange((n + 63) // 64) % 3 != 0).astype(np.uint8)          # every third 64-chunk has no weight decay
+    flags = torch.from_numpy(fl).cuda()
+    wd_vec = (np.repeat(fl, 64)[:n] * np.float32(wd)).astype(np.float32)
     for state_bf16 in (False, True):
         p = torch.from_numpy(p0.copy()).cuda()
         sd = torch.bfloat16 if state_bf16 else torch.float32
@@ -155,7 +158,7 @@ def test_adamw_matches_reference_update_rule():
 
         for it in range(3):
             gnp = (rng.randn(n) * 0.01).astype(np.float32)
-            ops.adamw_step(p, torch.from_numpy(gnp).cuda(), m, v, lr, b1, b2, eps, wd)
+            ops.adamw_step(p, torch.from_numpy(gnp).cuda(), m, v, lr, b1, b2, eps, wd, wd_flags=flags)
             g2 = gnp * gnp + np.float32(1e-30)
             if state_bf16:
                 v_dec = np.where(vr > 0, np.abs(vr), np.abs(vr) * np.float32(1.00390625)).astype(np.float32)
@@ -163,7 +166,7 @@ def test_adamw_matches_reference_update_rule():
                 v_dec = vr
             nm_ = (np.float32(b1) * mr + np.float32(1 - b1) * gnp).astype(np.float32)
             nv_ = (np.float32(b2) * v_dec + np.float32(1 - b2) * g2).astype(np.float32)
-            upd = nm_ / (np.sqrt(nv_) + np.float32(eps)) + np.float32(wd) * pr
+            upd = nm_ / (np.sqrt(nv_) + np.float32(eps)) + wd_vec * pr
             pr = (pr - np.float32(lr) * upd).astype(np.float32)
             if state_bf16:
                 mr = to_bf16(nm_)
