@@ -140,7 +140,8 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     ctx = None
-    if world > 1:
+    force_dist = os.environ.get('MERLOT_FORCE_DIST', '0') == '1' and 'RANK' in os.environ
+    if world > 1 or force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=device)
         ctx = DistContext()
@@ -169,7 +170,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     ops.TIMER = None
-    loss = float(out['loss'])
+    loss = float(out['loss'].detach())
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -206,7 +207,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline()
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

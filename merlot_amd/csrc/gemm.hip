@@ -1081,6 +1081,8 @@ using RingH = ring::Cfg<2, 2, 2, 2, 64, 2>;   // 128x128, BK 64, 2 stages, 64 KB
 using RingI = ring::Cfg<4, 2, 2, 2, 32, 3>;   // 256x128, BK 32, 3 stages, 72 KB (2 blocks/CU, 16 waves)
 using RingJ = ring::Cfg<4, 2, 2, 4, 32, 5>;   // 256x256, BK 32, 5 stages, 160 KB
 using RingK = ring::Cfg<2, 4, 2, 2, 32, 3>;   // 128x256, BK 32, 3 stages, 72 KB (2 blocks/CU)
+using RingL = ring::Cfg<2, 2, 4, 4, 32, 4>;   // 256x256 with FOUR waves of 128x128 (1 wave/SIMD, 256 acc regs)
+using RingM = ring::Cfg<2, 2, 4, 4, 64, 2>;   // same, BK 64, 2 stages
 
 int nt_config_override() {
     static int v = -2;
@@ -1121,6 +1123,8 @@ int gemm_nt_dispatch(GemmNTArgs& a, int epilogue, int out_f32, bool patch, hipSt
         case 9: return launch_ring<RingI>(a, epilogue, out_f32, s);
         case 10: return launch_ring<RingJ>(a, epilogue, out_f32, s);
         case 11: return launch_ring<RingK>(a, epilogue, out_f32, s);
+        case 12: return launch_ring<RingL>(a, epilogue, out_f32, s);
+        case 13: return launch_ring<RingM>(a, epilogue, out_f32, s);
         case 20: return launch_persist(a, epilogue, out_f32, s);
         default: break;
     }
@@ -1162,18 +1166,27 @@ int tn_launch(GemmTNArgs& a, int accumulate, bool patch_b, bool v2, hipStream_t 
 }
 
 using TnRingC = ring::Cfg<4, 2, 2, 4, 32, 4>;   // 256x256, BK 32, 4 stages, 8 waves, 1 workgroup / CU
+using TnRingK = ring::Cfg<2, 4, 2, 2, 32, 3>;   // 128x256, BK 32, 3 stages, 8 waves, 2 workgroups / CU
+
+int tn_config() {
+    if (const char* e = getenv("MERLOT_TN_CFG")) return atoi(e);      // experiments only
+    return 1;                                            // 128x256, 2 WG/CU: +5-7 % over 256x256 on the wgrad shapes
+}
 
 // split plan of the ring TN kernel (shared with the workspace-size query)
 struct TnPlan {
     int ntm, ntn, splits, chunk;
 };
 TnPlan tn_plan(int64_t M, int64_t N, int64_t R) {
+    const bool k = tn_config() == 1;
+    const int bm = k ? TnRingK::BM : TnRingC::BM, bn = k ? TnRingK::BN : TnRingC::BN;
+    const int slots = k ? 512 : 256;
     TnPlan pl;
-    pl.ntm = cdiv(M, TnRingC::BM);
-    pl.ntn = cdiv(N, TnRingC::BN);
+    pl.ntm = cdiv(M, bm);
+    pl.ntn = cdiv(N, bn);
     const int tiles = pl.ntm * pl.ntn;
     const int ksteps = (int)(R / TnRingC::BK);
-    int splits = 256 / tiles;                            // one round of 256 CUs
+    int splits = slots / tiles;                          // one round of resident workgroups
     if (splits < 1) splits = 1;
     if (splits > ksteps / 8) splits = ksteps / 8 > 0 ? ksteps / 8 : 1;
     if (const char* env = getenv("MERLOT_TN_SPLITS")) {   // tuning / experiments only
@@ -1185,17 +1198,8 @@ TnPlan tn_plan(int64_t M, int64_t N, int64_t R) {
     return pl;
 }
 
-int tn_ring_launch(GemmTNArgs& a, int accumulate, float* ws, int64_t ws_bytes, hipStream_t s) {
-    using C = TnRingC;
-    const TnPlan pl = tn_plan(a.M, a.N, a.R);
-    a.ntm = pl.ntm; a.ntn = pl.ntn; a.splits = pl.splits; a.rchunk = pl.chunk;
-    a.use_atomics = accumulate;                          // meaning here: accumulate into C when splits == 1
-    if (const char* e = getenv("MERLOT_DBG")) a.dbg = atoi(e);
-    if (pl.splits > 1) {
-        const int64_t need = (int64_t)pl.splits * a.M * a.N * 4;
-        MERLOT_CHECK(ws != nullptr && ws_bytes >= need, MERLOT_ESHAPE,
-                     "merlot_gemm_bf16_tn: workspace too small (%lld < %lld bytes)", (long long)ws_bytes, (long long)need);
-    }
+template <typename C>
+int tn_ring_launch_cfg(GemmTNArgs& a, const TnPlan& pl, float* ws, hipStream_t s) {
     auto kern = gemm_tn_ring_kernel<C>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1205,6 +1209,21 @@ int tn_ring_launch(GemmTNArgs& a, int accumulate, float* ws, int64_t ws_bytes, h
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(pl.ntm * pl.ntn * pl.splits), dim3(C::NT), C::LDS_BYTES, s, a, ws);
+    return MERLOT_OK;
+}
+
+int tn_ring_launch(GemmTNArgs& a, int accumulate, float* ws, int64_t ws_bytes, hipStream_t s) {
+    const TnPlan pl = tn_plan(a.M, a.N, a.R);
+    a.ntm = pl.ntm; a.ntn = pl.ntn; a.splits = pl.splits; a.rchunk = pl.chunk;
+    a.use_atomics = accumulate;                          // meaning here: accumulate into C when splits == 1
+    if (const char* e = getenv("MERLOT_DBG")) a.dbg = atoi(e);
+    if (pl.splits > 1) {
+        const int64_t need = (int64_t)pl.splits * a.M * a.N * 4;
+        MERLOT_CHECK(ws != nullptr && ws_bytes >= need, MERLOT_ESHAPE,
+                     "merlot_gemm_bf16_tn: workspace too small (%lld < %lld bytes)", (long long)ws_bytes, (long long)need);
+    }
+    int rc = tn_config() == 1 ? tn_ring_launch_cfg<TnRingK>(a, pl, ws, s) : tn_ring_launch_cfg<TnRingC>(a, pl, ws, s);
+    if (rc != MERLOT_OK) return rc;
     if (pl.splits > 1) {
         int64_t total = (int64_t)a.M * (a.N / 4);
         int grid = (int)((total + 255) / 256);

@@ -10,8 +10,13 @@ Replaces the reference's three cross-replica call sites:
     heads, stems) goes in `finish()`.  Reduction is a SUM (reference-faithful); `mean` is
     available through the optimizer's grad_scale at no extra pass.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+# MERLOT_FORCE_DIST=1 issues every collective even at world_size 1 (exercises the RCCL code path on a 1-GPU box)
+FORCE = os.environ.get('MERLOT_FORCE_DIST', '0') == '1'
 
 
 class _AllGatherCat(torch.autograd.Function):
@@ -48,7 +53,7 @@ class DistContext(object):
         self.world_size = dist.get_world_size(group)
 
     def all_gather_cat(self, x):
-        if self.world_size == 1:
+        if self.world_size == 1 and not FORCE:
             return x
         return _AllGatherCat.apply(x, self.group)
 
@@ -77,7 +82,7 @@ class GradReducer(object):
         return r
 
     def _on_ready(self, group):
-        if self.ctx.world_size == 1:
+        if self.ctx.world_size == 1 and not FORCE:
             return
         c = self._seen.get(group, 0) + 1
         self._seen[group] = c
@@ -93,7 +98,7 @@ class GradReducer(object):
 
     def finish(self):
         """all-reduce whatever the backward hooks have not covered, then wait for everything."""
-        if self.ctx.world_size > 1:
+        if self.ctx.world_size > 1 or FORCE:
             done = sorted(self._done)
             pos = 0
             for s, e in done + [(self.store.numel, self.store.numel)]:

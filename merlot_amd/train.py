@@ -49,7 +49,8 @@ class Trainer(object):
         self.opt = build_optimizer_from_config(self.store, config.optimizer, world_size=world, grad_reduce=grad_reduce)
         self.model_fn = model_fn_builder(config)
         self.reducer = None
-        if dist_ctx is not None and world > 1:
+        from .parallel import FORCE
+        if dist_ctx is not None and (world > 1 or FORCE):
             # encoder weights receive gradients from the joint AND the text-only pass before they may be reduced
             self.reducer = GradReducer(self.store, dist_ctx,
                                        expected_passes={'encoder': 2, 'encoder/LayerNorm_ln_final': 2, '*': 1})
