@@ -1,8 +1,9 @@
 """CPU restatement of the MERLOT pretraining hot path (torch-CPU fp32, unfused).
 
-TEST INFRASTRUCTURE ONLY (see oracle/__init__.py) -- parity unpinned: the
-reference is TF-1.15 graph code that cannot run here; this file follows it op
-for op and cites the reference file:line each function restates.  It is the
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py for the parity status: pinned
+against the reference's own program executed under oracle/tf_shim.py, unpinned
+only for the semantics of TensorFlow's primitive kernels).  This file follows
+the reference op for op and cites the reference file:line each function restates.  It is the
 `use_tpu: False, use_bfloat16: False` variant of the graph: fp32 everywhere,
 three separate Q/K/V GEMMs, materialised SxS attention, separate LN / GELU /
 residual ops.  Dropout is 0 (TF's RNG stream is not reproducible) and every

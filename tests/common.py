@@ -55,3 +55,9 @@ def synth_batch(cfg, E=2, num_chunks=4, Lc=32, seed=1, two_videos=True):
 def rel_l2(a, b):
     a, b = a.detach().float().cpu(), b.detach().float().cpu()
     return float((a - b).norm() / (b.norm() + 1e-20))
+
+
+def head(a, rows=16):
+    """how the shim fixtures store big tensors: [.., last] flattened to 2-D, first `rows` rows (small ones whole)."""
+    a = np.asarray(a)
+    return a.reshape(-1, a.shape[-1])[:rows] if a.size > 65536 else a

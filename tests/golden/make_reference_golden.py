@@ -1,0 +1,357 @@
+"""Runs the UNMODIFIED reference modules (/root/reference, read at run time only) under oracle/tf_shim.py and stores
+their inputs and outputs as fixtures.  BUILD container only.  Fixtures are data: seeded inputs, the weights by TF
+variable name, the random draws the reference made, and what the reference's own program computed from them.
+
+    python tests/golden/make_reference_golden.py            # writes tests/golden/ref_shim_*.npz
+
+What this pins (and what it does not) is stated in oracle/tf_shim.py's header: the reference's control flow, scoping,
+reshape/tile order, masking logic, loss assembly, optimizer arithmetic -- with primitive-op semantics supplied by the
+shim.  The script also prints the restatement-vs-reference differences so a regression is visible at generation time.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+OUT = os.environ.get('MERLOT_GOLDEN_OUT', HERE)          # the live test writes to a temp dir and diffs
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(HERE))
+
+from oracle import tf_shim                                   # noqa: E402
+tf = tf_shim.install()
+sys.path.insert(1, REF)
+from model import modeling as ref_modeling                   # noqa: E402  (the reference, unmodified)
+from utils import optimization as ref_optimization           # noqa: E402
+
+from oracle import merlot_oracle as mo                       # noqa: E402
+from common import tiny_config, synth_batch, head            # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def npy(x):
+    if isinstance(x, torch.Tensor):
+        x = x.detach().cpu()
+        return (x.float() if x.dtype == torch.bfloat16 else x).numpy()
+    return np.asarray(x)
+
+
+GRAD_SAMPLES = ('encoder/layer01/query_layer/kernel', 'encoder/layer00/intermediate/bias',
+                'vision_backbone/vision_transformer/conv2d/kernel', 'vision_backbone/img_idx_pe',
+                'contrastive/lang_proj/kernel', 'lm_head/output_bias', 'viz_viz_temporal/logits/kernel',
+                'vision_backbone/vision_transformer/layer00/LayerNorm_mlp_ln0/gamma',
+                'position_embeddings/position_embeddings', 'langonly_embeddings/LayerNorm_embed_norm/beta',
+                'word_embeddings/word_embeddings')
+
+
+def draws_to_noise(draws, B, L, nm):
+    """the reference's five random calls inside mask_inputs, in program order (model/modeling.py:445-481)."""
+    kinds = [k for k, _ in draws]
+    assert kinds == ['uniform', 'categorical', 'categorical', 'uniform', 'categorical'], kinds
+    u = draws[0][1].float()
+    return dict(gumbel=npy(-torch.log(-torch.log(u))).astype(np.float32).reshape(B, L),
+                gumbel_uniform=npy(u).reshape(B, L),
+                span_lower=npy(draws[1][1]).astype(np.int32).reshape(B, nm),
+                span_upper=npy(draws[2][1]).astype(np.int32).reshape(B, nm),
+                random_ids=npy(draws[3][1]).astype(np.int32).reshape(-1),
+                option=npy(draws[4][1]).astype(np.int32).reshape(-1))
+
+
+def run_reference(cfg, weights, batch, seed, is_training=True, mask_input=True, with_optimizer=None,
+                  global_step=0):
+    tf_shim.STATE.reset(seed=seed, injected={k: npy(v) for k, v in weights.items()})
+    image = tf_shim._w(batch['image'].float().clone())
+    ids = tf_shim._w(batch['input_ids'].to(torch.int32).clone())
+    sidx = tf_shim._w(torch.from_numpy(np.asarray(batch['shuffled_idx_img']).reshape(-1)).to(torch.int32))
+    vsrc = tf_shim._w(torch.from_numpy(np.asarray(batch['video_src_ids'])).to(torch.int32))
+    model = ref_modeling.MerlotModel(config=cfg, is_training=is_training, use_tpu=False, image=image,
+                                     input_ids=ids, mask_input=mask_input, shuffled_idx_img=sidx)
+    out = {'model': model}
+    if mask_input:
+        # model_fn, model/modeling.py:700-713
+        lang_loss, lang_losses = model.mask_loss()
+        contr_loss, contr_losses = model.contrastive_loss()
+        temp_loss, temp_losses = model.temporal_loss(shuffled_idx_img=sidx, video_src_ids=vsrc)
+        loss = lang_loss + contr_loss + temp_loss
+        out.update(loss=loss, lang=lang_losses, contr=contr_losses, temporal=temp_losses)
+        if with_optimizer is not None:
+            gs = tf.compat.v1.train.get_or_create_global_step()
+            gs.assign(torch.tensor(global_step))
+            steps = []
+            for _ in range(2):          # two consecutive updates: the second one decodes a non-zero bf16 m / v state
+                before = {n: npy(v).copy() for n, v in tf_shim.STATE.vars.items()}
+                _, metrics = ref_optimization.build_optimizer_from_config(loss, with_optimizer, {'use_tpu': False})
+                steps.append(dict(before=before, lr=npy(metrics['learning_rate']),
+                                  after={n: npy(v).copy() for n, v in tf_shim.STATE.vars.items()},
+                                  grads={n: npy(g) for n, g in tf_shim.STATE.gradients_log[0].items()
+                                         if g is not None}))
+            out.update(opt_steps=steps, grads=steps[0]['grads'])
+    return out
+
+
+def main():
+    cfg = tiny_config(use_bfloat16=False)
+    batch = synth_batch(cfg, E=2, num_chunks=4, Lc=32, seed=1)
+    weights = mo.init_weights(cfg, seed=0, perturb=True)
+    optimizer_cfg = dict(type='adam_optimizer', learning_rate=1e-4, num_train_steps=1000, num_warmup_steps=100,
+                         weight_decay_rate=0.1, beta_2=0.98, clip_norm=0.0, adafactor=False, epsilon=1e-6,
+                         use_bfloat16_adam=True,
+                         param_overrides=[[["LayerNorm", "layer_norm", "GroupNorm", "bias"],
+                                           {"weight_decay_rate": 0}]])
+
+    ref = run_reference(cfg, weights, batch, seed=7, with_optimizer=optimizer_cfg, global_step=7)
+    m = ref['model']
+    st = tf_shim.STATE
+    print('variables created by the reference:', len(st.vars), '| not covered by the injected dict:',
+          [n for n in st.created_by_initializer if 'adam_' not in n and n != 'global_step'])
+    unused = sorted(set(weights) - set(st.vars))
+    print('injected but never requested by the reference:', unused)
+    assert not unused
+
+    B, L = m.B, m.L
+    nm = int(L * cfg['masking_rate'])
+    noise = draws_to_noise(st.draws, B, L, nm)
+
+    # ---- the restatement on the same inputs / weights / draws
+    o = mo.MerlotOracle(cfg, weights, batch['image'], batch['input_ids'], mask_input=True,
+                        shuffled_idx_img=batch['shuffled_idx_img'], noise=noise)
+    for t in weights.values():
+        t.requires_grad_(True)
+    o = mo.MerlotOracle(cfg, weights, batch['image'], batch['input_ids'], mask_input=True,
+                        shuffled_idx_img=batch['shuffled_idx_img'], noise=noise)
+    o_loss, o_info = o.total_loss(batch['shuffled_idx_img'], batch['video_src_ids'])
+    o_loss.backward()
+
+    def cmp(name, a, b):
+        a, b = npy(a).astype(np.float64), npy(b).astype(np.float64)
+        err = np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
+        print(f'  {name:44s} max-rel-err {err:.3e}')
+        return err
+
+    print('restatement vs shim-executed reference:')
+    worst = 0.0
+    stages = {
+        'vit_hidden_state': (o.vision_transformer_info['hidden_state'], m.vision_transformer_info['hidden_state']),
+        'img_trg_h': (o.img_trg_h, m.img_trg_h),
+        'lang_trg_h': (o.lang_trg_h, m.lang_trg_h),
+        'attention_summs': (o.attention_summs(),
+                            tf.reshape(tf.reduce_sum(m.lang_transformer_info['self_attn_probs'], [1, 2]), [B, L])),
+        'encoder_viz': (o.encoder_hidden_states['viz'], m.encoder_hidden_states['viz']),
+        'encoder_lang': (o.encoder_hidden_states['lang'], m.encoder_hidden_states['lang']),
+        'loss': (o_loss, ref['loss']),
+    }
+    for k, (a, b) in stages.items():
+        worst = max(worst, cmp(k, a, b))
+    assert np.array_equal(npy(o.lang_mask_info['masked_ids']), npy(m.lang_mask_info['masked_ids'])), 'masked_ids'
+    assert np.array_equal(npy(o.lang_mask_info['masked_idx']), npy(m.lang_mask_info['masked_idx'])), 'masked_idx'
+    print('  masked_ids / masked_idx                      bit-exact')
+    for grp, od in (('lang', o_info['lang']), ('contr', o_info['contr']), ('temporal', o_info['temporal'])):
+        for k, v in ref[grp].items():
+            worst = max(worst, cmp(f'{grp}/{k}', od[k], v))
+    for k, v in m.attention_log.items():
+        worst = max(worst, cmp(f'attention_log/{k}', o.attention_log[k], v))
+    gerr = {n: float(np.abs(npy(weights[n].grad) - g).max() / (np.abs(g).max() + 1e-30))
+            for n, g in ref['grads'].items()}
+    # key biases: softmax is invariant to a per-query constant, so their true gradient is 0 and what both programs
+    # hold is round-off -- excluded from the relative check (and from the fixture's per-tensor list)
+    gerr = {n: e for n, e in gerr.items() if not n.endswith('key_layer/bias')}
+    worst_g = max(gerr, key=gerr.get)
+    print(f'  gradients: {len(gerr)} tensors, worst {worst_g} {gerr[worst_g]:.3e}')
+    for n in sorted(gerr, key=gerr.get)[-4:]:
+        print(f'      {n:70s} {gerr[n]:.3e}')
+    assert set(ref['grads']) == set(weights), set(weights) ^ set(ref['grads'])
+    assert worst < 2e-4 and gerr[worst_g] < 2e-3, (worst, gerr[worst_g])
+
+    # ---- fixture 1: model outputs (config #1, fp32)
+    fx = {f'noise/{k}': v for k, v in noise.items()}
+    fx.update({
+        'image': npy(batch['image']), 'input_ids': npy(batch['input_ids']).astype(np.int32),
+        'shuffled_idx_img': np.asarray(batch['shuffled_idx_img']).astype(np.int32),
+        'video_src_ids': np.asarray(batch['video_src_ids']).astype(np.int32),
+        'weights_seed': np.int64(0),
+        'variable_names': np.array(sorted(n for n in st.vars if 'adam_' not in n and n != 'global_step')),
+        'variable_shapes': np.array([str(list(st.vars[n].size())) for n in
+                                     sorted(n for n in st.vars if 'adam_' not in n and n != 'global_step')]),
+        'out/vit_hidden_state': npy(m.vision_transformer_info['hidden_state']),
+        'out/img_trg_h': npy(m.img_trg_h), 'out/lang_trg_h': npy(m.lang_trg_h),
+        'out/attention_summs': npy(stages['attention_summs'][1]),
+        'out/masked_ids': npy(m.lang_mask_info['masked_ids']).astype(np.int32),
+        'out/masked_idx': npy(m.lang_mask_info['masked_idx']).astype(np.int32),
+        'out/encoder_viz': npy(m.encoder_hidden_states['viz']),
+        'out/encoder_lang': npy(m.encoder_hidden_states['lang']),
+        'out/loss': npy(ref['loss']),
+    })
+    for grp in ('lang', 'contr', 'temporal'):
+        for k, v in ref[grp].items():
+            fx[f'out/{grp}/{k}'] = npy(v)
+    for k, v in m.attention_log.items():
+        fx[f'out/attention_log/{k}'] = npy(v)
+    # gradients: norms of all, full tensors of a handful (keeps the fixture small)
+    fx['grad_names'] = np.array(sorted(ref['grads']))
+    fx['grad_norms'] = np.array([np.linalg.norm(ref['grads'][n].astype(np.float64)) for n in sorted(ref['grads'])])
+    for n in GRAD_SAMPLES:
+        fx[f'grad/{n}'] = head(ref['grads'][n])
+    fx['weights_checksum'] = np.float64(sum(float(npy(v).astype(np.float64).sum()) for v in weights.values()))
+    np.savez_compressed(os.path.join(OUT, 'ref_shim_config1.npz'), **fx)
+
+    # ---- fixture 2: the reference optimizer (utils/optimization.py:55-416) applied twice, global_step 7 and 8.
+    # (the second call re-uses the first call's loss graph, so its `grad` is not a true gradient of the updated
+    #  weights -- irrelevant here: the vectors pin the element-wise update rule given (param, grad, m, v, step).)
+    ofx = {'learning_rate': np.float64(optimizer_cfg['learning_rate']), 'num_train_steps': np.int64(1000),
+           'num_warmup_steps': np.int64(100), 'weight_decay_rate': np.float64(0.1), 'beta_2': np.float64(0.98),
+           'epsilon': np.float64(1e-6)}
+    for i, stp in enumerate(ref['opt_steps']):
+        ofx[f's{i}/global_step'] = stp['before']['global_step']
+        ofx[f's{i}/lr_metric'] = stp['lr']
+        for n in ('encoder/layer01/query_layer/kernel', 'encoder/layer00/intermediate/bias',
+                  'vision_backbone/vision_transformer/layer00/LayerNorm_mlp_ln0/gamma', 'lm_head/output_bias',
+                  'viz_viz_temporal/logits/kernel'):
+            ofx[f's{i}/param/{n}'] = head(stp['before'][n])
+            ofx[f's{i}/grad/{n}'] = head(stp['grads'][n])
+            for k in ('adam_m', 'adam_v'):
+                b4 = stp['before'].get(f'{n}/{k}')
+                ofx[f's{i}/{k}/{n}'] = head(np.zeros_like(stp['before'][n]) if b4 is None else b4.astype(np.float32))
+                ofx[f's{i}/new_{k}/{n}'] = head(stp['after'][f'{n}/{k}'].astype(np.float32))
+            ofx[f's{i}/new_param/{n}'] = head(stp['after'][n])
+    np.savez_compressed(os.path.join(OUT, 'ref_shim_optimizer.npz'), **ofx)
+    print('wrote ref_shim_config1.npz, ref_shim_optimizer.npz')
+    make_dp2(cfg, weights, optimizer_cfg)
+    make_sort_story()
+
+
+def make_dp2(cfg, weights, optimizer_cfg):
+    """Two simulated replicas (threads sharing the variables; tf.tpu.cross_replica_sum = barrier + sum): the
+    reference's tpu_cross_replica_stack (utils/model_utils.py:673-707), the labels offset (model/modeling.py:519) and
+    CrossShardOptimizer's gradient psum (utils/optimization.py:241-245) run as written."""
+    world = 2
+    batches = [synth_batch(cfg, E=2, num_chunks=4, Lc=32, seed=10 + r) for r in range(world)]
+    st = tf_shim.STATE
+    st.reset(seed=11, injected={k: npy(v) for k, v in weights.items()}, num_shards=world)
+    summed = {}
+
+    def replica(r):
+        b = batches[r]
+        image = tf_shim._w(b['image'].float().clone())
+        ids = tf_shim._w(b['input_ids'].to(torch.int32).clone())
+        sidx = tf_shim._w(torch.from_numpy(b['shuffled_idx_img'].reshape(-1)).to(torch.int32))
+        vsrc = tf_shim._w(torch.from_numpy(b['video_src_ids']).to(torch.int32))
+        m = ref_modeling.MerlotModel(config=cfg, is_training=True, use_tpu=False, image=image, input_ids=ids,
+                                     mask_input=True, shuffled_idx_img=sidx)
+        l1, i1 = m.mask_loss()
+        l2, i2 = m.contrastive_loss()
+        l3, i3 = m.temporal_loss(shuffled_idx_img=sidx, video_src_ids=vsrc)
+        loss = l1 + l2 + l3
+        # CrossShardOptimizer wraps the optimizer only under use_tpu (utils/optimization.py:241-242)
+        opt = dict(optimizer_cfg)
+        real_apply = ref_optimization.AdamOptimizer.apply_gradients
+
+        def capture(self, grads_and_vars, global_step=None, name=None):
+            gv = list(grads_and_vars)
+            if r == 0:
+                summed.update({v.name[:-2]: npy(g) for g, v in gv if g is not None})
+            return real_apply(self, gv, global_step=global_step, name=name)
+        ref_optimization.AdamOptimizer.apply_gradients = capture
+        try:
+            ref_optimization.build_optimizer_from_config(loss, opt, {'use_tpu': True})
+        finally:
+            ref_optimization.AdamOptimizer.apply_gradients = real_apply
+        return dict(loss=npy(loss), contr={k: npy(v) for k, v in i2.items()}, lang=npy(l1), temporal=npy(l3),
+                    masked_ids=npy(m.lang_mask_info['masked_ids']), masked_idx=npy(m.lang_mask_info['masked_idx']),
+                    B=m.B, L=m.L)
+
+    res = tf_shim.run_replicas(replica, world)
+    nm = int(res[0]['L'] * cfg['masking_rate'])
+    noises = [draws_to_noise(st.draws_of(r), res[r]['B'], res[r]['L'], nm) for r in range(world)]
+
+    # restatement: both replicas in one graph, contrastive sets gathered, objective = SUM over replicas
+    for t in weights.values():
+        t.grad = None
+        t.requires_grad_(True)
+    models = [mo.MerlotOracle(cfg, weights, b['image'], b['input_ids'], mask_input=True,
+                              shuffled_idx_img=b['shuffled_idx_img'], noise=nz) for b, nz in zip(batches, noises)]
+    embs = [m.contrastive_embeddings() for m in models]
+    all_lang = torch.cat([e[0] for e in embs], 0)
+    all_viz = torch.cat([e[1] for e in embs], 0)
+    total = 0.0
+    print('2 simulated replicas, restatement vs shim-executed reference:')
+    for r, (m, b) in enumerate(zip(models, batches)):
+        lc, ic = m.contrastive_loss(all_lang=all_lang, all_viz=all_viz, my_group_idx=r)
+        lt = m.mask_loss()[0] + lc + m.temporal_loss(b['shuffled_idx_img'], b['video_src_ids'])[0]
+        print(f"  replica {r}: loss {float(lt):.6f} vs {float(res[r]['loss']):.6f}; lang_to_viz "
+              f"{float(ic['lang_to_viz']):.6f} vs {float(res[r]['contr']['lang_to_viz']):.6f}")
+        assert abs(float(lt) - float(res[r]['loss'])) < 1e-4
+        assert np.array_equal(npy(m.lang_mask_info['masked_ids']), res[r]['masked_ids'])
+        total = total + lt
+    total.backward()
+    gerr = {n: float(np.abs(npy(weights[n].grad) - g).max() / (np.abs(g).max() + 1e-30))
+            for n, g in summed.items() if not n.endswith('key_layer/bias')}
+    worst = max(gerr, key=gerr.get)
+    print(f'  summed gradients: {len(gerr)} tensors, worst {worst} {gerr[worst]:.3e}')
+    assert gerr[worst] < 2e-3
+
+    fx = {'world': np.int64(world), 'batch_seeds': np.array([10, 11])}
+    for r in range(world):
+        for k, v in noises[r].items():
+            fx[f'r{r}/noise/{k}'] = v
+        fx[f'r{r}/loss'] = res[r]['loss']
+        fx[f'r{r}/lang'] = res[r]['lang']
+        fx[f'r{r}/temporal'] = res[r]['temporal']
+        for k, v in res[r]['contr'].items():
+            fx[f'r{r}/contr/{k}'] = v
+        fx[f'r{r}/masked_ids'] = res[r]['masked_ids'].astype(np.int32)
+        fx[f'r{r}/masked_idx'] = res[r]['masked_idx'].astype(np.int32)
+    fx['grad_names'] = np.array(sorted(summed))
+    fx['grad_norms'] = np.array([np.linalg.norm(summed[n].astype(np.float64)) for n in sorted(summed)])
+    for n in GRAD_SAMPLES:
+        fx[f'grad/{n}'] = head(summed[n])
+    np.savez_compressed(os.path.join(OUT, 'ref_shim_dp2.npz'), **fx)
+    print('wrote ref_shim_dp2.npz')
+
+
+def make_sort_story():
+    """downstream/sort_story/get_zero_shot_logits.py: its `model_fn` is AST-extracted (the module itself opens
+    checkpoints and h5 files at import) and executed unmodified under the shim."""
+    import ast
+    import types
+    src = open(os.path.join(REF, 'downstream/sort_story/get_zero_shot_logits.py')).read()
+    tree = ast.parse(src)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == 'model_fn']
+    assert len(fn) == 1
+    cfg = tiny_config(use_bfloat16=False, num_chunks_in_group=5)
+    config = types.SimpleNamespace(model=cfg, device={'use_tpu': False})
+    from utils.model_utils import get_shape_list
+    ns = {'tf': tf, 'MerlotModel': ref_modeling.MerlotModel, 'get_shape_list': get_shape_list, 'config': config,
+          'NUM_CHUNKS': 5, 'duplication_factor': 2}
+    exec(compile(ast.Module(body=fn, type_ignores=[]), 'get_zero_shot_logits_extract', 'exec'), ns)
+
+    bs, n = 2, 5
+    weights = mo.init_weights(cfg, seed=3, perturb=True)
+    b = synth_batch(cfg, E=bs, num_chunks=n, Lc=32, seed=5)
+    tf_shim.STATE.reset(seed=21, injected={k: npy(v) for k, v in weights.items()})
+    H, W = cfg['image_size']
+    features = {'images': tf_shim._w(b['image'].float().reshape(bs, n, H, W, 3).clone()),
+                'sentences': tf_shim._w(b['input_ids'].to(torch.int32).clone())}
+    spec = ns['model_fn'](features, None, 'infer', {'batch_size': bs})
+    pred = spec['predictions']
+    draws = tf_shim.STATE.draws_of(0)
+    assert [k for k, _ in draws] == ['uniform']
+    u = npy(draws[0][1]).astype(np.float32)
+    o = mo.sort_story_probs(cfg, weights, b['image'].float().reshape(bs, n, H, W, 3), b['input_ids'], u,
+                            duplication_factor=2, faithful_dup_reshape=True)
+    print('sort_story model_fn, restatement vs shim-executed reference:')
+    for k in ('lang_viz_probs', 'viz_viz_probs'):
+        err = float(np.abs(npy(o[k]) - npy(pred[k])).max())
+        print(f'  {k:20s} max-abs-err {err:.3e}')
+        assert err < 1e-5
+    np.savez_compressed(os.path.join(OUT, 'ref_shim_sort_story.npz'), u_shuffle=u, weights_seed=np.int64(3),
+                        batch_seed=np.int64(5), lang_viz_probs=npy(pred['lang_viz_probs']),
+                        viz_viz_probs=npy(pred['viz_viz_probs']))
+    print('wrote ref_shim_sort_story.npz')
+
+
+if __name__ == '__main__':
+    main()

@@ -17,6 +17,11 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(HERE))
 
 
+def _fixture_noise(rank):
+    fx = np.load(os.path.join(HERE, 'golden', 'ref_shim_dp2.npz'))
+    return {k: fx[f'r{rank}/noise/{k}'] for k in ('gumbel', 'span_lower', 'span_upper', 'random_ids', 'option')}
+
+
 def _worker(rank, world, port, out_dir):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -37,6 +42,7 @@ def _worker(rank, world, port, out_dir):
     cfg = tiny_config()
     w = mo.init_weights(cfg, 0)
     b = synth_batch(cfg, seed=10 + rank)                       # each replica its own data
+    b['noise'] = _fixture_noise(rank)                          # the draws the reference program made (dp2 fixture)
     st = ParamStore(cfg, 'cpu', seed=0)
     st.load_tf_weights(w)
     ctx = DistContext()
@@ -78,6 +84,7 @@ def test_dp2_matches_single_process_oracle(tmp_path):
     models, batches = [], []
     for r in range(world):
         b = synth_batch(cfg, seed=10 + r)
+        b['noise'] = _fixture_noise(r)
         m = mo.MerlotOracle(cfg, w, b['image'], b['input_ids'], mask_input=True, shuffled_idx_img=b['shuffled_idx_img'],
                             noise=b['noise'])
         models.append(m)
@@ -101,3 +108,16 @@ def test_dp2_matches_single_process_oracle(tmp_path):
         rels.append(rel_l2(res[0]['grad'][k], v.grad))
         assert rels[-1] < 0.15, (k, rels[-1])
     assert np.median(rels) < 3e-2
+
+    # and directly against the reference's own two-replica program (tpu_cross_replica_stack + CrossShardOptimizer
+    # executed under oracle/tf_shim.py, tests/golden/ref_shim_dp2.npz): per-replica losses, summed gradients
+    from common import head
+    fx = np.load(os.path.join(HERE, 'golden', 'ref_shim_dp2.npz'))
+    for r in range(world):
+        assert abs(res[r]['loss'] - float(fx[f'r{r}/loss'])) < 3e-2
+        assert abs(res[r]['contr']['lang_to_viz'] - float(fx[f'r{r}/contr/lang_to_viz'])) < 2e-2
+    for k in fx.files:
+        if k.startswith('grad/'):
+            n = k[5:]
+            r_ = rel_l2(torch.from_numpy(head(res[0]['grad'][n].float().numpy())), torch.from_numpy(fx[k]))
+            assert r_ < 0.15, (n, r_)

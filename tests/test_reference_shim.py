@@ -1,0 +1,188 @@
+"""The restatement (oracle/) and the host-side name map against fixtures produced by running the UNMODIFIED reference
+modules under oracle/tf_shim.py (tests/golden/make_reference_golden.py; what that pins: see tf_shim.py's header).
+CPU only.  The last test re-runs the generator live when /root/reference is present (build container) and is
+skipped elsewhere (the GPU box never sees the reference)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from common import tiny_config, synth_batch, head
+from oracle import merlot_oracle as mo
+from oracle import optimizer_oracle as oo
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+REL = 2e-5            # fp32 restatement vs fp32 shim run: different summation orders only
+
+
+def _load(name):
+    return np.load(os.path.join(GOLD, name), allow_pickle=False)
+
+
+def _relmax(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def _noise(fx, prefix='noise/'):
+    return {k: fx[prefix + k] for k in ('gumbel', 'span_lower', 'span_upper', 'random_ids', 'option')}
+
+
+def _weights(cfg, seed, fx=None):
+    w = mo.init_weights(cfg, seed=seed, perturb=True)
+    if fx is not None:   # the fixture was generated from these very numbers (guards against RNG drift)
+        assert abs(sum(float(v.double().sum()) for v in w.values()) - float(fx['weights_checksum'])) < 1e-6
+    for t in w.values():
+        t.requires_grad_(True)
+    return w
+
+
+def test_restatement_matches_reference_program_config1():
+    fx = _load('ref_shim_config1.npz')
+    cfg = tiny_config(use_bfloat16=False)
+    w = _weights(cfg, 0, fx)
+    sidx, vsrc = fx['shuffled_idx_img'], fx['video_src_ids']
+    o = mo.MerlotOracle(cfg, w, torch.from_numpy(fx['image']), torch.from_numpy(fx['input_ids']).long(),
+                        mask_input=True, shuffled_idx_img=sidx, noise=_noise(fx))
+    loss, info = o.total_loss(sidx, vsrc)
+    loss.backward()
+    # integer outputs: bit-exact
+    assert np.array_equal(o.lang_mask_info['masked_ids'].numpy(), fx['out/masked_ids'])
+    assert np.array_equal(o.lang_mask_info['masked_idx'].numpy(), fx['out/masked_idx'])
+    got = {'vit_hidden_state': o.vision_transformer_info['hidden_state'], 'img_trg_h': o.img_trg_h,
+           'lang_trg_h': o.lang_trg_h, 'attention_summs': o.attention_summs(),
+           'encoder_viz': o.encoder_hidden_states['viz'], 'encoder_lang': o.encoder_hidden_states['lang'],
+           'loss': loss}
+    for grp in ('lang', 'contr', 'temporal'):
+        for k, v in info[grp].items():
+            got[f'{grp}/{k}'] = v
+    for k, v in o.attention_log.items():
+        got[f'attention_log/{k}'] = v
+    checked = 0
+    for k in fx.files:
+        if k.startswith('out/') and k[4:] in got:
+            assert _relmax(got[k[4:]].detach().numpy(), fx[k]) < REL, k
+            checked += 1
+    assert checked >= 20
+    # gradients of every trainable variable (norms) + a sample of full tensors
+    names = [str(n) for n in fx['grad_names']]
+    assert set(names) == set(w)
+    for n, ref_norm in zip(names, fx['grad_norms']):
+        if n.endswith('key_layer/bias'):      # true gradient is 0 (softmax shift invariance): round-off on both sides
+            assert float(w[n].grad.norm()) < 1e-5
+            continue
+        assert abs(float(w[n].grad.double().norm()) - ref_norm) <= 2e-4 * ref_norm + 1e-9, n
+    for k in fx.files:
+        if k.startswith('grad/'):
+            assert _relmax(head(w[k[5:]].grad.numpy()), fx[k]) < 2e-4, k
+
+
+def test_variable_names_and_layouts_are_the_reference_ones():
+    """what the reference's variable scopes actually create == oracle.variable_shapes == ParamStore's TF export."""
+    fx = _load('ref_shim_config1.npz')
+    cfg = tiny_config(use_bfloat16=False)
+    ref = {str(n): str(s) for n, s in zip(fx['variable_names'], fx['variable_shapes'])}
+    mine = {n: str(list(s)) for n, s in mo.variable_shapes(cfg).items()}
+    assert mine == ref
+    from merlot_amd.params import ParamStore
+    st = ParamStore(tiny_config(), 'cpu', seed=0)
+    exported = {n: str(list(t.shape)) for n, t in st.export_tf_weights().items()}
+    assert exported == ref
+
+
+def test_restatement_matches_reference_program_two_replicas():
+    """tpu_cross_replica_stack + CrossShardOptimizer semantics: each replica's loss uses the gathered negatives with
+    its label offset; the applied gradient is the SUM over replicas including the cross-replica terms."""
+    fx = _load('ref_shim_dp2.npz')
+    cfg = tiny_config(use_bfloat16=False)
+    w = _weights(cfg, 0)
+    world = int(fx['world'])
+    batches = [synth_batch(cfg, seed=int(s)) for s in fx['batch_seeds']]
+    models = [mo.MerlotOracle(cfg, w, b['image'], b['input_ids'], mask_input=True,
+                              shuffled_idx_img=b['shuffled_idx_img'], noise=_noise(fx, f'r{r}/noise/'))
+              for r, b in enumerate(batches)]
+    embs = [m.contrastive_embeddings() for m in models]
+    all_lang, all_viz = torch.cat([e[0] for e in embs], 0), torch.cat([e[1] for e in embs], 0)
+    total = 0.0
+    for r, (m, b) in enumerate(zip(models, batches)):
+        assert np.array_equal(m.lang_mask_info['masked_ids'].numpy(), fx[f'r{r}/masked_ids'])
+        lc, ic = m.contrastive_loss(all_lang=all_lang, all_viz=all_viz, my_group_idx=r)
+        for k in ('lang_to_viz', 'viz_to_lang', 'loss_all'):
+            assert abs(float(ic[k]) - float(fx[f'r{r}/contr/{k}'])) < 1e-5, (r, k)
+        lt = m.mask_loss()[0] + lc + m.temporal_loss(b['shuffled_idx_img'], b['video_src_ids'])[0]
+        assert abs(float(lt) - float(fx[f'r{r}/loss'])) < 5e-5
+        total = total + lt
+    assert world == 2
+    total.backward()
+    for n, ref_norm in zip(fx['grad_names'], fx['grad_norms']):
+        n = str(n)
+        if n.endswith('key_layer/bias'):
+            continue
+        assert abs(float(w[n].grad.double().norm()) - ref_norm) <= 2e-4 * ref_norm + 1e-9, n
+    for k in fx.files:
+        if k.startswith('grad/'):
+            assert _relmax(head(w[k[5:]].grad.numpy()), fx[k]) < 2e-4, k
+
+
+def test_restatement_matches_reference_sort_story_model_fn():
+    """downstream/sort_story/get_zero_shot_logits.py model_fn (dup x2, argsort(u)+64, softmax[:,1:], the [batch, dup]
+    reshape quirk) executed by the reference's own code."""
+    fx = _load('ref_shim_sort_story.npz')
+    cfg = tiny_config(use_bfloat16=False, num_chunks_in_group=5)
+    w = mo.init_weights(cfg, seed=int(fx['weights_seed']), perturb=True)
+    bs, n = 2, 5
+    b = synth_batch(cfg, E=bs, num_chunks=n, Lc=32, seed=int(fx['batch_seed']))
+    H, W = cfg['image_size']
+    with torch.no_grad():
+        o = mo.sort_story_probs(cfg, w, b['image'].float().reshape(bs, n, H, W, 3), b['input_ids'], fx['u_shuffle'],
+                                duplication_factor=2, faithful_dup_reshape=True)
+    for k in ('lang_viz_probs', 'viz_viz_probs'):
+        assert float(np.abs(o[k].numpy() - fx[k]).max()) < 1e-5
+
+
+def test_optimizer_restatement_matches_reference_adam():
+    """utils/optimization.py AdamOptimizer.apply_gradients (bias correction, bf16 m, sign-encoded v, decoupled decay
+    except LayerNorm/bias) + the warm-up/decay scale, two consecutive steps."""
+    fx = _load('ref_shim_optimizer.npz')
+    lr0, nts, nws = float(fx['learning_rate']), int(fx['num_train_steps']), int(fx['num_warmup_steps'])
+    from merlot_amd.optimization import learning_rate_scale as host_scale
+    seen_negative_v = False
+    for i in (0, 1):
+        gs = int(fx[f's{i}/global_step'])
+        scale = oo.learning_rate_scale(gs, nts, nws)
+        assert abs(float(lr0 * scale) - float(fx[f's{i}/lr_metric'])) < 1e-6 * lr0
+        assert abs(host_scale(gs, nts, nws) - float(scale)) < 1e-6            # host mirror (python doubles)
+        names = sorted({k.split('/', 2)[2] for k in fx.files if k.startswith(f's{i}/param/')})
+        assert len(names) == 5
+        for n in names:
+            decay = 0.0 if any(s in n for s in ('LayerNorm', 'layer_norm', 'GroupNorm', 'bias')) else 0.1
+            p, m, v = oo.adamw_update(fx[f's{i}/param/{n}'], fx[f's{i}/grad/{n}'], fx[f's{i}/adam_m/{n}'],
+                                      fx[f's{i}/adam_v/{n}'], gs, lr0, scale, decay, beta_2=float(fx['beta_2']),
+                                      epsilon=float(fx['epsilon']), use_bfloat16_adam=True)
+            assert np.array_equal(m, fx[f's{i}/new_adam_m/{n}']), n                     # bf16 states: bit-exact
+            assert np.array_equal(v, fx[f's{i}/new_adam_v/{n}']), n
+            assert np.allclose(p, fx[f's{i}/new_param/{n}'], rtol=2e-7, atol=1e-9), n
+            seen_negative_v |= bool((fx[f's{i}/new_adam_v/{n}'] < 0).any())
+    assert seen_negative_v          # the sign-bit encoding path was exercised
+    assert oo.learning_rate_scale(500, 1000, 100) == np.float32(1000.0 / 901.0) * np.float32(0.5)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.skipif(not os.path.isdir('/root/reference/model'), reason="reference sources only exist in the build "
+                    "container; the committed fixtures carry its outputs everywhere else")
+def test_live_reference_run_reproduces_committed_fixtures(tmp_path):
+    env = dict(os.environ, MERLOT_GOLDEN_OUT=str(tmp_path))
+    r = subprocess.run([sys.executable, os.path.join(GOLD, 'make_reference_golden.py')], env=env,
+                       capture_output=True, text=True, timeout=850)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    for name in ('ref_shim_config1.npz', 'ref_shim_optimizer.npz', 'ref_shim_dp2.npz', 'ref_shim_sort_story.npz'):
+        new, old = np.load(os.path.join(str(tmp_path), name)), _load(name)
+        assert sorted(new.files) == sorted(old.files)
+        for k in old.files:
+            if old[k].dtype.kind in 'iuUSb':
+                assert np.array_equal(new[k], old[k]), (name, k)
+            else:
+                assert np.allclose(new[k], old[k], rtol=1e-5, atol=1e-7), (name, k)
