@@ -49,16 +49,57 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return cdf + x * pdf;
 }
 
-// counter-based dropout keep decision: one 32-bit hash per element (site seed + linear index).
+// GEMM-epilogue forms (bf16 outputs): Abramowitz-Stegun 7.1.26 for erf (|error| <= 1.5e-7 absolute, i.e. far below
+// the bf16 rounding of the result) on raw v_rcp / v_exp -- ~14 VALU instructions instead of ocml erff's two-branch
+// evaluation; the epilogue arithmetic of a K=768 GEMM was costing a third of its main loop
+// (profiles/r01_f_epilogue_decomposition.txt).  gelu'(u) re-uses the same exponential: exp(-z^2), z = |u|/sqrt(2).
+__device__ __forceinline__ float erf_abs_fast(float z, float& e) {          // z >= 0; returns erf(z), e = exp(-z*z)
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+    float poly = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    poly = __builtin_fmaf(poly, t, 1.421413741f);
+    poly = __builtin_fmaf(poly, t, -0.284496736f);
+    poly = __builtin_fmaf(poly, t, 0.254829592f);
+    e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+    return __builtin_fmaf(-poly * t, e, 1.0f);
+}
+__device__ __forceinline__ float gelu_fast(float x) {
+    float e;
+    const float er = erf_abs_fast(__builtin_fabsf(x) * 0.70710678118654752440f, e);
+    return x * __builtin_fmaf(0.5f, __builtin_copysignf(er, x), 0.5f);
+}
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+    float e;
+    const float er = erf_abs_fast(__builtin_fabsf(x) * 0.70710678118654752440f, e);
+    const float cdf = __builtin_fmaf(0.5f, __builtin_copysignf(er, x), 0.5f);
+    return __builtin_fmaf(x * 0.39894228040143267794f, e, cdf);
+}
+
+// counter-based dropout keep decision (site seed + linear element index): ONE 32-bit hash per PAIR of elements, its
+// two 16-bit halves compared with a 16-bit threshold (p is resolved to 2^-16).  Every user -- GEMM residual epilogue,
+// merlot_dropout_apply, the fused mask in ln_bwd -- goes through these functions, so forward and backward agree.
 __device__ __forceinline__ uint32_t hash32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }
+__device__ __forceinline__ uint32_t dropout_word(uint64_t seed, uint64_t pair) {
+    return hash32((uint32_t)pair ^ (uint32_t)seed) ^ ((uint32_t)(seed >> 32) * 0x9E3779B1u);
+}
 __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
-    // thresh = p * 2^32 ; keep iff hash >= thresh
-    uint32_t h = hash32((uint32_t)idx ^ (uint32_t)seed) ^ hash32((uint32_t)(idx >> 32) + (uint32_t)(seed >> 32) + 0x9e3779b9U);
-    h = hash32(h);
-    return h >= thresh;
+    // thresh = p * 2^32 ; keep iff this element's 16-bit field >= p * 2^16
+    const uint32_t w = dropout_word(seed, idx >> 1);
+    return ((idx & 1) ? (w >> 16) : (w & 0xffffu)) >= (thresh >> 16);
+}
+// N consecutive elements starting at an EVEN index: N/2 hashes
+template <int N>
+__device__ __forceinline__ void dropout_keep_n(uint64_t seed, uint64_t idx0, uint32_t thresh, bool (&keep)[N]) {
+    static_assert(N % 2 == 0, "pairs");
+    const uint32_t t16 = thresh >> 16;
+#pragma unroll
+    for (int j = 0; j < N / 2; ++j) {
+        const uint32_t w = dropout_word(seed, (idx0 >> 1) + j);
+        keep[2 * j] = (w & 0xffffu) >= t16;
+        keep[2 * j + 1] = (w >> 16) >= t16;
+    }
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

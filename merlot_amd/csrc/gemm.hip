@@ -16,6 +16,7 @@
 //     the grid with fp32 atomics fills the 256 CUs when M*N is only a few dozen tiles.
 //   * block -> tile map is XCD-aware: the 8 XCDs each walk a contiguous band of row tiles, all column
 //     tiles of a row tile adjacent, so an A row band is fetched from HBM once per XCD L2.
+#include <atomic>
 #include <cstdlib>
 
 #include "common.h"
@@ -135,7 +136,7 @@ __device__ __forceinline__ void nt_epilogue_quad(const GemmNTArgs& p, int m, int
                 }
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+            for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
         } else if (EPI == MERLOT_EPI_DGELU) {
             const bf16* ai = p.aux_in + (int64_t)m * p.ld_aux_in + n;
             float u[4] = {0.f, 0.f, 0.f, 0.f};
@@ -147,7 +148,7 @@ __device__ __forceinline__ void nt_epilogue_quad(const GemmNTArgs& p, int m, int
                 for (int e = 0; e < ne; ++e) u[e] = (float)ai[e];
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(u[e]);
+            for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_fast(u[e]);
         } else if (EPI == MERLOT_EPI_RESIDUAL) {
             if (p.drop_thresh) {
 #pragma unroll
@@ -420,6 +421,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTNArgs p) {
 template <int EPI, bool OUT_F32>
 __device__ __forceinline__ void epilogue_row8(const GemmNTArgs& p, int m, int n, float (&v)[8]) {
     // v = alpha * acc for columns n..n+7 of row m; n + 7 < N guaranteed, 16-B alignment guaranteed by the caller
+    if (p.dbg & 8) {                                     // experiments: epilogue arithmetic + staging, no memory ops
+        if (v[0] == 12345.678f) *reinterpret_cast<float*>(p.C) = v[1];
+        return;
+    }
     if (p.bias) {
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
         const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
@@ -437,18 +442,23 @@ __device__ __forceinline__ void epilogue_row8(const GemmNTArgs& p, int m, int n,
             *reinterpret_cast<bf16x8*>(p.aux_out + (int64_t)m * p.ld_aux_out + n) = u8;
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+        for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
     } else if (EPI == MERLOT_EPI_DGELU) {
         const bf16x8 u8 = *reinterpret_cast<const bf16x8*>(p.aux_in + (int64_t)m * p.ld_aux_in + n);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f((float)u8[e]);
+        for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_fast((float)u8[e]);
     } else if (EPI == MERLOT_EPI_RESIDUAL) {
         if (p.drop_thresh) {
+            bool keep[8];
+            const uint64_t idx0 = (uint64_t)m * (uint64_t)p.N + (uint64_t)n;      // n % 8 == 0 on this path
+            if (!(p.N & 1)) {
+                dropout_keep_n<8>(p.drop_seed, idx0, p.drop_thresh, keep);
+            } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const uint64_t idx = (uint64_t)m * (uint64_t)p.N + (uint64_t)(n + e);
-                v[e] = dropout_keep(p.drop_seed, idx, p.drop_thresh) ? v[e] * p.drop_scale : 0.f;
+                for (int e = 0; e < 8; ++e) keep[e] = dropout_keep(p.drop_seed, idx0 + e, p.drop_thresh);
             }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = keep[e] ? v[e] * p.drop_scale : 0.f;
         }
         const bf16x8 r8 = *reinterpret_cast<const bf16x8*>(p.aux_in + (int64_t)m * p.ld_aux_in + n);
 #pragma unroll
@@ -713,6 +723,122 @@ __device__ __forceinline__ void slab_epilogue(const GemmNTArgs& p, const f32x16&
     __builtin_amdgcn_wave_barrier();
 }
 
+// Tile epilogue for INTERIOR tiles of the persistent kernels (every row/column valid, 16-B aligned operands): the
+// same LDS slab staging as slab_epilogue, but nothing in it waits on a fresh global load.  Measured on the old path
+// (profiles/r01_f_epilogue_latency.txt): the epilogue's instructions are ~free, its HBM traffic is modest -- what
+// cost as much as the whole K=768 main loop was LATENCY: `bias` was re-loaded after every store (may alias C) and
+// each residual / pre-activation row segment was loaded right where it was consumed, 16 dependent round trips per
+// wave per tile.  Here bias is read once per tile and the auxiliary operand runs PF passes (1 KiB each) ahead.
+template <int EPI, bool OUT_F32>
+__device__ __forceinline__ void fast_tile_epilogue(const GemmNTArgs& p, f32x16 (&acc)[2][4], char* slab, int m_base,
+                                                   int n_base, int lane) {
+    constexpr bool HAS_AUX = (EPI == MERLOT_EPI_RESIDUAL) || (EPI == MERLOT_EPI_DGELU);
+    constexpr int PF = 8;                                // aux prefetch distance in passes (4 VGPRs each)
+    const int hi = lane >> 5, row = lane & 31;
+    const int rr = lane >> 3, c0 = (lane & 7) * 8, ch = 2 * (lane & 7);
+    f32x4 bias_r[2][2];
+#pragma unroll
+    for (int fp = 0; fp < 2; ++fp) {
+        if (p.bias) {
+            bias_r[fp][0] = *reinterpret_cast<const f32x4*>(p.bias + n_base + fp * 64 + c0);
+            bias_r[fp][1] = *reinterpret_cast<const f32x4*>(p.bias + n_base + fp * 64 + c0 + 4);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bias_r[fp][0][e] = bias_r[fp][1][e] = 0.f;
+        }
+    }
+    // pass q = slab * 4 + ps, slab = fi * 2 + fp: rows m_base + fi*32 + ps*8 + rr, columns n_base + fp*64 + c0 .. +7
+    auto aux_addr = [&](int q) {
+        const int sl = q >> 2, ps = q & 3;
+        return p.aux_in + (int64_t)(m_base + (sl >> 1) * 32 + ps * 8 + rr) * p.ld_aux_in + (n_base + (sl & 1) * 64 + c0);
+    };
+    bf16x8 aux[PF];
+    if (HAS_AUX) {
+#pragma unroll
+        for (int q = 0; q < PF; ++q) aux[q] = *reinterpret_cast<const bf16x8*>(aux_addr(q));
+        __builtin_amdgcn_sched_barrier(0);               // keep the prefetch up here (the scheduler sinks loads)
+    }
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+        const int fi = sl >> 1, fp = sl & 1;
+#pragma unroll
+        for (int fj = 0; fj < 2; ++fj)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                f32x4 t;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = acc[fi][2 * fp + fj][4 * q4 + e] * p.alpha;
+                const int chunk = fj * 8 + 2 * q4 + hi;
+                *reinterpret_cast<f32x4*>(slab + row * 256 + ((chunk ^ (row & 15)) << 4)) = t;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int q = sl * 4 + ps;
+            const int r = ps * 8 + rr;
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(slab + r * 256 + ((ch ^ (r & 15)) << 4));
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(slab + r * 256 + (((ch + 1) ^ (r & 15)) << 4));
+            const int m = m_base + fi * 32 + r, n = n_base + fp * 64 + c0;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = x0[e] + bias_r[fp][0][e];
+                v[4 + e] = x1[e] + bias_r[fp][1][e];
+            }
+            const bool no_store = p.dbg & 8, no_math = p.dbg & 128;       // experiments only
+            if (EPI == MERLOT_EPI_GELU) {
+                if (p.aux_out && !no_store) {
+                    bf16x8 u8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) u8[e] = (bf16)v[e];
+                    *reinterpret_cast<bf16x8*>(p.aux_out + (int64_t)m * p.ld_aux_out + n) = u8;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = no_math ? v[e] : gelu_fast(v[e]);
+            } else if (EPI == MERLOT_EPI_DGELU) {
+                const bf16x8 u8 = aux[q % PF];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= no_math ? (float)u8[e] : gelu_grad_fast((float)u8[e]);
+            } else if (EPI == MERLOT_EPI_RESIDUAL) {
+                if (p.drop_thresh && !no_math) {
+                    bool keep[8];                        // interior tiles: N % 256 == 0, the index is even
+                    dropout_keep_n<8>(p.drop_seed, (uint64_t)m * (uint64_t)p.N + (uint64_t)n, p.drop_thresh, keep);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = keep[e] ? v[e] * p.drop_scale : 0.f;
+                }
+                const bf16x8 r8 = aux[q % PF];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
+            }
+            if (HAS_AUX && q + PF < 16) {
+                aux[q % PF] = *reinterpret_cast<const bf16x8*>(aux_addr(q + PF));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (no_store) {
+                if (v[0] == 12345.678f) *reinterpret_cast<float*>(p.C) = v[1];
+            } else if (OUT_F32) {
+                float* c = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n;
+                f32x4 o0, o1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o0[e] = v[e];
+                    o1[e] = v[4 + e];
+                }
+                *reinterpret_cast<f32x4*>(c) = o0;
+                *reinterpret_cast<f32x4*>(c + 4) = o1;
+            } else {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+                *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + n) = o;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 using RingP = ring::Cfg<4, 2, 2, 4, 32, 3>;          // 256x256, BK 32, 3 stages (96 KB) + 64 KB epilogue staging
 constexpr int PERSIST_LDS = RingP::RING_BYTES + 8 * 8192;
 
@@ -829,6 +955,198 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const GemmNTArgs p
 #pragma unroll
             for (int fp = 0; fp < C::FN / 2; ++fp)
                 slab_epilogue<EPI, OUT_F32>(p, acc[fi][2 * fp], acc[fi][2 * fp + 1], slab, m_base + fi * 32, n_base + fp * 64, lane);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Persistent NT kernel with DYNAMIC tile claims (production).  Same schedule as gemm_nt_persist_kernel while every
+// workgroup progresses evenly: XCD x hands out ITS band of tiles (round j, position i -> tile j*nwg + band_x + i) in
+// order, so co-resident workgroups still share B panels in their XCD's L2.  The difference: the k-th tile of a band
+// goes to whichever workgroup of that XCD asks k-th (one agent-scope atomic per tile, issued a whole tile ahead of
+// its use), not to a fixed owner.  A workgroup that starts late or runs slowly -- its CU is shared with an RCCL
+// all-reduce kernel of the overlapped gradient reduction, which also keeps a 160 KiB-LDS workgroup from becoming
+// resident there at all -- then simply takes fewer tiles instead of stretching the whole launch by a full tile round.
+// Counters live in a small pool of self-resetting slots (the last workgroup to leave zeroes its slot).
+// ------------------------------------------------------------------------------------------------
+constexpr int PERSIST_SLOTS = 1024;
+__device__ unsigned int g_persist_ctr[PERSIST_SLOTS * 16];   // [slot][0..7] claims per XCD, [slot][8] departures
+
+template <int EPI, bool OUT_F32>
+__global__ __launch_bounds__(512) void gemm_nt_persist_dyn_kernel(const GemmNTArgs p, const int ctr_slot) {
+    using C = RingP;
+    extern __shared__ __attribute__((aligned(1024))) char dsm[];
+    constexpr int BK = C::BK, S = C::STAGES;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntiles = p.ntm * p.ntn;
+    const int nk = p.K / BK;
+    const int nwg = gridDim.x;
+    const int xcd = blockIdx.x & 7;
+    const int n_x = (nwg >> 3) + (xcd < (nwg & 7) ? 1 : 0);          // workgroups in this XCD's band
+    const int slot = xcd_remap(blockIdx.x, nwg);
+    const int band0 = slot - ((int)blockIdx.x >> 3);                  // first tile of the band in round 0
+    unsigned int* ctr = g_persist_ctr + ctr_slot * 16;
+    volatile int* bcast = reinterpret_cast<volatile int*>(dsm + C::RING_BYTES);   // wave 0's idle epilogue slab
+    const bool fast_ok = !(p.dbg & 32) && !(p.N & 1) && ((p.ldc & 7) == 0) && ((p.ld_aux_in & 7) == 0) && ((p.ld_aux_out & 7) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) && ((reinterpret_cast<uintptr_t>(p.aux_in) & 15) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(p.aux_out) & 15) == 0) && ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0) &&
+                         !(OUT_F32 && p.accumulate) && !(EPI == MERLOT_EPI_GELU && !p.aux_out && false);
+
+    constexpr int CH = BK / 8;
+    const int prow = lane / CH, pch = lane % CH;
+    int a_rowoff[C::A_PIECES], b_rowoff[C::B_PIECES], a_chunk[C::A_PIECES], b_chunk[C::B_PIECES];
+#pragma unroll
+    for (int i = 0; i < C::A_PIECES; ++i) {
+        a_rowoff[i] = (wave * C::A_PIECES + i) * C::RP + prow;
+        a_chunk[i] = ((pch ^ (a_rowoff[i] >> 2)) & 3) * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < C::B_PIECES; ++i) {
+        b_rowoff[i] = (wave * C::B_PIECES + i) * C::RP + prow;
+        b_chunk[i] = ((pch ^ (b_rowoff[i] >> 2)) & 3) * 8;
+    }
+    const bf16* a_src[C::A_PIECES];
+    const bf16* b_src[C::B_PIECES];
+    auto set_tile = [&](int tile) {
+        const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
+#pragma unroll
+        for (int i = 0; i < C::A_PIECES; ++i)
+            a_src[i] = p.A + (int64_t)min(tm * C::BM + a_rowoff[i], p.M - 1) * p.lda + a_chunk[i];
+#pragma unroll
+        for (int i = 0; i < C::B_PIECES; ++i)
+            b_src[i] = p.B + (int64_t)min(tn * C::BN + b_rowoff[i], p.N - 1) * p.ldb + b_chunk[i];
+    };
+    // load stream: ld_step stages issued so far; it follows the claimed tiles one after the other
+    int ld_kt = 0, ld_step = 0, next_tile = ntiles;
+    bool stream_end = false;
+    auto stage_next = [&]() {
+        if (stream_end) return;
+        char* la = dsm + (ld_step % S) * C::STAGE_BYTES + wave * C::A_PIECES * 1024;
+        char* lb = dsm + (ld_step % S) * C::STAGE_BYTES + C::A_BYTES + wave * C::B_PIECES * 1024;
+        const int k0 = ld_kt * BK;
+#pragma unroll
+        for (int i = 0; i < C::A_PIECES; ++i)
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(a_src[i] + k0), LDS_PTR(la + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < C::B_PIECES; ++i)
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(b_src[i] + k0), LDS_PTR(lb + i * 1024), 16, 0, 0);
+        ++ld_step;
+        if (++ld_kt == nk) {                             // the stream moves on to the tile claimed at kt == 0
+            ld_kt = 0;
+            next_tile = __builtin_amdgcn_readfirstlane(*bcast);
+            if (next_tile < ntiles) set_tile(next_tile);
+            else stream_end = true;
+        }
+    };
+
+    const int wm = wave / C::WN, wn = wave % C::WN;
+    const int hi = lane >> 5;
+    int a_row[C::FM], b_row[C::FN];
+#pragma unroll
+    for (int f = 0; f < C::FM; ++f) a_row[f] = (wm * C::FM + f) * 32 + (lane & 31);
+#pragma unroll
+    for (int f = 0; f < C::FN; ++f) b_row[f] = (wn * C::FN + f) * 32 + (lane & 31);
+    char* slab = dsm + C::RING_BYTES + wave * 8192;
+
+    // thread 0 claims one tile AHEAD of the load stream: tile i+1 is claimed before tile i starts (here for i = 0,
+    // then at the top of tile i-1's epilogue), published through LDS after wave 0's slab is idle again, and read by
+    // every wave when the stream wraps from tile i to tile i+1 (at least one s_barrier later).
+    auto claim = [&]() -> int {
+        const unsigned int sq = (unsigned int)n_x + atomicAdd(ctr + xcd, 1u);          // position in the band's order
+        const unsigned int t2 = (sq / (unsigned int)n_x) * (unsigned int)nwg + (unsigned int)band0 + sq % (unsigned int)n_x;
+        return t2 < (unsigned int)ntiles ? (int)t2 : ntiles;
+    };
+    // De-phase the workgroups.  Every tile costs the same, so workgroups launched together reach their epilogues
+    // together: 256 CUs then store 32 MiB at once, the stores back up behind HBM and every CU idles, after which HBM
+    // idles while every CU computes -- measured as "epilogue time == write time, nothing overlapped".  Starting the
+    // 8 workgroups that share a position modulo 8 within their XCD an eighth of a tile apart spreads the stores over
+    // the whole tile period (dynamic claims make the late starters simply take fewer tiles).
+    if (!(p.dbg & 64)) {
+        const int phase = ((int)blockIdx.x >> 3) & 7;
+        if (phase) {
+            const long long t0 = __builtin_amdgcn_s_memtime();
+            const long long wait = (long long)phase * nk * 150;      // ~1/8 tile: a K-step takes ~1200 clocks
+            while ((long long)__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    bool claims_open = true;
+    if (tid == 0) {
+        const int c = claim();
+        claims_open = c < ntiles;
+        *bcast = c;
+    }
+    __syncthreads();
+    set_tile(slot);                                      // grid <= ntiles: the first tile is the static one
+#pragma unroll
+    for (int t = 0; t < S - 1; ++t) stage_next();
+
+    int g = 0;
+    for (int tile = slot; tile < ntiles; tile = next_tile) {
+        f32x16 acc[C::FM][C::FN];
+#pragma unroll
+        for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+            for (int j = 0; j < C::FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int kt = 0; kt < nk; ++kt, ++g) {
+            if (ld_step - g == S - 1) {
+                if ((p.dbg & 16) && kt < 2 && tile != slot)
+                    ring::wait_vmcnt<63>();              // experiments: do not wait for the previous epilogue's stores
+                else
+                    ring::wait_vmcnt<(S - 2) * C::LOADS>();
+            } else {
+                ring::wait_vmcnt<0>();
+            }
+            __builtin_amdgcn_s_barrier();
+            stage_next();
+            const char* la = dsm + (g % S) * C::STAGE_BYTES;
+            const char* lb = la + C::A_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                bf16x8 af[C::FM], bfr[C::FN];
+#pragma unroll
+                for (int f = 0; f < C::FM; ++f) af[f] = *reinterpret_cast<const bf16x8*>(la + ring::kc_off<BK>(a_row[f], 2 * kk + hi));
+#pragma unroll
+                for (int f = 0; f < C::FN; ++f) bfr[f] = *reinterpret_cast<const bf16x8*>(lb + ring::kc_off<BK>(b_row[f], 2 * kk + hi));
+#pragma unroll
+                for (int fi = 0; fi < C::FM; ++fi)
+#pragma unroll
+                    for (int fj = 0; fj < C::FN; ++fj)
+                        acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[fj], af[fi], acc[fi][fj], 0, 0, 0);
+            }
+        }
+        int claimed = ntiles;
+        if (tid == 0 && claims_open) claimed = claim();  // for the tile after next; the return is awaited below
+        const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
+        const int m_base = tm * C::BM + wm * C::FM * 32, n_base = tn * C::BN + wn * C::FN * 32;
+        if (!(p.dbg & 1)) {
+            const bool interior = fast_ok && (tm + 1) * C::BM <= p.M && (tn + 1) * C::BN <= p.N;
+            if (interior) {
+                fast_tile_epilogue<EPI, OUT_F32>(p, acc, slab, m_base, n_base, lane);
+            } else {
+#pragma unroll
+                for (int fi = 0; fi < C::FM; ++fi)
+#pragma unroll
+                    for (int fp = 0; fp < C::FN / 2; ++fp)
+                        slab_epilogue<EPI, OUT_F32>(p, acc[fi][2 * fp], acc[fi][2 * fp + 1], slab, m_base + fi * 32, n_base + fp * 64, lane);
+            }
+        }
+        if (tid == 0) {
+            claims_open = claimed < ntiles;
+            *bcast = claimed;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // published before the next s_barrier
+        }
+    }
+    // departure: the last workgroup out zeroes the slot for its next user (all claims precede all departures)
+    if (tid == 0) {
+        __threadfence();
+        if (atomicAdd(ctr + 8, 1u) == (unsigned int)nwg - 1u) {
+#pragma unroll
+            for (int x = 0; x < 8; ++x) atomicExch(ctr + x, 0u);
+            atomicExch(ctr + 8, 0u);
+        }
     }
 }
 
@@ -1056,9 +1374,31 @@ int launch_persist_one(GemmNTArgs& a, hipStream_t s) {
     return merlot_launch_status("merlot_gemm_bf16_nt(persistent)");
 }
 
-int launch_persist(GemmNTArgs& a, int epilogue, int out_f32, hipStream_t s) {
-#define PERSIST_CASE(E) \
-    case E: return out_f32 ? launch_persist_one<E, true>(a, s) : launch_persist_one<E, false>(a, s);
+template <int EPI, bool OUT_F32>
+int launch_persist_dyn_one(GemmNTArgs& a, hipStream_t s) {
+    auto kern = gemm_nt_persist_dyn_kernel<EPI, OUT_F32>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           PERSIST_LDS);
+        MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipFuncSetAttribute(LDS=%d) failed: %s", PERSIST_LDS, hipGetErrorString(e));
+        attr_set = true;
+    }
+    a.ntm = cdiv(a.M, RingP::BM);
+    a.ntn = cdiv(a.N, RingP::BN);
+    int grid = a.ntm * a.ntn;
+    if (grid > 256) grid = 256;
+    static std::atomic<unsigned int> seq{0};             // counter slots are handed out round-robin; a slot is free
+    const int slot = (int)(seq.fetch_add(1) % PERSIST_SLOTS);   // again long before 1024 later launches are issued
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), PERSIST_LDS, s, a, slot);
+    return merlot_launch_status("merlot_gemm_bf16_nt(persistent, dynamic)");
+}
+
+int launch_persist(GemmNTArgs& a, int epilogue, int out_f32, bool dyn, hipStream_t s) {
+#define PERSIST_CASE(E)                                                                                      \
+    case E:                                                                                                  \
+        if (dyn) return out_f32 ? launch_persist_dyn_one<E, true>(a, s) : launch_persist_dyn_one<E, false>(a, s); \
+        return out_f32 ? launch_persist_one<E, true>(a, s) : launch_persist_one<E, false>(a, s);
     switch (epilogue) {
         PERSIST_CASE(MERLOT_EPI_NONE)
         PERSIST_CASE(MERLOT_EPI_GELU)
@@ -1070,19 +1410,10 @@ int launch_persist(GemmNTArgs& a, int epilogue, int out_f32, hipStream_t s) {
     return MERLOT_ESHAPE;
 }
 
-using RingA = ring::Cfg<2, 2, 2, 2, 64, 3>;   // 128x128, BK 64, 3 stages,  96 KB, 4 waves
-using RingB = ring::Cfg<4, 2, 2, 2, 64, 3>;   // 256x128, BK 64, 3 stages, 144 KB, 8 waves
+// (configs 1,2,4-10,12,13 of the round-1 tile sweep -- profiles/r01_gemm_tile_sweep.txt -- lost everywhere and were
+// removed from the build; ids kept stable)
 using RingC = ring::Cfg<4, 2, 2, 4, 32, 4>;   // 256x256, BK 32, 4 stages, 128 KB, 8 waves
-using RingD = ring::Cfg<2, 2, 2, 2, 32, 4>;   // 128x128, BK 32, 4 stages,  64 KB, 4 waves (2 blocks/CU)
-using RingE = ring::Cfg<4, 2, 2, 4, 64, 2>;   // 256x256, BK 64, 2 stages, 128 KB
-using RingF = ring::Cfg<2, 4, 4, 2, 64, 2>;   // 256x256 (wave 128x64), BK 64, 2 stages
-using RingG = ring::Cfg<4, 2, 2, 4, 32, 3>;   // 256x256, BK 32, 3 stages, 96 KB
-using RingH = ring::Cfg<2, 2, 2, 2, 64, 2>;   // 128x128, BK 64, 2 stages, 64 KB (2 blocks/CU)
-using RingI = ring::Cfg<4, 2, 2, 2, 32, 3>;   // 256x128, BK 32, 3 stages, 72 KB (2 blocks/CU, 16 waves)
-using RingJ = ring::Cfg<4, 2, 2, 4, 32, 5>;   // 256x256, BK 32, 5 stages, 160 KB
 using RingK = ring::Cfg<2, 4, 2, 2, 32, 3>;   // 128x256, BK 32, 3 stages, 72 KB (2 blocks/CU)
-using RingL = ring::Cfg<2, 2, 4, 4, 32, 4>;   // 256x256 with FOUR waves of 128x128 (1 wave/SIMD, 256 acc regs)
-using RingM = ring::Cfg<2, 2, 4, 4, 64, 2>;   // same, BK 64, 2 stages
 
 int nt_config_override() {
     static int v = -2;
@@ -1109,23 +1440,17 @@ int gemm_nt_dispatch(GemmNTArgs& a, int epilogue, int out_f32, bool patch, hipSt
         // otherwise 128x256 tiles with two co-resident workgroups per CU (id 11) absorb the ragged tail better.
         const int64_t tiles = (int64_t)cdiv(a.M, 256) * cdiv(a.N, 256);
         const int64_t rounds = (tiles + 255) / 256;
-        cfg = (tiles * 100 >= rounds * 256 * 85) ? 20 : 11;
+        static const int persist_id = [] {
+            const char* e = getenv("MERLOT_NT_PERSIST_DYN");           // 1 = dynamic tile claims, 0 = static striding
+            return (e ? atoi(e) : 1) ? 21 : 20;
+        }();
+        cfg = (tiles * 100 >= rounds * 256 * 85) ? persist_id : 11;
     }
     switch (cfg) {
-        case 1: return launch_ring<RingA>(a, epilogue, out_f32, s);
-        case 2: return launch_ring<RingB>(a, epilogue, out_f32, s);
         case 3: return launch_ring<RingC>(a, epilogue, out_f32, s);
-        case 4: return launch_ring<RingD>(a, epilogue, out_f32, s);
-        case 5: return launch_ring<RingE>(a, epilogue, out_f32, s);
-        case 6: return launch_ring<RingF>(a, epilogue, out_f32, s);
-        case 7: return launch_ring<RingG>(a, epilogue, out_f32, s);
-        case 8: return launch_ring<RingH>(a, epilogue, out_f32, s);
-        case 9: return launch_ring<RingI>(a, epilogue, out_f32, s);
-        case 10: return launch_ring<RingJ>(a, epilogue, out_f32, s);
         case 11: return launch_ring<RingK>(a, epilogue, out_f32, s);
-        case 12: return launch_ring<RingL>(a, epilogue, out_f32, s);
-        case 13: return launch_ring<RingM>(a, epilogue, out_f32, s);
-        case 20: return launch_persist(a, epilogue, out_f32, s);
+        case 20: return launch_persist(a, epilogue, out_f32, false, s);
+        case 21: return launch_persist(a, epilogue, out_f32, a.K / RingP::BK >= 4, s);
         default: break;
     }
     a.ntm = cdiv(a.M, BM);

@@ -139,12 +139,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
             store4(dx + row * H + i * 256 + lane * 4, o);
             if (dcolsum) {
                 if (drop_thresh) {
+                    bool keep[4];                         // H % 4 == 0: the index of element 0 is even
+                    dropout_keep_n<4>(drop_seed, (uint64_t)row * H + (uint64_t)(i * 256 + lane * 4), drop_thresh, keep);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const uint64_t idx = (uint64_t)row * H + (uint64_t)(i * 256 + lane * 4 + e);
                         // the branch gradient is taken from the value as the next kernels will read it (bf16)
                         const float ob = sizeof(TDX) == 2 ? (float)(bf16)o[e] : o[e];
-                        o[e] = dropout_keep(drop_seed, idx, drop_thresh) ? ob * drop_scale : 0.f;
+                        o[e] = keep[e] ? ob * drop_scale : 0.f;
                     }
                     store4(dx_drop + row * H + i * 256 + lane * 4, o);
                 }

@@ -26,6 +26,20 @@ __global__ void probe_tr16_kernel(const bf16* __restrict__ tile, bf16* __restric
     const bf16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(lds + lane * 4));
     *reinterpret_cast<bf16x4*>(out + lane * 4) = r;
 }
+
+// Occupies `blocks` CUs' worth of LDS (each workgroup declares lds_bytes of dynamic LDS) for ~`cycles` shader clocks:
+// a stand-in for a communication kernel running beside the GEMMs (scripts/exp_persist_dyn.py).
+__global__ void probe_cu_hog_kernel(long long cycles, unsigned int* sink) {
+    extern __shared__ char hog_lds[];
+    hog_lds[threadIdx.x] = (char)threadIdx.x;
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    unsigned int acc = 0;
+    while ((long long)__builtin_amdgcn_s_memtime() - t0 < cycles) {
+        acc += hog_lds[(threadIdx.x + acc) & 63];
+        __builtin_amdgcn_s_sleep(32);
+    }
+    if (acc == 0xffffffffu) sink[0] = acc;
+}
 }  // namespace
 
 extern "C" int merlot_probe_mfma32(const void* a, const void* b, float* d, merlot_stream_t stream) {
@@ -37,4 +51,17 @@ extern "C" int merlot_probe_tr16(const void* tile, void* out, merlot_stream_t st
     MERLOT_CHECK(tile && out, MERLOT_ESHAPE, "merlot_probe_tr16: null operand");
     hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16*)tile, (bf16*)out);
     return merlot_launch_status("merlot_probe_tr16");
+}
+extern "C" int merlot_probe_cu_hog(int blocks, int lds_bytes, int64_t cycles, void* sink, merlot_stream_t stream) {
+    MERLOT_CHECK(blocks > 0 && lds_bytes >= 64 && lds_bytes <= 160 * 1024 && sink, MERLOT_ESHAPE, "merlot_probe_cu_hog: bad arguments");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(probe_cu_hog_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(probe_cu_hog_kernel, dim3(blocks), dim3(64), lds_bytes, (hipStream_t)stream, (long long)cycles,
+                       (unsigned int*)sink);
+    return merlot_launch_status("merlot_probe_cu_hog");
 }
