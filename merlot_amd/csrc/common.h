@@ -49,29 +49,51 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return cdf + x * pdf;
 }
 
-// GEMM-epilogue forms (bf16 outputs): Abramowitz-Stegun 7.1.26 for erf (|error| <= 1.5e-7 absolute, i.e. far below
-// the bf16 rounding of the result) on raw v_rcp / v_exp -- ~14 VALU instructions instead of ocml erff's two-branch
-// evaluation; the epilogue arithmetic of a K=768 GEMM was costing a third of its main loop
-// (profiles/r01_f_epilogue_decomposition.txt).  gelu'(u) re-uses the same exponential: exp(-z^2), z = |u|/sqrt(2).
-__device__ __forceinline__ float erf_abs_fast(float z, float& e) {          // z >= 0; returns erf(z), e = exp(-z*z)
-    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
-    float poly = __builtin_fmaf(1.061405429f, t, -1.453152027f);
-    poly = __builtin_fmaf(poly, t, 1.421413741f);
-    poly = __builtin_fmaf(poly, t, -0.284496736f);
-    poly = __builtin_fmaf(poly, t, 0.254829592f);
-    e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
-    return __builtin_fmaf(-poly * t, e, 1.0f);
+// GEMM-epilogue forms of GELU and GELU' (bf16 outputs).  A K=768 GEMM spends 96 matrix-pipe cycles per output element
+// and lane; erff() + the rest cost ~100 VALU cycles per element on top, and even an Abramowitz-Stegun erf still pays
+// 2 quarter-rate transcendentals (profiles/r01_f_epilogue_decomposition.txt).  Here, with a = min(|x|, 4.5),
+//   gelu(x)  = max(x, 0) - r(a),            r(a) = a * Phi(-a)            (smooth hump, -> 0)
+//   gelu'(x) = x >= 0 ? 1 - d(a) : d(a),    d(a) = Phi(-a) - a * phi(a)   (smooth, -> 0)
+// and r, d are degree-12 polynomials in t = a * 2/4.5 - 1 (Chebyshev fit, fp32 Horner): max abs error 2.5e-6 / 4.2e-6
+// (1.5e-5 / 7e-5 beyond |x| = 4.5) -- three orders below the bf16 rounding of the result -- no transcendental, and
+// evaluated two elements per instruction with v_pk_fma_f32.  Coefficients: scripts/fit_gelu_poly.py.
+__device__ constexpr float GELU_R[13] = {2.750501223e-02f, -1.331440359e-01f, 2.460481972e-01f, -1.450011879e-01f, -1.969143003e-01f, 4.218034446e-01f, -2.295046449e-01f, -1.455463320e-01f, 2.215920240e-01f, -9.922845289e-03f, -8.095980436e-02f, 1.182068978e-02f, 1.224126294e-02f};
+__device__ constexpr float GELU_D[13] = {-5.918708444e-02f, 2.187175453e-01f, -1.923305541e-01f, -3.502573371e-01f, 9.239494205e-01f, -6.108126044e-01f, -3.885312378e-01f, 7.847974896e-01f, -1.774333119e-01f, -3.563932776e-01f, 1.924710423e-01f, 6.391551346e-02f, -4.897490889e-02f};
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_poly_pk(f32x2 a, const float (&c)[13]) {
+    const f32x2 lim = {4.5f, 4.5f}, sc = {2.0f / 4.5f, 2.0f / 4.5f}, m1 = {-1.0f, -1.0f};
+    a = __builtin_elementwise_min(a, lim);
+    const f32x2 t = __builtin_elementwise_fma(a, sc, m1);
+    f32x2 acc = {c[12], c[12]};
+#pragma unroll
+    for (int k = 11; k >= 0; --k) {
+        const f32x2 ck = {c[k], c[k]};
+        acc = __builtin_elementwise_fma(acc, t, ck);
+    }
+    return acc;
+}
+// in-place on 2 elements
+__device__ __forceinline__ void gelu_fast2(float& x0, float& x1) {
+    const f32x2 a = {__builtin_fabsf(x0), __builtin_fabsf(x1)};
+    const f32x2 r = gelu_poly_pk(a, GELU_R);
+    x0 = __builtin_fmaxf(x0, 0.f) - r[0];
+    x1 = __builtin_fmaxf(x1, 0.f) - r[1];
+}
+__device__ __forceinline__ void gelu_grad_fast2(float u0, float u1, float& g0, float& g1) {
+    const f32x2 a = {__builtin_fabsf(u0), __builtin_fabsf(u1)};
+    const f32x2 d = gelu_poly_pk(a, GELU_D);
+    g0 = u0 >= 0.f ? 1.0f - d[0] : d[0];
+    g1 = u1 >= 0.f ? 1.0f - d[1] : d[1];
 }
 __device__ __forceinline__ float gelu_fast(float x) {
-    float e;
-    const float er = erf_abs_fast(__builtin_fabsf(x) * 0.70710678118654752440f, e);
-    return x * __builtin_fmaf(0.5f, __builtin_copysignf(er, x), 0.5f);
+    float y0 = x, y1 = x;
+    gelu_fast2(y0, y1);
+    return y0;
 }
 __device__ __forceinline__ float gelu_grad_fast(float x) {
-    float e;
-    const float er = erf_abs_fast(__builtin_fabsf(x) * 0.70710678118654752440f, e);
-    const float cdf = __builtin_fmaf(0.5f, __builtin_copysignf(er, x), 0.5f);
-    return __builtin_fmaf(x * 0.39894228040143267794f, e, cdf);
+    float g0, g1;
+    gelu_grad_fast2(x, x, g0, g1);
+    return g0;
 }
 
 // counter-based dropout keep decision (site seed + linear element index): ONE 32-bit hash per PAIR of elements, its

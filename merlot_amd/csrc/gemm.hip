@@ -442,11 +442,16 @@ __device__ __forceinline__ void epilogue_row8(const GemmNTArgs& p, int m, int n,
             *reinterpret_cast<bf16x8*>(p.aux_out + (int64_t)m * p.ld_aux_out + n) = u8;
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+        for (int e = 0; e < 8; e += 2) gelu_fast2(v[e], v[e + 1]);
     } else if (EPI == MERLOT_EPI_DGELU) {
         const bf16x8 u8 = *reinterpret_cast<const bf16x8*>(p.aux_in + (int64_t)m * p.ld_aux_in + n);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_fast((float)u8[e]);
+        for (int e = 0; e < 8; e += 2) {
+            float g0, g1;
+            gelu_grad_fast2((float)u8[e], (float)u8[e + 1], g0, g1);
+            v[e] *= g0;
+            v[e + 1] *= g1;
+        }
     } else if (EPI == MERLOT_EPI_RESIDUAL) {
         if (p.drop_thresh) {
             bool keep[8];
@@ -568,6 +573,11 @@ __global__ __launch_bounds__(C::NT) void gemm_nt_ring_kernel(const GemmNTArgs p)
     const int tile_m = wgid / p.ntn;
     const int tile_n = wgid - tile_m * p.ntn;
     const int m0 = tile_m * C::BM, n0 = tile_n * C::BN;
+    if ((p.dbg & 256) && ((blockIdx.x >> 8) & 1) && blockIdx.x < 512) {   // experiment: de-phase the 2 WGs of a CU
+        const long long t0 = __builtin_amdgcn_s_memtime();
+        const long long wait = (long long)(p.K / BK) * 1100;
+        while ((long long)__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
 
     // ---- per-lane LDS-DMA sources
     constexpr int CH = BK / 8;                       // 16-B chunks per row
@@ -794,12 +804,19 @@ __device__ __forceinline__ void fast_tile_epilogue(const GemmNTArgs& p, f32x16 (
                     for (int e = 0; e < 8; ++e) u8[e] = (bf16)v[e];
                     *reinterpret_cast<bf16x8*>(p.aux_out + (int64_t)m * p.ld_aux_out + n) = u8;
                 }
+                if (!no_math) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = no_math ? v[e] : gelu_fast(v[e]);
+                    for (int e = 0; e < 8; e += 2) gelu_fast2(v[e], v[e + 1]);
+                }
             } else if (EPI == MERLOT_EPI_DGELU) {
                 const bf16x8 u8 = aux[q % PF];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= no_math ? (float)u8[e] : gelu_grad_fast((float)u8[e]);
+                for (int e = 0; e < 8; e += 2) {
+                    float g0 = (float)u8[e], g1 = (float)u8[e + 1];
+                    if (!no_math) gelu_grad_fast2((float)u8[e], (float)u8[e + 1], g0, g1);
+                    v[e] *= g0;
+                    v[e + 1] *= g1;
+                }
             } else if (EPI == MERLOT_EPI_RESIDUAL) {
                 if (p.drop_thresh && !no_math) {
                     bool keep[8];                        // interior tiles: N % 256 == 0, the index is even

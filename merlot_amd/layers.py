@@ -136,15 +136,35 @@ def transformer_stack(h, stack, B, S, valid, opts):
     return TransformerStackFn.apply(h, stack, B, S, valid, opts)
 
 
+def split_bf16(x):
+    """fp32 -> (hi, lo) bf16 with hi + lo == x to ~2^-17 relative: lets the bf16 MFMA GEMMs carry fp32 activations
+    of the small heads (the reference keeps contrastive / temporal / lm-head activations fp32, SURVEY 8 dtype policy)."""
+    hi = ops.cast_bf16(x)
+    lo = ops.cast_bf16((x - hi.float()).contiguous())
+    return hi, lo
+
+
 class LinearFn(torch.autograd.Function):
     """y = act(x @ W^T + b) for the small heads.  x: [T, in] f32 or bf16 -> y f32 (heads are kept fp32 outside
-    the MFMA contraction, model/modeling.py:184).  act in {None, 'gelu'}."""
+    the MFMA contraction, model/modeling.py:184).  act in {None, 'gelu'}.
+
+    fp32 inputs take the two-term path: activations and their gradients enter the bf16 MFMA GEMMs as hi + lo pairs
+    (x_hi W + x_lo W, fp32 accumulation across the launches), weights as their bf16 working copy -- the reference's
+    own policy (fp32 head activations, bf16-cast variables).  The heads are a few hundred rows: the extra launches
+    are noise in the step, while single-term bf16 made gradients that cancel heavily (everything behind
+    l2-normalise at temperature 0.05) lose a digit."""
 
     @staticmethod
     def forward(ctx, x, lin, act):
-        xb = x if x.dtype == BF16 else ops.cast_bf16(x.contiguous())
-        y = ops.gemm_nt(xb, lin.wb, bias=lin.b, out_dtype=F32)
-        ctx.lin, ctx.act, ctx.xb, ctx.x_dtype = lin, act, xb, x.dtype
+        two = x.dtype == F32
+        if two:
+            xb, xlo = split_bf16(x.contiguous())
+            y = ops.gemm_nt(xb, lin.wb, bias=lin.b, out_dtype=F32)
+            ops.gemm_nt(xlo, lin.wb, out=y, accumulate=True)
+        else:
+            xb, xlo = x, None
+            y = ops.gemm_nt(xb, lin.wb, bias=lin.b, out_dtype=F32)
+        ctx.lin, ctx.act, ctx.xb, ctx.xlo, ctx.x_dtype = lin, act, xb, xlo, x.dtype
         if act == 'gelu':
             ctx.pre = y
             y = ops.gelu_fwd(y)
@@ -156,26 +176,42 @@ class LinearFn(torch.autograd.Function):
         dy = dy.contiguous()
         if ctx.act == 'gelu':
             dy = ops.gelu_bwd(dy, ctx.pre)
-        dyb = ops.cast_bf16(dy)
+        two = ctx.xlo is not None
+        if two:
+            dyb, dylo = split_bf16(dy)
+        else:
+            dyb, dylo = ops.cast_bf16(dy), None
         if lin.gb is not None:
             ops.colsum_bf16(dyb, lin.gb)
+            if two:
+                ops.colsum_bf16(dylo, lin.gb)
         out_dim = lin.w.shape[0]
-        if out_dim % 2 == 0:
-            ops.gemm_tn(dyb, ctx.xb, lin.gw)
-        else:
+        if out_dim % 2 != 0:
             raise ValueError("LinearFn: odd output width unsupported")
+        ops.gemm_tn(dyb, ctx.xb, lin.gw)
+        if two:
+            ops.gemm_tn(dylo, ctx.xb, lin.gw)
+            ops.gemm_tn(dyb, ctx.xlo, lin.gw)
         dx = None
         if ctx.needs_input_grad[0]:
+            out_dt = F32 if ctx.x_dtype == F32 else BF16
             # K of the dgrad = out_dim must be a multiple of 64; the 4-wide temporal logits pad through wbT rows
             if out_dim % 64 == 0:
-                dx = ops.gemm_nt(dyb, lin.wbT, out_dtype=F32 if ctx.x_dtype == F32 else BF16)
+                dx = ops.gemm_nt(dyb, lin.wbT, out_dtype=out_dt)
+                if two:
+                    ops.gemm_nt(dylo, lin.wbT, out=dx, accumulate=True)
             else:
                 kp = (out_dim + 63) // 64 * 64
-                dyp = torch.zeros((dyb.shape[0], kp), device=dyb.device, dtype=BF16)
-                dyp[:, :out_dim] = dyb
                 wp = torch.zeros((lin.wbT.shape[0], kp), device=dyb.device, dtype=BF16)
                 wp[:, :out_dim] = lin.wbT
-                dx = ops.gemm_nt(dyp, wp, out_dtype=F32 if ctx.x_dtype == F32 else BF16)
+                dx = None
+                for part in ((dyb, dylo) if two else (dyb,)):
+                    dyp = torch.zeros((part.shape[0], kp), device=part.device, dtype=BF16)
+                    dyp[:, :out_dim] = part
+                    if dx is None:
+                        dx = ops.gemm_nt(dyp, wp, out_dtype=out_dt)
+                    else:
+                        ops.gemm_nt(dyp, wp, out=dx, accumulate=True)
         return dx, None, None
 
 

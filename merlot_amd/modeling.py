@@ -493,31 +493,47 @@ class MerlotModel(object):
 
 
 class _ContrastiveLogitsFn(torch.autograd.Function):
-    """All-pairs logits x @ y^T * inv_temp (model/modeling.py:521) as one MFMA GEMM with the scale fused."""
+    """All-pairs logits x @ y^T * inv_temp (model/modeling.py:521) on the MFMA GEMM with the scale fused.  The
+    embeddings and the logit gradients are fp32 in the reference; they enter the bf16 GEMMs as hi + lo pairs (three
+    of the four cross terms, the lo*lo one is below fp32 resolution), fp32 accumulation across launches."""
 
     @staticmethod
     def forward(ctx, x, y, inv_temp):
-        xb, yb = ops.cast_bf16(x.contiguous()), ops.cast_bf16(y.contiguous())
-        ctx.xb, ctx.yb, ctx.inv_temp = xb, yb, inv_temp
+        from .layers import split_bf16
+        xh, xl = split_bf16(x.contiguous())
+        yh, yl = split_bf16(y.contiguous())
+        ctx.x, ctx.y, ctx.inv_temp = (xh, xl), (yh, yl), inv_temp
         npad = (y.shape[0] + 3) // 4 * 4
         out = torch.empty((x.shape[0], npad), device=x.device, dtype=F32)
-        ops.gemm_nt(xb, yb, out=out, alpha=inv_temp, n=y.shape[0])
+        ops.gemm_nt(xh, yh, out=out, alpha=inv_temp, n=y.shape[0])
+        ops.gemm_nt(xl, yh, out=out, alpha=inv_temp, n=y.shape[0], accumulate=True)
+        ops.gemm_nt(xh, yl, out=out, alpha=inv_temp, n=y.shape[0], accumulate=True)
         return out[:, :y.shape[0]] if npad != y.shape[0] else out
 
     @staticmethod
     def backward(ctx, dlog):
-        xb, yb = ctx.xb, ctx.yb
-        n_x, n_y = xb.shape[0], yb.shape[0]
+        from .layers import split_bf16
+        (xh, xl), (yh, yl) = ctx.x, ctx.y
+        n_x, n_y = xh.shape[0], yh.shape[0]
         kp = (n_y + 63) // 64 * 64
-        d = torch.zeros((n_x, kp), device=dlog.device, dtype=BF16)
-        d[:, :n_y] = dlog
+        dh, dl = split_bf16(dlog.contiguous())
+
+        def pad_cols(t):
+            o = torch.zeros((t.shape[0], kp), device=t.device, dtype=BF16)
+            o[:, :n_y] = t
+            return o
+        dh, dl = pad_cols(dh), pad_cols(dl)
         # dx[n_x, C] = dlog @ y : reduction over n_y -> NT with Bt = y^T (padded)
-        ytp = torch.zeros((yb.shape[1], kp), device=dlog.device, dtype=BF16)
-        ytp[:, :n_y] = yb.t()
-        dx = ops.gemm_nt(d, ytp, out_dtype=F32, alpha=ctx.inv_temp)
+        yth, ytl = pad_cols(yh.t()), pad_cols(yl.t())
+        dx = ops.gemm_nt(dh, yth, out_dtype=F32, alpha=ctx.inv_temp)
+        ops.gemm_nt(dl, yth, out=dx, alpha=ctx.inv_temp, accumulate=True)
+        ops.gemm_nt(dh, ytl, out=dx, alpha=ctx.inv_temp, accumulate=True)
         # dy[n_y, C] = dlog^T @ x : reduction over n_x
-        dy = torch.zeros((n_y + (n_y % 2), xb.shape[1]), device=dlog.device, dtype=F32)
-        ops.gemm_tn(d, xb, dy, accumulate=False, alpha=ctx.inv_temp, m=n_y + (n_y % 2))
+        m = n_y + (n_y % 2)
+        dy = torch.zeros((m, xh.shape[1]), device=dlog.device, dtype=F32)
+        ops.gemm_tn(dh, xh, dy, accumulate=False, alpha=ctx.inv_temp, m=m)
+        ops.gemm_tn(dl, xh, dy, accumulate=True, alpha=ctx.inv_temp, m=m)
+        ops.gemm_tn(dh, xl, dy, accumulate=True, alpha=ctx.inv_temp, m=m)
         return dx, dy[:n_y], None
 
 
