@@ -207,6 +207,8 @@ int merlot_probe_mfma32(const void* a, const void* b, float* d, merlot_stream_t 
 int merlot_probe_tr16(const void* tile, void* out, merlot_stream_t stream);
 /* experiment helper: `blocks` one-wave workgroups that each hold lds_bytes of LDS and spin for ~cycles shader clocks
  * (a stand-in for a communication kernel sharing the GPU with the GEMMs); sink = any 4-byte device buffer. */
+/* experiment helper: copy the persistent GEMM's per-workgroup timeline (recorded when MERLOT_DBG has bit 512) */
+int merlot_probe_persist_trace(void* dst, int64_t bytes, merlot_stream_t stream);
 int merlot_probe_cu_hog(int blocks, int lds_bytes, int64_t cycles, void* sink, merlot_stream_t stream);
 
 #ifdef __cplusplus

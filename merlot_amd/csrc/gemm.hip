@@ -573,11 +573,6 @@ __global__ __launch_bounds__(C::NT) void gemm_nt_ring_kernel(const GemmNTArgs p)
     const int tile_m = wgid / p.ntn;
     const int tile_n = wgid - tile_m * p.ntn;
     const int m0 = tile_m * C::BM, n0 = tile_n * C::BN;
-    if ((p.dbg & 256) && ((blockIdx.x >> 8) & 1) && blockIdx.x < 512) {   // experiment: de-phase the 2 WGs of a CU
-        const long long t0 = __builtin_amdgcn_s_memtime();
-        const long long wait = (long long)(p.K / BK) * 1100;
-        while ((long long)__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
-    }
 
     // ---- per-lane LDS-DMA sources
     constexpr int CH = BK / 8;                       // 16-B chunks per row
@@ -986,6 +981,9 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const GemmNTArgs p
 // Counters live in a small pool of self-resetting slots (the last workgroup to leave zeroes its slot).
 // ------------------------------------------------------------------------------------------------
 constexpr int PERSIST_SLOTS = 1024;
+// experiments (dbg & 512): per-workgroup timeline, [wg][tile-slot][0..2] = s_memtime at tile start / loop end / epilogue end
+constexpr int TRACE_TILES = 32;
+__device__ long long g_persist_trace[256 * TRACE_TILES * 4];
 __device__ unsigned int g_persist_ctr[PERSIST_SLOTS * 16];   // [slot][0..7] claims per XCD, [slot][8] departures
 
 template <int EPI, bool OUT_F32>
@@ -1099,7 +1097,12 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_dyn_kernel(const GemmNTAr
     for (int t = 0; t < S - 1; ++t) stage_next();
 
     int g = 0;
+    int trace_i = 0;
     for (int tile = slot; tile < ntiles; tile = next_tile) {
+        if ((p.dbg & 512) && tid == 0 && trace_i < TRACE_TILES) {
+            g_persist_trace[(blockIdx.x * TRACE_TILES + trace_i) * 4 + 0] = __builtin_amdgcn_s_memtime();
+            g_persist_trace[(blockIdx.x * TRACE_TILES + trace_i) * 4 + 3] = tile;
+        }
         f32x16 acc[C::FM][C::FN];
 #pragma unroll
         for (int i = 0; i < C::FM; ++i)
@@ -1134,6 +1137,8 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_dyn_kernel(const GemmNTAr
                         acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[fj], af[fi], acc[fi][fj], 0, 0, 0);
             }
         }
+        if ((p.dbg & 512) && tid == 0 && trace_i < TRACE_TILES)
+            g_persist_trace[(blockIdx.x * TRACE_TILES + trace_i) * 4 + 1] = __builtin_amdgcn_s_memtime();
         int claimed = ntiles;
         if (tid == 0 && claims_open) claimed = claim();  // for the tile after next; the return is awaited below
         const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
@@ -1154,7 +1159,10 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_dyn_kernel(const GemmNTAr
             claims_open = claimed < ntiles;
             *bcast = claimed;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // published before the next s_barrier
+            if ((p.dbg & 512) && trace_i < TRACE_TILES)
+                g_persist_trace[(blockIdx.x * TRACE_TILES + trace_i) * 4 + 2] = __builtin_amdgcn_s_memtime();
         }
+        ++trace_i;
     }
     // departure: the last workgroup out zeroes the slot for its next user (all claims precede all departures)
     if (tid == 0) {
@@ -1411,10 +1419,10 @@ int launch_persist_dyn_one(GemmNTArgs& a, hipStream_t s) {
     return merlot_launch_status("merlot_gemm_bf16_nt(persistent, dynamic)");
 }
 
-int launch_persist(GemmNTArgs& a, int epilogue, int out_f32, bool dyn, hipStream_t s) {
+int launch_persist(GemmNTArgs& a, int epilogue, int out_f32, int kind, hipStream_t s) {   // 0 static, 1 dynamic claims
 #define PERSIST_CASE(E)                                                                                      \
     case E:                                                                                                  \
-        if (dyn) return out_f32 ? launch_persist_dyn_one<E, true>(a, s) : launch_persist_dyn_one<E, false>(a, s); \
+        if (kind == 1) return out_f32 ? launch_persist_dyn_one<E, true>(a, s) : launch_persist_dyn_one<E, false>(a, s); \
         return out_f32 ? launch_persist_one<E, true>(a, s) : launch_persist_one<E, false>(a, s);
     switch (epilogue) {
         PERSIST_CASE(MERLOT_EPI_NONE)
@@ -1458,16 +1466,16 @@ int gemm_nt_dispatch(GemmNTArgs& a, int epilogue, int out_f32, bool patch, hipSt
         const int64_t tiles = (int64_t)cdiv(a.M, 256) * cdiv(a.N, 256);
         const int64_t rounds = (tiles + 255) / 256;
         static const int persist_id = [] {
-            const char* e = getenv("MERLOT_NT_PERSIST_DYN");           // 1 = dynamic tile claims, 0 = static striding
-            return (e ? atoi(e) : 1) ? 21 : 20;
+            const char* e = getenv("MERLOT_NT_PERSIST_ID");            // 20 static striding / 21 dynamic claims
+            return e ? atoi(e) : 21;
         }();
         cfg = (tiles * 100 >= rounds * 256 * 85) ? persist_id : 11;
     }
     switch (cfg) {
         case 3: return launch_ring<RingC>(a, epilogue, out_f32, s);
         case 11: return launch_ring<RingK>(a, epilogue, out_f32, s);
-        case 20: return launch_persist(a, epilogue, out_f32, false, s);
-        case 21: return launch_persist(a, epilogue, out_f32, a.K / RingP::BK >= 4, s);
+        case 20: return launch_persist(a, epilogue, out_f32, 0, s);
+        case 21: return launch_persist(a, epilogue, out_f32, a.K / RingP::BK >= 4 ? 1 : 0, s);
         default: break;
     }
     a.ntm = cdiv(a.M, BM);
@@ -1683,4 +1691,13 @@ extern "C" int merlot_patch_embed_wgrad(const void* image, int n_img, int H, int
     a.M = hidden; a.N = P * P * 3; a.R = n_img * (H / P) * (W / P); a.alpha = 1.f;
     a.pg = PatchGeom{H, W, P, H / P, W / P};
     return gemm_tn_dispatch(a, accumulate, true, nullptr, 0, (hipStream_t)stream);
+}
+
+extern "C" int merlot_probe_persist_trace(void* dst, int64_t bytes, merlot_stream_t stream) {
+    MERLOT_CHECK(dst && bytes > 0 && bytes <= (int64_t)sizeof(long long) * 256 * TRACE_TILES * 4, MERLOT_ESHAPE,
+                 "merlot_probe_persist_trace: bad size");
+    hipError_t e = hipMemcpyFromSymbolAsync(dst, HIP_SYMBOL(g_persist_trace), (size_t)bytes, 0, hipMemcpyDeviceToDevice,
+                                            (hipStream_t)stream);
+    MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipMemcpyFromSymbolAsync: %s", hipGetErrorString(e));
+    return MERLOT_OK;
 }
