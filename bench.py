@@ -91,15 +91,15 @@ def cpu_baseline():
 
 
 def measured_traffic():
-    """HBM-side bytes per launch of the representative dominant launch (fc1 forward, M=50688 N=3072 K=768), from the
-    TCC counters collected in separate rocprofv3 --pmc passes (profiles/r01_c_traffic.txt, scripts/gpu_traffic.sh):
+    """HBM-side bytes per launch of the representative dominant launch (M=101376 N=3072 K=768, bias epilogue), from the
+    TCC counters collected in separate rocprofv3 --pmc passes (profiles/r01_f_traffic.txt, scripts/gpu_traffic.sh):
     2 * FETCH_SIZE (gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE, in bytes.  None if the file is absent."""
-    path = os.path.join(ROOT, 'profiles', 'r01_c_traffic.txt')
+    path = os.path.join(ROOT, 'profiles', 'r01_f_traffic.txt')
     if not os.path.exists(path):
         return None
     fetch = write = None
     for line in open(path):
-        if 'gemm_nt_ring_kernel<ring::Cfg<4, 2, 2, 4, 32, 4>' in line:
+        if 'gemm_nt_persist_dyn_kernel<0, false>' in line:
             kb = float(line.split()[-2])
             if line.startswith('FETCH_SIZE'):
                 fetch = kb
@@ -107,9 +107,9 @@ def measured_traffic():
                 write = kb
     if fetch is None or write is None:
         return None
-    return {'bytes_per_launch': (2.0 * fetch + write) * 1024.0, 'algorithmic_bytes_per_launch': 394.0e6,
-            'launch': 'fc1 forward M=50688 N=3072 K=768 (gemm_nt_ring_kernel<Cfg<4,2,2,4,32,4>,0>)',
-            'source': 'profiles/r01_c_traffic.txt'}
+    return {'bytes_per_launch': (2.0 * fetch + write) * 1024.0, 'algorithmic_bytes_per_launch': 783.3e6,
+            'launch': 'QKV-shaped forward M=101376 N=3072 K=768, plain epilogue (gemm_nt_persist_dyn_kernel<0,false>)',
+            'source': 'profiles/r01_f_traffic.txt'}
 
 
 def main():
@@ -171,10 +171,19 @@ def main():
     elapsed = time.perf_counter() - t0
     ops.TIMER = None
     loss = float(out['loss'].detach())
+    # forward-only figure, measured AFTER the timed region with the same bracket; not part of `value`
+    fwd_steps = max(2, min(args.steps, 4))
+    trainer.forward_only(batch)
+    sync()
+    t1 = time.perf_counter()
+    for _ in range(fwd_steps):
+        trainer.forward_only(batch)
+    sync()
+    fwd_elapsed = time.perf_counter() - t1
     if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed, fwd_elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, fwd_elapsed = float(t[0].item()), float(t[1].item())
 
     if rank == 0:
         value = world * seg_per_gpu * args.steps / elapsed
@@ -188,12 +197,16 @@ def main():
                        'num_chunks': config.data['num_chunks'], 'parallelism': f'dp{world}', 'grad_reduce': 'sum',
                        'final_loss': loss},
             'model_flops_utilization': value * TRAIN_GFLOP_PER_SEGMENT / 1e3 / (world * PEAK_BF16_TFLOPS),
+            'forward_only': {'value': world * seg_per_gpu * fwd_steps / fwd_elapsed, 'unit': 'segments/s',
+                             'ms_per_pass': 1e3 * fwd_elapsed / fwd_steps, 'passes': fwd_steps,
+                             'model_flops_utilization': world * seg_per_gpu * fwd_steps / fwd_elapsed *
+                             (TRAIN_GFLOP_PER_SEGMENT / 3.0) / 1e3 / (world * PEAK_BF16_TFLOPS)},
         }
         if timer is not None:
             summ = timer.summary()
             f, t, n = summ.get('gemm_nt', (0.0, 1.0, 0))
             res['roofline'] = {'bound': 'mfma',
-                               'kernel': 'merlot_gemm_bf16_nt = gemm_nt_persist_kernel<EPI,OUT> + gemm_nt_ring_kernel<Cfg,EPI,OUT> '
+                               'kernel': 'merlot_gemm_bf16_nt = gemm_nt_persist_dyn_kernel<EPI,OUT> + gemm_nt_ring_kernel<Cfg<2,4,2,2,32,3>,EPI,OUT> '
                                          '(bf16 MFMA 32x32x16, all epilogues; the dominant kernel family of the step)',
                                'achieved': f / t / 1e12, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                                'frac': f / t / 1e12 / PEAK_BF16_TFLOPS, 'traffic': measured_traffic(), 'launches': n,

@@ -56,6 +56,12 @@ class Trainer(object):
                                        expected_passes={'encoder': 2, 'encoder/LayerNorm_ln_final': 2, '*': 1})
         self.step_idx = 0
 
+    def forward_only(self, features):
+        """one forward pass (ViT, text-only, masking, joint, the three losses) with the training graph's ops but no
+        tape: the `fwd-only` figure SURVEY.md 8(d) asks for next to the training step."""
+        with torch.no_grad():
+            return self.model_fn(features, None, 'train', {'store': self.store, 'dist': self.dist, 'seed': self.step_idx + 1})
+
     def step(self, features):
         self.store.zero_grad()
         out = self.model_fn(features, None, 'train', {'store': self.store, 'dist': self.dist, 'seed': self.step_idx + 1})
