@@ -167,8 +167,12 @@ class MerlotOracle(object):
     """
 
     def __init__(self, config, weights, image, input_ids, mask_input=False, shuffled_idx_img=None,
-                 log_attention_probs=True, noise=None):
+                 log_attention_probs=True, noise=None, attention_summs=None):
+        """attention_summs (optional, [B, L] fp32): use THESE per-key attention sums for the top-k step of mask_inputs
+        instead of the oracle's own -- lets a test hold the integer masking logic to bit-exactness when the other
+        implementation's sums differ in the last bf16 digits (a near-tie then legitimately flips the top-k set)."""
         self.config = dict(config)
+        self._summs_override = attention_summs
         self.w = weights
         cfg = self.config
         input_ids = torch.as_tensor(input_ids).long()
@@ -301,6 +305,8 @@ class MerlotOracle(object):
         """model/modeling.py:381-489 via index_oracle.mask_inputs (integer, explicit noise)."""
         ids2d = self.input_ids.reshape(self.B, self.L).numpy().astype(np.int32)
         summ = self.attention_summs().detach().numpy() if self.config.get('masking_use_attn', True) else None
+        if summ is not None and self._summs_override is not None:
+            summ = np.asarray(self._summs_override, dtype=np.float32).reshape(summ.shape)
         masked_ids, masked_idx = ix.mask_inputs(ids2d, summ, self.config, self.vocab_size, noise)
         return {'masked_ids': torch.from_numpy(masked_ids).long().reshape(self.input_ids.shape),
                 'masked_idx': torch.from_numpy(masked_idx).long()}

@@ -221,6 +221,7 @@ def main():
     print('wrote ref_shim_config1.npz, ref_shim_optimizer.npz')
     make_dp2(cfg, weights, optimizer_cfg)
     make_sort_story()
+    make_inference_2d()
 
 
 def make_dp2(cfg, weights, optimizer_cfg):
@@ -351,6 +352,40 @@ def make_sort_story():
                         batch_seed=np.int64(5), lang_viz_probs=npy(pred['lang_viz_probs']),
                         viz_viz_probs=npy(pred['viz_viz_probs']))
     print('wrote ref_shim_sort_story.npz')
+
+
+def make_inference_2d():
+    """The constructor's other branches, as the downstream callers use it (downstream/vcr/modeling.py:48 style):
+    2-D input_ids (=> num_chunks = 1, model/modeling.py:72-77), is_training=False, mask_input=False,
+    shuffled_idx_img=None (=> un-shuffled image position embeddings, :312-315), ragged captions incl. an all-padding
+    row except START and a full 32-token row."""
+    cfg = tiny_config(use_bfloat16=False)
+    weights = mo.init_weights(cfg, seed=4, perturb=True)
+    g = torch.Generator().manual_seed(17)
+    bs = 3
+    image = torch.rand(bs, 64, 64, 3, generator=g).to(torch.bfloat16).float()
+    ids = torch.zeros(bs, 32, dtype=torch.long)
+    ids[:, 0] = 2
+    ids[0, 1:32] = torch.randint(100, 50354, (31,), generator=g)       # no padding at all
+    ids[2, 1:9] = torch.randint(100, 50354, (8,), generator=g)         # row 1 stays START + padding
+    tf_shim.STATE.reset(seed=5, injected={k: npy(v) for k, v in weights.items()})
+    m = ref_modeling.MerlotModel(config=cfg, is_training=False, use_tpu=False, image=tf_shim._w(image.clone()),
+                                 input_ids=tf_shim._w(ids.to(torch.int32)), mask_input=False, shuffled_idx_img=None)
+    assert not tf_shim.STATE.draws_of(0)
+    with torch.no_grad():
+        o = mo.MerlotOracle(cfg, weights, image, ids, mask_input=False, shuffled_idx_img=None)
+    print('2-D ids / inference / un-shuffled, restatement vs shim-executed reference:')
+    for k in ('viz', 'lang'):
+        err = float(np.abs(npy(o.encoder_hidden_states[k]) - npy(m.encoder_hidden_states[k])).max())
+        print(f'  encoder_hidden_states[{k}] max-abs-err {err:.3e}  shape {tuple(npy(m.encoder_hidden_states[k]).shape)}')
+        assert err < 2e-5
+    assert (m.B, m.L, m.P, m.num_chunks) == (o.B, o.L, o.P, 1)
+    np.savez_compressed(os.path.join(OUT, 'ref_shim_inference2d.npz'), image=npy(image), input_ids=npy(ids).astype(np.int32),
+                        weights_seed=np.int64(4), encoder_viz=npy(m.encoder_hidden_states['viz']),
+                        encoder_lang=npy(m.encoder_hidden_states['lang']),
+                        attention_log=np.array([float(npy(v)) for _, v in sorted(m.attention_log.items())]),
+                        attention_log_keys=np.array(sorted(m.attention_log)))
+    print('wrote ref_shim_inference2d.npz')
 
 
 if __name__ == '__main__':

@@ -1,0 +1,90 @@
+"""GPU: shapes and inputs at the edges of the path against the CPU oracle -- BASELINE config #5 geometry (384^2 frames,
+16-segment groups: Sv = 578, P = 2320, L = 512, joint S = 2832), batches whose token counts are not multiples of any
+tile size, captions with no padding / only padding, and a group whose tokens are nearly all special (masking has to
+fall back on special positions).  Tolerances as in test_model_gpu.py."""
+import numpy as np
+import pytest
+import torch
+
+from common import tiny_config, synth_batch, rel_l2
+from oracle import merlot_oracle as mo
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(cfg, b, mask_input=True, grads=False):
+    from merlot_amd import MerlotModel, ParamStore
+    w = mo.init_weights(cfg, 0)
+    for t in w.values():
+        t.requires_grad_(grads)
+    ctx = torch.enable_grad() if grads else torch.no_grad()
+    with ctx:
+        st = ParamStore(cfg, 'cuda', seed=0)
+        st.load_tf_weights({k: v.detach() for k, v in w.items()})
+        pm = MerlotModel(cfg, True, False, b['image'].cuda(), b['input_ids'].cuda(), mask_input=mask_input,
+                         shuffled_idx_img=torch.from_numpy(b['shuffled_idx_img']).cuda(), params=st,
+                         noise={k: torch.from_numpy(v) for k, v in b['noise'].items()})
+        # the oracle ranks keys by the HIP path's attention sums (checked to be close to its own below): the integer
+        # masking outputs are then comparable bit for bit even where two keys are within bf16 noise of each other
+        summs = pm.lang_transformer_info['attention_summs'].reshape(pm.B, pm.L).float().cpu().numpy() if mask_input else None
+        m = mo.MerlotOracle(cfg, w, b['image'], b['input_ids'], mask_input=mask_input,
+                            shuffled_idx_img=b['shuffled_idx_img'], noise=b['noise'], attention_summs=summs)
+        if mask_input:
+            assert rel_l2(torch.from_numpy(summs), m.attention_summs()) < 1e-2
+    return w, m, st, pm
+
+
+def test_config5_geometry_384px_16_segments():
+    cfg = tiny_config(image_size=[384, 384], num_chunks_in_group=16, max_position_embeddings=1024)
+    b = synth_batch(cfg, E=1, num_chunks=16, seed=3)
+    w, m, st, pm = _both(cfg, b)
+    assert (pm.P, pm.L, pm.viz_chunk_length) == (2320, 512, 145)
+    assert np.array_equal(pm.lang_mask_info['masked_idx'].cpu().numpy(), m.lang_mask_info['masked_idx'].numpy())
+    assert np.array_equal(pm.lang_mask_info['masked_ids'].cpu().numpy(), m.lang_mask_info['masked_ids'].numpy())
+    for k in ('viz', 'lang'):
+        assert rel_l2(pm.encoder_hidden_states[k], m.encoder_hidden_states[k]) < 2e-2, k
+    with torch.no_grad():
+        l1, l2, l3 = pm.mask_loss()[0], pm.contrastive_loss()[0], pm.temporal_loss(
+            torch.from_numpy(b['shuffled_idx_img']).cuda(), torch.from_numpy(b['video_src_ids']).cuda())[0]
+        ref, _ = m.total_loss(b['shuffled_idx_img'], b['video_src_ids'])
+    assert abs(float(l1 + l2 + l3) - float(ref)) < 3e-2
+
+
+def test_ragged_batch_odd_sizes_forward_backward():
+    """3 examples x 4 chunks (12 frames: 216 ViT tokens, 3 x 148 joint tokens -- no multiple of 32/64/128/256), one
+    caption without padding, one that is START only."""
+    cfg = tiny_config()
+    b = synth_batch(cfg, E=3, num_chunks=4, seed=7)
+    ids = b['input_ids']
+    ids[0, 0, 1:] = torch.randint(100, 50354, (31,), generator=torch.Generator().manual_seed(1))
+    ids[1, 2, 1:] = 0
+    w, m, st, pm = _both(cfg, b, grads=True)
+    loss, info = m.total_loss(b['shuffled_idx_img'], b['video_src_ids'])
+    loss.backward()
+    assert np.array_equal(pm.lang_mask_info['masked_ids'].cpu().numpy(), m.lang_mask_info['masked_ids'].numpy())
+    for k in ('viz', 'lang'):
+        assert rel_l2(pm.encoder_hidden_states[k], m.encoder_hidden_states[k]) < 2e-2, k
+    st.zero_grad()
+    l = pm.mask_loss()[0] + pm.contrastive_loss()[0] + pm.temporal_loss(
+        torch.from_numpy(b['shuffled_idx_img']).cuda(), torch.from_numpy(b['video_src_ids']).cuda())[0]
+    assert abs(float(l) - float(loss)) < 2e-2
+    l.backward()
+    torch.cuda.synchronize()
+    gt = st.export_tf_grads()
+    rels = [rel_l2(gt[k], v.grad) for k, v in w.items() if v.grad is not None and not k.endswith('key_layer/bias')]
+    assert np.median(rels) < 3e-2 and max(rels) < 0.2
+
+
+def test_group_of_special_tokens_only():
+    """every token id < 100 (special): log-mask is -1e8 everywhere, the Gumbel draw alone decides; integer outputs must
+    still agree bit for bit, and nothing may be NaN."""
+    cfg = tiny_config()
+    b = synth_batch(cfg, E=2, num_chunks=4, seed=9)
+    b['input_ids'][0] = torch.randint(2, 100, b['input_ids'][0].shape, generator=torch.Generator().manual_seed(2))
+    w, m, st, pm = _both(cfg, b)
+    assert np.array_equal(pm.lang_mask_info['masked_idx'].cpu().numpy(), m.lang_mask_info['masked_idx'].numpy())
+    assert np.array_equal(pm.lang_mask_info['masked_ids'].cpu().numpy(), m.lang_mask_info['masked_ids'].numpy())
+    with torch.no_grad():
+        l = pm.mask_loss()[0]
+    assert torch.isfinite(l)
+    assert rel_l2(pm.encoder_hidden_states['lang'], m.encoder_hidden_states['lang']) < 2e-2

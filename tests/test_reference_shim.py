@@ -143,6 +143,22 @@ def test_restatement_matches_reference_sort_story_model_fn():
         assert float(np.abs(o[k].numpy() - fx[k]).max()) < 1e-5
 
 
+def test_restatement_matches_reference_inference_2d_ids():
+    """2-D input_ids (num_chunks = 1), is_training=False, mask_input=False, shuffled_idx_img=None, a caption with no
+    padding and one that is START + padding only (fully padded query rows attend uniformly, -1e10 mask)."""
+    fx = _load('ref_shim_inference2d.npz')
+    cfg = tiny_config(use_bfloat16=False)
+    w = mo.init_weights(cfg, seed=int(fx['weights_seed']), perturb=True)
+    with torch.no_grad():
+        o = mo.MerlotOracle(cfg, w, torch.from_numpy(fx['image']), torch.from_numpy(fx['input_ids']).long(),
+                            mask_input=False, shuffled_idx_img=None)
+    assert (o.B, o.L, o.P, o.num_chunks) == (3, 32, 5, 1)
+    assert float(np.abs(o.encoder_hidden_states['viz'].numpy() - fx['encoder_viz']).max()) < 2e-5
+    assert float(np.abs(o.encoder_hidden_states['lang'].numpy() - fx['encoder_lang']).max()) < 2e-5
+    for k, v in zip(fx['attention_log_keys'], fx['attention_log']):
+        assert abs(float(o.attention_log[str(k)]) - float(v)) < 1e-6
+
+
 def test_optimizer_restatement_matches_reference_adam():
     """utils/optimization.py AdamOptimizer.apply_gradients (bias correction, bf16 m, sign-encoded v, decoupled decay
     except LayerNorm/bias) + the warm-up/decay scale, two consecutive steps."""
@@ -178,7 +194,8 @@ def test_live_reference_run_reproduces_committed_fixtures(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(GOLD, 'make_reference_golden.py')], env=env,
                        capture_output=True, text=True, timeout=850)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    for name in ('ref_shim_config1.npz', 'ref_shim_optimizer.npz', 'ref_shim_dp2.npz', 'ref_shim_sort_story.npz'):
+    for name in ('ref_shim_config1.npz', 'ref_shim_optimizer.npz', 'ref_shim_dp2.npz', 'ref_shim_sort_story.npz',
+                 'ref_shim_inference2d.npz'):
         new, old = np.load(os.path.join(str(tmp_path), name)), _load(name)
         assert sorted(new.files) == sorted(old.files)
         for k in old.files:

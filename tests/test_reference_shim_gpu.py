@@ -101,6 +101,28 @@ def test_hip_sort_story_matches_reference_model_fn():
                 assert ix.best_permutation(probs[s])[0] == ix.best_permutation(fx[f'{name}_probs'][s])[0]
 
 
+def test_hip_inference_2d_ids_matches_reference_program():
+    """2-D input_ids, is_training=False, no masking, shuffled_idx_img=None, ragged captions (one without padding, one that
+    is START + padding) -- the way the downstream callers construct MerlotModel."""
+    from merlot_amd import MerlotModel, ParamStore
+    fx = _load('ref_shim_inference2d.npz')
+    cfg = tiny_config()
+    w = mo.init_weights(cfg, seed=int(fx['weights_seed']), perturb=True)
+    with torch.no_grad():
+        st = ParamStore(cfg, 'cuda', seed=0)
+        st.load_tf_weights(w)
+        pm = MerlotModel(cfg, False, False, torch.from_numpy(fx['image']).cuda(),
+                         torch.from_numpy(fx['input_ids']).long().cuda(), mask_input=False, shuffled_idx_img=None,
+                         params=st)
+    assert (pm.B, pm.L, pm.P, pm.num_chunks) == (3, 32, 5, 1)
+    assert rel_l2(pm.encoder_hidden_states['viz'], torch.from_numpy(fx['encoder_viz'])) < 2e-2
+    # rows of the START+padding caption: compare on valid tokens (padded positions carry no contract downstream) and
+    # on everything (padded query rows attend uniformly in both programs)
+    assert rel_l2(pm.encoder_hidden_states['lang'], torch.from_numpy(fx['encoder_lang'])) < 2e-2
+    for k, v in zip(fx['attention_log_keys'], fx['attention_log']):
+        assert abs(float(pm.attention_log[str(k)]) - float(v)) < 2e-3, k
+
+
 def test_hip_adamw_matches_reference_optimizer():
     """merlot_adamw_step vs what utils/optimization.py's AdamOptimizer wrote (two consecutive steps, bf16 m,
     sign-encoded v, decay on kernels only)."""
