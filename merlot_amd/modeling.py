@@ -543,8 +543,13 @@ def model_fn_builder(config):
 
     def model_fn(features, labels=None, mode='train', params=None):
         store = params['store']
+        images = features['images']
+        if mode == 'train' and config.model.get('transpose_input', False):      # :683-685 (HWCN infeed layout)
+            images = images.permute(3, 0, 1, 2).contiguous()
+        elif mode != 'train':                                                   # :686-687
+            images = images.reshape([-1] + list(config.model['image_size']) + [3])
         model = MerlotModel(config=config.model, is_training=True,            # quirk kept: always True (:691-693)
-                            image=features['images'], input_ids=features['input_ids'],
+                            image=images, input_ids=features['input_ids'],
                             use_tpu=config.device.get('use_tpu', False),
                             shuffled_idx_img=features.get('shuffled_idx_img', None), mask_input=True,
                             params=store, noise=features.get('noise'), dist=params.get('dist'),

@@ -129,3 +129,28 @@ def test_mask_inputs_kernel_algorithm_vs_oracle(emu):
                                      c['num_to_mask'], c['w_nontopk'], c['w_topk'], c['log_nontopk'], c['log_topk'],
                                      c['max_weight'])
         assert np.array_equal(mids.numpy(), k[f'{tag}_masked_ids']) and np.array_equal(midx.numpy(), k[f'{tag}_masked_idx'])
+
+
+def test_model_fn_builder_mirrors_reference_model_fn(emu, oracle_run):
+    """model_fn (model/modeling.py:671-713): features dict in, summed loss + metric names out; `transpose_input`
+    (HWCN infeed layout, :683-685) and the non-training reshape (:686-687) handled as the reference does."""
+    from merlot_amd import ParamStore, model_fn_builder
+    from merlot_amd.config import NeatConfig
+    cfg, w, b, m, loss, info = oracle_run
+    outs = {}
+    for transposed in (False, True):
+        config = NeatConfig.from_dict({'model': dict(cfg, transpose_input=transposed),
+                                       'data': {'num_chunks': 4, 'chunk_text_len': 32},
+                                       'device': {'use_tpu': False, 'output_dir': '/tmp/unused'}, 'optimizer': {}})
+        st = ParamStore(cfg, 'cpu', seed=0)
+        st.load_tf_weights({k: v.detach() for k, v in w.items()})
+        images = b['image'].permute(1, 2, 3, 0).contiguous() if transposed else b['image']
+        features = {'images': images, 'input_ids': b['input_ids'], 'shuffled_idx_img': torch.from_numpy(b['shuffled_idx_img']),
+                    'video_src_ids': torch.from_numpy(b['video_src_ids']),
+                    'noise': {k: torch.from_numpy(v) for k, v in b['noise'].items()}}
+        outs[transposed] = model_fn_builder(config)(features, None, 'train', {'store': st})
+    for o in outs.values():
+        assert abs(float(o['loss']) - float(loss)) < 3e-2
+        assert {'lang/loss', 'lang/acc', 'contr/lang_to_viz', 'contr/viz_to_lang', 'contr/loss_all', 'temporal/loss',
+                'temporal/lang_viz_loss', 'temporal/viz_viz_acc', 'attn/encoder/viz2lang'} <= set(o['metrics'])
+    assert float(outs[True]['loss']) == float(outs[False]['loss'])
