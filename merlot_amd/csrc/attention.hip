@@ -556,7 +556,12 @@ __global__ __launch_bounds__(64) void attn_colsum_kernel(const AttnArgs p) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
         kf[kk] = *reinterpret_cast<const bf16x8*>(kbase + (int64_t)key * p.ld + kk * 16 + hi * 8);
+    // per element:  p = exp2(s * a_r + c_r) * (row valid ? m_k : 1)
+    //   a_r = valid query row ? scale*log2e : 0   (a padded query row scores 0 against every key: uniform 1/S)
+    //   c_r = -lse_r*log2e if the row counts (inside S, and valid unless padded rows count too), else -inf => p = 0
+    //   m_k = 1 for a valid key, 0 for a padded one (its probability under a valid query is exp2(-1e10...) = 0)
     const float sc = p.scale * LOG2E;
+    const float m_k = kv ? 1.f : 0.f;
     float acc_lo = 0.f, acc_hi = 0.f;
     const int nqb = (S + 31) / 32;
     for (int qb = 0; qb < nqb; ++qb) {
@@ -567,24 +572,30 @@ __global__ __launch_bounds__(64) void attn_colsum_kernel(const AttnArgs p) {
             const bf16x8 qfr = *reinterpret_cast<const bf16x8*>(base + (int64_t)qrow * p.ld + kk * 16 + hi * 8);
             st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr, kf[kk], st, 0, 0, 0);  // D[q][key]
         }
+        // this lane's query row of the block: validity and lse, handed to the 16 accumulator rows by lane shuffles
         const int ql = qb * 32 + (lane & 31);
         const bool q_in = ql < S;
-        const bool qvl = q_in && (vrow ? vrow[min(ql, S - 1)] != 0 : true);
-        const uint64_t qin_mask = __ballot(q_in && lane < 32) >> (4 * hi);
-        const uint64_t qv_mask = __ballot(qvl && lane < 32) >> (4 * hi);
+        const bool qvl = q_in && (vrow ? vrow[qrow] != 0 : true);
+        const bool counts = q_in && (p.valid_q_only ? qvl : true);
+        const float my_a = qvl ? sc : 0.f;
+        const float my_c = counts ? -lse_b[qrow] * LOG2E : -INFINITY;
+        const bool all_lo = (qb + 1) * 32 <= p.qsplit, all_hi = qb * 32 >= p.qsplit;
+        float part = 0.f, part_lo = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int bit = acc_row(r);
-            const int qi = qb * 32 + bit + 4 * hi;
-            const bool qin = (qin_mask >> bit) & 1;
-            const bool qvalid = (qv_mask >> bit) & 1;
-            const bool live = kv && qvalid;
-            const float t = qvalid ? (kv ? st[r] * sc : MASKED_T) : 0.f;
-            const float l2 = lse_b[min(qi, S - 1)] * LOG2E;
-            float pv = exp2f(t - l2);
-            const bool count = qin && (p.valid_q_only ? live : true);
-            pv = count ? pv : 0.f;
-            if (qi < p.qsplit) acc_lo += pv; else acc_hi += pv;
+            const int src = acc_row(r) + 4 * hi;         // lane (0..31) that owns this accumulator row's query
+            const float a_r = __shfl(my_a, src, 64);
+            const float c_r = __shfl(my_c, src, 64);
+            const float e = fast_exp2(fmaf(st[r], a_r, c_r));
+            const float pv = e * (a_r != 0.f ? m_k : 1.f);
+            part += pv;
+            if (!all_lo && !all_hi && qb * 32 + src < p.qsplit) part_lo += pv;
+        }
+        if (all_lo) acc_lo += part;
+        else if (all_hi) acc_hi += part;
+        else {
+            acc_lo += part_lo;
+            acc_hi += part - part_lo;
         }
     }
     acc_lo += __shfl_xor(acc_lo, 32, 64);
