@@ -14,6 +14,7 @@ Weights are a dict keyed by the reference's TF variable names, in TF layouts
 over this forward.
 """
 import math
+import re
 
 import numpy as np
 import torch
@@ -115,8 +116,118 @@ def transformer(hidden_state, mask, w, scope, num_layers, num_heads, return_attn
 # ----------------------------------------------------------------------------------------------
 # utils/vision_transformer.py
 # ----------------------------------------------------------------------------------------------
+# ResNet-hybrid stem (utils/vision_transformer.py:8-170, utils/model_utils.py:133-222): what merlot.yaml:30
+# (`resnet_layers: [3, 4, 9]`) and the released checkpoints use.  NHWC tensors as in the reference.
+# ----------------------------------------------------------------------------------------------
+def group_norm(x, w, scope, num_groups=32, eps=1e-4):
+    """utils/model_utils.py:133-222 with mean_close_to_zero=True: one-pass moments E[x^2] - E[x]^2 per (sample,
+    group) over (H, W, C/groups), then per-channel gamma / beta."""
+    N, Hh, Ww, C = x.shape
+    g = x.reshape(N, Hh, Ww, num_groups, C // num_groups)
+    cnt = Hh * Ww * (C // num_groups)
+    mean = g.sum((1, 2, 4), keepdim=True) / cnt                                   # :198-201
+    var = (g * g).sum((1, 2, 4), keepdim=True) / cnt - mean * mean
+    y = ((g - mean) * torch.rsqrt(var + eps)).reshape(N, Hh, Ww, C)               # :205
+    return y * w[scope + '/gamma'] + w[scope + '/beta']                           # :219
+
+
+def standardize_kernel(k):
+    """utils/vision_transformer.py:52-56: per output channel over (kh, kw, cin), population variance, eps 1e-5."""
+    mean = k.mean((0, 1, 2), keepdim=True)
+    var = ((k - mean) ** 2).mean((0, 1, 2), keepdim=True)
+    return (k - mean) * torch.rsqrt(var + 1e-5)
+
+
+def conv2d_fixed_padding(x, kernel, strides=1):
+    """utils/vision_transformer.py:31-63: weight-standardised conv, no bias; stride 1 -> SAME, stride > 1 -> explicit
+    (k-1)//2 low / rest high padding then VALID (fixed_padding, :8-19)."""
+    k = standardize_kernel(kernel)
+    ks = k.shape[0]
+    lo = (ks - 1) // 2
+    hi_ = ks - 1 - lo
+    xc = torch.nn.functional.pad(x.permute(0, 3, 1, 2), [lo, hi_, lo, hi_])      # SAME for odd k at stride 1 == this
+    out = torch.nn.functional.conv2d(xc, k.permute(3, 2, 0, 1), None, stride=strides)
+    return out.permute(0, 2, 3, 1)
+
+
+def _avg_pool(x, k):
+    return torch.nn.functional.avg_pool2d(x.permute(0, 3, 1, 2), k, k).permute(0, 2, 3, 1)
+
+
+def lite_resnet50(x, w, scope, layers, width=64):
+    """utils/vision_transformer.py:114-170 (+ bottleneck_block :66-93, block_group :96-111).  Variable names are the
+    ones tf.layers.Conv2D / variable_scope(default_name=...) generate: conv2d, conv2d_1, ... and GroupNorm,
+    GroupNorm_1, ... counted per enclosing scope in creation order."""
+    rs = f'{scope}/resnet50lite'
+    relu = torch.relu
+    x = relu(group_norm(conv2d_fixed_padding(x, w[f'{rs}/stem/conv2d/kernel'], 2), w, f'{rs}/stem/GroupNorm_stem0'))
+    x = relu(group_norm(conv2d_fixed_padding(x, w[f'{rs}/stem/conv2d_1/kernel']), w, f'{rs}/stem/GroupNorm_stem1'))
+    x = relu(group_norm(conv2d_fixed_padding(x, w[f'{rs}/stem/conv2d_2/kernel']), w, f'{rs}/stem/GroupNorm_stem2'))
+    c = _avg_pool(x, 2)                                                           # :158
+    for i, blocks in enumerate(layers):
+        gs = f'{rs}/block_group{i + 1}'
+        strides = 1 if i == 0 else 2
+        idx = [0, 0]                                                              # next conv2d / GroupNorm suffix
+
+        def nm(kind):
+            j = 0 if kind == 'conv2d' else 1
+            name = kind if idx[j] == 0 else f'{kind}_{idx[j]}'
+            idx[j] += 1
+            return f'{gs}/{name}'
+
+        for bi in range(blocks):
+            st = strides if bi == 0 else 1
+            shortcut = c
+            if bi == 0:                                                           # projection shortcut (:75-83)
+                sc_in = _avg_pool(c, st) if st > 1 else c
+                shortcut = group_norm(conv2d_fixed_padding(sc_in, w[nm('conv2d') + '/kernel']), w, nm('GroupNorm'))
+            h = relu(group_norm(conv2d_fixed_padding(c, w[nm('conv2d') + '/kernel']), w, nm('GroupNorm')))
+            h = relu(group_norm(conv2d_fixed_padding(h, w[nm('conv2d') + '/kernel']), w, nm('GroupNorm')))
+            if st > 1:
+                h = _avg_pool(h, st)                                              # :89-90
+            h = group_norm(conv2d_fixed_padding(h, w[nm('conv2d') + '/kernel']), w, nm('GroupNorm'))
+            c = relu(h + shortcut)                                                # :93
+    return c
+
+
+def resnet_variable_shapes(cfg, scope='vision_backbone/vision_transformer', width=64):
+    layers = cfg.get('resnet_layers', [])
+    rs = f'{scope}/resnet50lite'
+    shapes = {}
+
+    def gn(name, c):
+        shapes[name + '/gamma'] = (c,)
+        shapes[name + '/beta'] = (c,)
+    for j, (ci, co) in enumerate([(3, width // 2), (width // 2, width // 2), (width // 2, width)]):
+        shapes[f'{rs}/stem/conv2d' + (f'_{j}' if j else '') + '/kernel'] = (3, 3, ci, co)
+        gn(f'{rs}/stem/GroupNorm_stem{j}', co)
+    cin = width
+    for i, blocks in enumerate(layers):
+        f = width * (2 ** i)
+        gs = f'{rs}/block_group{i + 1}'
+        k = 0
+
+        def add(kh, ci, co):
+            nonlocal k
+            sfx = f'_{k}' if k else ''
+            shapes[f'{gs}/conv2d{sfx}/kernel'] = (kh, kh, ci, co)
+            gn(f'{gs}/GroupNorm{sfx}', co)
+            k += 1
+        for bi in range(blocks):
+            if bi == 0:
+                add(1, cin, 4 * f)
+            add(1, cin, f)
+            add(3, f, f)
+            add(1, f, 4 * f)
+            cin = 4 * f
+    shapes[f'{scope}/conv_postresnet_proj/kernel'] = (1, 1, cin, cfg['hidden_size'])
+    shapes[f'{scope}/conv_postresnet_proj/bias'] = (cfg['hidden_size'],)
+    return shapes
+
+
+# ----------------------------------------------------------------------------------------------
 def vision_transformer_backbone(image, w, cfg, scope='vision_backbone/vision_transformer'):
-    """utils/vision_transformer.py:173-274, patch-conv stem (resnet_layers == [])."""
+    """utils/vision_transformer.py:173-274: patch-conv stem (resnet_layers == []) or the ResNet hybrid (:206-223)."""
     P = cfg['patch_size']
     H = cfg['hidden_size']
     num_cls = cfg.get('num_cls_emb', 2)
@@ -124,10 +235,17 @@ def vision_transformer_backbone(image, w, cfg, scope='vision_backbone/vision_tra
     assert h0 % P == 0 and w0 % P == 0
     h1, w1 = h0 // P, w0 // P
     x = image - 0.5                                                               # :193
-    kern = w[f'{scope}/conv2d/kernel']                                            # HWIO [P, P, 3, H]
-    # 16x16 / stride 16 VALID conv == im2col (ph, pw, c) x [P*P*3, H]        :196-205
-    patches = x.reshape(N, h1, P, w1, P, 3).permute(0, 1, 3, 2, 4, 5).reshape(N, h1 * w1, P * P * 3)
-    x = patches @ kern.reshape(P * P * 3, H) + w[f'{scope}/conv2d/bias']
+    resnet_layers = cfg.get('resnet_layers', [])
+    if len(resnet_layers) == 0:
+        kern = w[f'{scope}/conv2d/kernel']                                        # HWIO [P, P, 3, H]
+        # 16x16 / stride 16 VALID conv == im2col (ph, pw, c) x [P*P*3, H]    :196-205
+        patches = x.reshape(N, h1, P, w1, P, 3).permute(0, 1, 3, 2, 4, 5).reshape(N, h1 * w1, P * P * 3)
+        x = patches @ kern.reshape(P * P * 3, H) + w[f'{scope}/conv2d/bias']
+    else:
+        assert P == 16                                                            # :208
+        c = lite_resnet50(x, w, scope, resnet_layers)                             # [N, h1, w1, 1024 (3 groups)]
+        pk = w[f'{scope}/conv_postresnet_proj/kernel']                            # 1x1 conv to hidden (:213-223)
+        x = c.reshape(N, h1 * w1, c.shape[-1]) @ pk.reshape(pk.shape[2], H) + w[f'{scope}/conv_postresnet_proj/bias']
     x = torch.cat([torch.zeros(N, num_cls, H, dtype=x.dtype), x], 1)             # :231
     pos = position_embedder2d(w, f'{scope}/pos_embs', h1, w1, num_cls)           # :232-233
     x = layer_norm(x + pos, w, f'{scope}/LayerNorm_ctx_patches_pre_ln')          # :234
@@ -459,8 +577,11 @@ def variable_shapes(cfg):
         ln(f'{scope}/LayerNorm_ln_final')
 
     vs = 'vision_backbone/vision_transformer'
-    shapes[f'{vs}/conv2d/kernel'] = (P, P, 3, H)
-    shapes[f'{vs}/conv2d/bias'] = (H,)
+    if len(cfg.get('resnet_layers', [])) == 0:
+        shapes[f'{vs}/conv2d/kernel'] = (P, P, 3, H)
+        shapes[f'{vs}/conv2d/bias'] = (H,)
+    else:
+        shapes.update(resnet_variable_shapes(cfg, vs))
     shapes[f'{vs}/pos_embs/pos_embs'] = (1, 64, 64, H)
     shapes[f'{vs}/pos_embs/cls_emb'] = (1, ncls, H)
     ln(f'{vs}/LayerNorm_ctx_patches_pre_ln')
@@ -503,7 +624,7 @@ def init_weights(cfg, seed=0, perturb=True):
             t = torch.ones(shp) + (0.1 * torch.randn(shp, generator=g) if perturb else 0)
         elif name.endswith('/beta') or name.endswith('/bias') or name.endswith('output_bias'):
             t = (0.02 * torch.randn(shp, generator=g)) if perturb else torch.zeros(shp)
-        elif name.endswith('conv2d/kernel'):
+        elif re.search(r'(conv2d(_\d+)?|conv_postresnet_proj)/kernel$', name):       # variance_scaling (fan_in)
             fan_in = shp[0] * shp[1] * shp[2]
             t = torch.randn(shp, generator=g).clamp(-2, 2) * math.sqrt(1.0 / fan_in)
         else:

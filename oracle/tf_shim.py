@@ -607,9 +607,73 @@ def tf_dropout(x, keep_prob=None, noise_shape=None, seed=None, name=None, rate=N
 
 
 def avg_pool2d(value, ksize, strides, padding, data_format='NHWC', name=None):
-    assert data_format == 'NHWC' and padding == 'VALID'
+    assert data_format == 'NHWC'
     x = _t(value).permute(0, 3, 1, 2)
+    if padding == 'SAME':       # TF averages over the valid elements only; with even sizes and k == s nothing is padded
+        assert int(x.shape[2]) % int(strides) == 0 and int(x.shape[3]) % int(strides) == 0 and ksize == strides
     return _w(F.avg_pool2d(x, kernel_size=ksize, stride=strides).permute(0, 2, 3, 1))
+
+
+def tf_pad(tensor, paddings, mode='CONSTANT', name=None, constant_values=0):
+    x = _t(tensor)
+    flat = []
+    for lo, hi_ in reversed([list(p) for p in paddings]):
+        flat += [int(lo), int(hi_)]
+    return _w(F.pad(x, flat, value=constant_values))
+
+
+def nn_conv2d(input=None, filter=None, strides=None, padding='SAME', data_format='NHWC', name=None, filters=None, **_):
+    """tf.nn.conv2d, NHWC x HWIO.  SAME = TF's rule: total pad = max((ceil(in/s)-1)*s + k - in, 0), extra on the high side."""
+    assert data_format == 'NHWC'
+    x, w = _t(input), _t(filter if filter is not None else filters)
+    sh, sw = (strides[1], strides[2]) if len(strides) == 4 else (strides[0], strides[-1])
+    kh, kw = int(w.shape[0]), int(w.shape[1])
+    xc = x.permute(0, 3, 1, 2)
+    if padding.upper() == 'SAME':
+        ih, iw = int(x.shape[1]), int(x.shape[2])
+        ph = max((-(-ih // sh) - 1) * sh + kh - ih, 0)
+        pw = max((-(-iw // sw) - 1) * sw + kw - iw, 0)
+        xc = F.pad(xc, [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2])
+    out = F.conv2d(xc, w.permute(3, 2, 0, 1), None, stride=(sh, sw))
+    return _w(out.permute(0, 2, 3, 1))
+
+
+class Conv2DLayer(object):
+    """tf.layers.Conv2D as utils/vision_transformer.py:39-50 uses it: construct, .build(shape), read .weights[0] and
+    .padding.  The layer's variable scope is `variable_scope(None, default_name='conv2d')` at build time."""
+    def __init__(self, filters, kernel_size, strides=1, padding='valid', data_format='channels_last', use_bias=True,
+                 kernel_initializer=None, name=None, **_):
+        self.filters, self.use_bias, self.kernel_initializer, self.name = int(filters), use_bias, kernel_initializer, name
+        self.kernel_size = (kernel_size, kernel_size) if isinstance(kernel_size, int) else tuple(kernel_size)
+        self.padding = padding
+        self.weights = []
+
+    def build(self, input_shape):
+        cin = int(input_shape[-1])
+        with variable_scope(self.name, default_name='conv2d'):
+            self.weights = [get_variable('kernel', [self.kernel_size[0], self.kernel_size[1], cin, self.filters],
+                                         initializer=self.kernel_initializer)]
+            if self.use_bias:
+                self.weights.append(get_variable('bias', [self.filters], initializer=zeros_initializer()))
+
+
+def sufficient_statistics(x, axes, shift=None, keep_dims=False, name=None, keepdims=None):
+    x = _t(x)
+    kd = bool(keep_dims if keepdims is None else keepdims)
+    ax = _axes(axes)
+    count = 1
+    for a in ax:
+        count *= int(x.shape[a])
+    m_ss = torch.sum(x, dim=ax, keepdim=kd)
+    v_ss = torch.sum(torch.square(x), dim=ax, keepdim=kd)
+    return _w(torch.tensor(float(count))), _w(m_ss), _w(v_ss), None
+
+
+def normalize_moments(counts, mean_ss, variance_ss, shift, name=None):
+    divisor = 1.0 / _t(counts)
+    mean = _t(mean_ss) * divisor
+    variance = _t(variance_ss) * divisor - torch.square(mean)
+    return _w(mean), _w(variance)
 
 
 def _activation(x, activation):
@@ -846,9 +910,11 @@ def build_modules():
     tf.random = _mod('tensorflow.random', uniform=random_uniform, categorical=random_categorical,
                      stateless_uniform=lambda shape, seed, **kw: random_uniform(shape, **kw))
     tf.nn = _mod('tensorflow.nn', softmax=softmax, log_softmax=log_softmax, moments=moments, dropout=tf_dropout,
-                 avg_pool2d=avg_pool2d, relu=relu, top_k=top_k, bias_add=bias_add, l2_loss=l2_loss,
+                 avg_pool2d=avg_pool2d, relu=relu, top_k=top_k, bias_add=bias_add, l2_loss=l2_loss, conv2d=nn_conv2d,
+                 sufficient_statistics=sufficient_statistics, normalize_moments=normalize_moments,
                  embedding_lookup=embedding_lookup, l2_normalize=l2_normalize)
-    tf.layers = _mod('tensorflow.layers', dense=dense, conv2d=conv2d_layer)
+    tf.layers = _mod('tensorflow.layers', dense=dense, conv2d=conv2d_layer, Conv2D=Conv2DLayer)
+    tf.pad = tf_pad
     # referenced only in default arguments of input-pipeline functions that are never called here
     tf.image = _mod('tensorflow.image', ResizeMethod=types.SimpleNamespace(BILINEAR=0, NEAREST_NEIGHBOR=1,
                                                                            BICUBIC=2, AREA=3))

@@ -222,6 +222,7 @@ def main():
     make_dp2(cfg, weights, optimizer_cfg)
     make_sort_story()
     make_inference_2d()
+    make_resnet_stem()
 
 
 def make_dp2(cfg, weights, optimizer_cfg):
@@ -386,6 +387,61 @@ def make_inference_2d():
                         attention_log=np.array([float(npy(v)) for _, v in sorted(m.attention_log.items())]),
                         attention_log_keys=np.array(sorted(m.attention_log)))
     print('wrote ref_shim_inference2d.npz')
+
+
+def make_resnet_stem():
+    """SURVEY 8(f) #2, the ResNet-hybrid stem (utils/vision_transformer.py:8-170, 206-223; utils/model_utils.py:133-222):
+    `lite_resnet50` alone and the whole `vision_transformer_backbone` with resnet_layers = [1, 1, 2] (projection
+    shortcuts, stride-2 groups, an identity-shortcut block), forward + gradients of every stem variable."""
+    from utils.vision_transformer import vision_transformer_backbone, lite_resnet50
+    cfg = tiny_config(use_bfloat16=False, resnet_layers=[1, 1, 2])
+    weights = mo.init_weights(cfg, seed=6, perturb=True)
+    g = torch.Generator().manual_seed(23)
+    image = torch.rand(2, 64, 64, 3, generator=g).to(torch.bfloat16).float()
+    cot = torch.randn(2, 18, 768, generator=g)
+    tf_shim.STATE.reset(seed=3, injected={k: npy(v) for k, v in weights.items()})
+    with tf.variable_scope('vision_backbone'):
+        info = vision_transformer_backbone(tf_shim._w(image.clone()), cfg)
+    created = [n for n in tf_shim.STATE.created_by_initializer]
+    assert not created, created
+    ref_vars = {n: v for n, v in tf_shim.STATE.vars.items()}
+    loss = (info['hidden_state'] * tf_shim._w(cot)).sum()
+    names = sorted(n for n in ref_vars if 'resnet50lite' in n or 'conv_postresnet_proj' in n)
+    grads = torch.autograd.grad(loss, [ref_vars[n] for n in names])
+    tf_shim.STATE.default_names = {}                     # second pass over the same scopes: same conv2d_k / GroupNorm_k
+    with tf.variable_scope('vision_backbone'):
+        with tf.variable_scope('vision_transformer'):
+            c_ref = lite_resnet50(tf_shim._w(image.clone()) - 0.5, use_bfloat16=False, num_resnet_layers=3,
+                                  layers=cfg['resnet_layers'], width=64)
+    for t in weights.values():
+        t.grad = None
+        t.requires_grad_(True)
+    o = mo.vision_transformer_backbone(image, weights, cfg)
+    (o['hidden_state'] * cot).sum().backward()
+    c_or = mo.lite_resnet50(image - 0.5, weights, 'vision_backbone/vision_transformer', cfg['resnet_layers'])
+    print('ResNet-hybrid stem, restatement vs shim-executed reference:')
+    e1 = float(np.abs(npy(c_or) - npy(c_ref)).max() / np.abs(npy(c_ref)).max())
+    e2 = float(np.abs(npy(o['hidden_state']) - npy(info['hidden_state'])).max())
+    print(f'  lite_resnet50 output {tuple(npy(c_ref).shape)} max-rel-err {e1:.3e}; ViT hidden_state max-abs-err {e2:.3e}')
+    assert e1 < 1e-5 and e2 < 2e-5
+    gerr = {n: float(np.abs(npy(weights[n].grad) - npy(gr)).max() / (np.abs(npy(gr)).max() + 1e-30)) for n, gr in zip(names, grads)}
+    worst = max(gerr, key=gerr.get)
+    print(f'  gradients of {len(names)} stem variables, worst {worst} {gerr[worst]:.3e}')
+    assert gerr[worst] < 1e-3
+    assert set(mo.resnet_variable_shapes(cfg)) == set(names)
+    fx = {'image': npy(image), 'cotangent': npy(cot), 'weights_seed': np.int64(6), 'resnet_c': npy(c_ref),
+          'hidden_state': npy(info['hidden_state']), 'variable_names': np.array(names),
+          'variable_shapes': np.array([str(list(ref_vars[n].size())) for n in names]),
+          'grad_norms': np.array([float(gr.double().norm()) for gr in grads])}
+    for n in ('vision_backbone/vision_transformer/resnet50lite/stem/conv2d/kernel',
+              'vision_backbone/vision_transformer/resnet50lite/stem/GroupNorm_stem1/gamma',
+              'vision_backbone/vision_transformer/resnet50lite/block_group2/conv2d_2/kernel',
+              'vision_backbone/vision_transformer/resnet50lite/block_group3/conv2d_5/kernel',
+              'vision_backbone/vision_transformer/resnet50lite/block_group3/GroupNorm_6/beta',
+              'vision_backbone/vision_transformer/conv_postresnet_proj/kernel'):
+        fx['grad/' + n] = head(npy(grads[names.index(n)]))
+    np.savez_compressed(os.path.join(OUT, 'ref_shim_resnet_stem.npz'), **fx)
+    print('wrote ref_shim_resnet_stem.npz')
 
 
 if __name__ == '__main__':

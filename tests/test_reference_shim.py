@@ -159,6 +159,30 @@ def test_restatement_matches_reference_inference_2d_ids():
         assert abs(float(o.attention_log[str(k)]) - float(v)) < 1e-6
 
 
+def test_restatement_matches_reference_resnet_hybrid_stem():
+    """lite_resnet50 (weight-standardised convs, GroupNorm(32, eps 1e-4, one-pass moments), ReLU, avg-pool
+    strides, projection / identity shortcuts) + conv_postresnet_proj + ViT, forward and gradients of all 56 stem
+    variables; variable names as the reference's scopes generate them."""
+    fx = _load('ref_shim_resnet_stem.npz')
+    cfg = tiny_config(use_bfloat16=False, resnet_layers=[1, 1, 2])
+    w = mo.init_weights(cfg, seed=int(fx['weights_seed']), perturb=True)
+    for t in w.values():
+        t.requires_grad_(True)
+    image = torch.from_numpy(fx['image'])
+    ref_names = {str(n): str(sh) for n, sh in zip(fx['variable_names'], fx['variable_shapes'])}
+    assert {n: str(list(sh)) for n, sh in mo.resnet_variable_shapes(cfg).items()} == ref_names
+    c = mo.lite_resnet50(image - 0.5, w, 'vision_backbone/vision_transformer', cfg['resnet_layers'])
+    assert _relmax(c.detach().numpy(), fx['resnet_c']) < 1e-5
+    o = mo.vision_transformer_backbone(image, w, cfg)
+    assert float(np.abs(o['hidden_state'].detach().numpy() - fx['hidden_state']).max()) < 2e-5
+    (o['hidden_state'] * torch.from_numpy(fx['cotangent'])).sum().backward()
+    for n, ref_norm in zip(fx['variable_names'], fx['grad_norms']):
+        assert abs(float(w[str(n)].grad.double().norm()) - ref_norm) <= 1e-4 * ref_norm + 1e-9, n
+    for k in fx.files:
+        if k.startswith('grad/'):
+            assert _relmax(head(w[k[5:]].grad.numpy()), fx[k]) < 1e-4, k
+
+
 def test_optimizer_restatement_matches_reference_adam():
     """utils/optimization.py AdamOptimizer.apply_gradients (bias correction, bf16 m, sign-encoded v, decoupled decay
     except LayerNorm/bias) + the warm-up/decay scale, two consecutive steps."""
@@ -195,7 +219,7 @@ def test_live_reference_run_reproduces_committed_fixtures(tmp_path):
                        capture_output=True, text=True, timeout=850)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     for name in ('ref_shim_config1.npz', 'ref_shim_optimizer.npz', 'ref_shim_dp2.npz', 'ref_shim_sort_story.npz',
-                 'ref_shim_inference2d.npz'):
+                 'ref_shim_inference2d.npz', 'ref_shim_resnet_stem.npz'):
         new, old = np.load(os.path.join(str(tmp_path), name)), _load(name)
         assert sorted(new.files) == sorted(old.files)
         for k in old.files:
