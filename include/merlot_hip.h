@@ -204,6 +204,33 @@ int merlot_adamw_step(float* param, const float* grad, void* m, void* v, int64_t
                       int state_bf16, merlot_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * ResNet-hybrid stem pieces: utils/vision_transformer.py:8-170 (conv2d_fixed_padding,
+ * bottleneck_block, lite_resnet50) and utils/model_utils.py:133-222 (group_norm).  Activations NHWC bf16, C % 8 == 0
+ * (C == 3 allowed for the first convolution's im2col).  The convolutions themselves run on merlot_gemm_bf16_nt /
+ * merlot_gemm_bf16_tn: 1x1 directly on [N*H*W, C], 3x3 on the im2col matrix.
+ * ---------------------------------------------------------------------------------------------- */
+/* out[(n,yo,xo)][(ky,kx,c)] = x[n][yo*s+ky-1][xo*s+kx-1][c] + shift (0 outside the image), row stride Kp >= 9*C,
+ * columns 9*C..Kp-1 zero.  Padding (1,1) = TF SAME at stride 1 = fixed_padding(3) + VALID at stride 2 (:8-19,43). */
+int merlot_im2col3x3(const void* x, void* out, int N, int H, int W, int C, int stride, int Kp, float shift,
+                     merlot_stream_t stream);
+/* input gradient of the same gather: dx[n][y][x][c] = sum over taps of dpatches[(n,yo,xo)][(ky,kx,c)]. */
+int merlot_col2im3x3(const void* dpatches, void* dx, int N, int H, int W, int C, int stride, int Kp,
+                     merlot_stream_t stream);
+/* y = [relu]( (x - mean) * rsqrt(var + eps) * gamma + beta [+ res] ), moments per (sample, group) over (H, W, C/G) from
+ * one pass (var = E[x^2] - E[x]^2, :196-201).  stats: f32 [N, G, 2] = {sum, sum of squares}, written here, kept for
+ * the backward.  res may be NULL. */
+int merlot_groupnorm_fwd(const void* x, const float* gamma, const float* beta, const void* res, void* y, float* stats,
+                         int N, int H, int W, int C, int G, float eps, int relu, merlot_stream_t stream);
+/* dy' = relu ? dy * (y > 0) : dy.  dgamma / dbeta (f32 [C]) are ACCUMULATED; gsum: f32 [N, G, 2] scratch; dx bf16;
+ * dres (optional) = dy' for the residual branch. */
+int merlot_groupnorm_bwd(const void* dy, const void* y, const void* x, const float* stats, const float* gamma,
+                         float* dgamma, float* dbeta, float* gsum, void* dx, void* dres, int N, int H, int W, int C,
+                         int G, float eps, int relu, merlot_stream_t stream);
+/* tf.nn.avg_pool2d(ksize 2, strides 2) on even H, W; the backward takes dy [N, H/2, W/2, C] and writes dx [N, H, W, C]. */
+int merlot_avgpool2_fwd(const void* x, void* y, int N, int H, int W, int C, merlot_stream_t stream);
+int merlot_avgpool2_bwd(const void* dy, void* dx, int N, int H, int W, int C, merlot_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Hardware-layout probes (diagnostics; used by tests to pin the MFMA / LDS-transpose lane maps the
  * kernels above assume).  out_* are small device buffers, see csrc/probe.hip.
  * ---------------------------------------------------------------------------------------------- */

@@ -1,0 +1,385 @@
+// HBM-bound pieces of the ResNet-hybrid stem (utils/vision_transformer.py:8-170,
+// utils/model_utils.py:133-222): 3x3 im2col / col2im around the MFMA GEMMs, GroupNorm(32) forward / backward with the
+// ReLU and the residual add of the bottleneck fused, 2x2 average pool.  Activations are NHWC bf16, C % 8 == 0 (C == 3
+// only for the very first convolution, scalar path).  One lane moves 16 B (8 channels).
+#include "common.h"
+
+namespace {
+
+inline int grid_for(int64_t work_items, int per_block, int cap = 65535) {
+    int64_t g = (work_items + per_block - 1) / per_block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ---- 3x3 im2col: out[(n,yo,xo)][(ky,kx,c)] = x[n][yo*s+ky-1][xo*s+kx-1][c] (0 outside), columns K..Kp-1 zero ----------
+// pad (1,1) is both TF's SAME at stride 1 and fixed_padding(kernel 3) + VALID at stride 2 (utils/vision_transformer.py:8-19,43)
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const bf16* __restrict__ x, bf16* __restrict__ out, int N, int H,
+                                                        int W, int C, int s, int Ho, int Wo, int Kp, float shift) {
+    const int cpr = Kp / 8;                               // 16-B chunks per output row (Kp % 8 == 0)
+    const int64_t total = (int64_t)N * Ho * Wo * cpr;
+    const int K = 9 * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / cpr;
+        const int k0 = (int)(i - row * cpr) * 8;
+        const int xo = (int)(row % Wo);
+        const int yo = (int)((row / Wo) % Ho);
+        const int n = (int)(row / ((int64_t)Wo * Ho));
+        bf16x8 v;
+        if ((C & 7) == 0 && k0 < K) {                     // one (ky,kx) tap, 8 consecutive channels
+            const int tap = k0 / C, c = k0 - tap * C;
+            const int y = yo * s + tap / 3 - 1, xx = xo * s + tap % 3 - 1;
+            if (y >= 0 && y < H && xx >= 0 && xx < W) {
+                v = *reinterpret_cast<const bf16x8*>(x + (((int64_t)n * H + y) * W + xx) * C + c);
+                if (shift != 0.f) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] + shift);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
+            }
+        } else {                                          // C == 3 (first convolution) or the zero padding columns
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = k0 + e;
+                float val = 0.f;
+                if (k < K) {
+                    const int tap = k / C, c = k - tap * C;
+                    const int y = yo * s + tap / 3 - 1, xx = xo * s + tap % 3 - 1;
+                    if (y >= 0 && y < H && xx >= 0 && xx < W) val = (float)x[(((int64_t)n * H + y) * W + xx) * C + c] + shift;
+                }
+                v[e] = (bf16)val;
+            }
+        }
+        *reinterpret_cast<bf16x8*>(out + row * Kp + k0) = v;
+    }
+}
+
+// ---- col2im (input gradient of the 3x3 convolution): dx[n][y][x][c] = sum over taps of dP[(n,yo,xo)][(ky,kx,c)] ----------
+__global__ __launch_bounds__(256) void col2im3x3_kernel(const bf16* __restrict__ dp, bf16* __restrict__ dx, int N, int H,
+                                                        int W, int C, int s, int Ho, int Wo, int Kp) {
+    const int cpr = C / 8;
+    const int64_t total = (int64_t)N * H * W * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = i / cpr;
+        const int c = (int)(i - pix * cpr) * 8;
+        const int xx = (int)(pix % W);
+        const int y = (int)((pix / W) % H);
+        const int n = (int)(pix / ((int64_t)W * H));
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int ty = y + 1 - ky;
+            if (ty < 0 || ty % s != 0 || ty / s >= Ho) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int tx = xx + 1 - kx;
+                if (tx < 0 || tx % s != 0 || tx / s >= Wo) continue;
+                const int64_t row = ((int64_t)n * Ho + ty / s) * Wo + tx / s;
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(dp + row * Kp + (ky * 3 + kx) * C + c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+            }
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)acc[e];
+        *reinterpret_cast<bf16x8*>(dx + pix * C + c) = o;
+    }
+}
+
+// ---- GroupNorm ----------------------------------------------------------------------------------------------------------
+// stats[n][g] = {sum x, sum x^2} over (H*W, C/G): the one-pass moments the reference asks for (mean_close_to_zero=True,
+// utils/model_utils.py:196-201).  A block owns one sample and one slice of its positions; a thread always touches the
+// same 8 channels, so it reduces in registers and the block folds channel chunks into groups through LDS.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16* __restrict__ x, float* __restrict__ stats, int HW, int C,
+                                                       int G, int pos_per_block) {
+    extern __shared__ float gred[];                        // [G][2]
+    const int n = blockIdx.x;
+    const int cpr = C / 8, cpg = C / G;
+    for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) gred[i] = 0.f;
+    __syncthreads();
+    const int p0 = blockIdx.y * pos_per_block, p1 = min(HW, p0 + pos_per_block);
+    const int chunk = threadIdx.x % cpr;                   // blockDim.x % cpr == 0 (host guarantees)
+    const int prow = threadIdx.x / cpr, pstep = blockDim.x / cpr;
+    float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (prow < pstep) {
+        for (int p = p0 + prow; p < p1; p += pstep) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + ((int64_t)n * HW + p) * C + chunk * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = (float)v[e];
+                s1[e] += f;
+                s2[e] += f * f;
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int g = (chunk * 8 + e) / cpg;
+        atomicAdd(&gred[2 * g], s1[e]);
+        atomicAdd(&gred[2 * g + 1], s2[e]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) atomicAdd(stats + (int64_t)n * 2 * G + i, gred[i]);
+}
+
+// y = [relu]( (x - mean) * rstd * gamma + beta [+ res] ), mean / var from the sums (var = E[x^2] - E[x]^2)
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16* __restrict__ x, const float* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const bf16* __restrict__ res, bf16* __restrict__ y, int64_t N, int HW,
+                                                       int C, int G, float eps, int relu) {
+    const int cpr = C / 8, cpg = C / G;
+    const float inv_cnt = 1.0f / ((float)HW * (float)cpg);
+    const int64_t total = N * HW * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cpr) * 8;
+        const int64_t n = i / ((int64_t)HW * cpr);
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + i * 8);
+        bf16x8 r8;
+        if (res) r8 = *reinterpret_cast<const bf16x8*>(res + i * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int g = (c + e) / cpg;
+            const float mean = stats[(n * G + g) * 2] * inv_cnt;
+            const float var = stats[(n * G + g) * 2 + 1] * inv_cnt - mean * mean;
+            float f = ((float)v[e] - mean) * rsqrtf(var + eps) * gamma[c + e] + beta[c + e];
+            if (res) f += (float)r8[e];
+            if (relu) f = fmaxf(f, 0.f);
+            o[e] = (bf16)f;
+        }
+        *reinterpret_cast<bf16x8*>(y + i * 8) = o;
+    }
+}
+
+// backward, pass 1: with dy' = relu ? dy * (y > 0) : dy and xhat = (x - mean) * rstd:
+//   dgamma[c] += sum dy' * xhat, dbeta[c] += sum dy'          (over samples and positions; atomics per block)
+//   gsum[n][g] = {sum_c gamma_c * dbeta_c(n), sum_c gamma_c * dgamma_c(n)}   (per sample)
+__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ y,
+                                                           const bf16* __restrict__ x, const float* __restrict__ stats,
+                                                           const float* __restrict__ gamma, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, float* __restrict__ gsum, int HW, int C,
+                                                           int G, float eps, int relu, int pos_per_block) {
+    extern __shared__ float sm[];                          // [C][2] per-channel partials of this block
+    const int n = blockIdx.x;
+    const int cpr = C / 8, cpg = C / G;
+    const float inv_cnt = 1.0f / ((float)HW * (float)cpg);
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) sm[i] = 0.f;
+    __syncthreads();
+    const int p0 = blockIdx.y * pos_per_block, p1 = min(HW, p0 + pos_per_block);
+    const int chunk = threadIdx.x % cpr;
+    const int prow = threadIdx.x / cpr, pstep = blockDim.x / cpr;
+    float mean[8], rstd[8], dg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, db[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int g = (chunk * 8 + e) / cpg;
+        mean[e] = stats[((int64_t)n * G + g) * 2] * inv_cnt;
+        rstd[e] = rsqrtf(stats[((int64_t)n * G + g) * 2 + 1] * inv_cnt - mean[e] * mean[e] + eps);
+    }
+    if (prow < pstep) {
+        for (int p = p0 + prow; p < p1; p += pstep) {
+            const int64_t off = ((int64_t)n * HW + p) * C + chunk * 8;
+            const bf16x8 d8 = *reinterpret_cast<const bf16x8*>(dy + off);
+            const bf16x8 x8 = *reinterpret_cast<const bf16x8*>(x + off);
+            bf16x8 y8;
+            if (relu) y8 = *reinterpret_cast<const bf16x8*>(y + off);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float d = (float)d8[e];
+                if (relu && !((float)y8[e] > 0.f)) d = 0.f;
+                dg[e] += d * ((float)x8[e] - mean[e]) * rstd[e];
+                db[e] += d;
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        atomicAdd(&sm[2 * (chunk * 8 + e)], dg[e]);
+        atomicAdd(&sm[2 * (chunk * 8 + e) + 1], db[e]);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float g_ = sm[2 * c], b_ = sm[2 * c + 1];
+        atomicAdd(dgamma + c, g_);
+        atomicAdd(dbeta + c, b_);
+        const int g = c / cpg;
+        atomicAdd(gsum + ((int64_t)n * G + g) * 2, gamma[c] * b_);
+        atomicAdd(gsum + ((int64_t)n * G + g) * 2 + 1, gamma[c] * g_);
+    }
+}
+
+// backward, pass 2: dx = rstd * (dy' * gamma - gsum0 / cnt - xhat * gsum1 / cnt); optionally dres = dy' (residual branch)
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ y,
+                                                           const bf16* __restrict__ x, const float* __restrict__ stats,
+                                                           const float* __restrict__ gsum, const float* __restrict__ gamma,
+                                                           bf16* __restrict__ dx, bf16* __restrict__ dres, int64_t N, int HW,
+                                                           int C, int G, float eps, int relu) {
+    const int cpr = C / 8, cpg = C / G;
+    const float inv_cnt = 1.0f / ((float)HW * (float)cpg);
+    const int64_t total = N * HW * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cpr) * 8;
+        const int64_t n = i / ((int64_t)HW * cpr);
+        const bf16x8 d8 = *reinterpret_cast<const bf16x8*>(dy + i * 8);
+        const bf16x8 x8 = *reinterpret_cast<const bf16x8*>(x + i * 8);
+        bf16x8 y8;
+        if (relu) y8 = *reinterpret_cast<const bf16x8*>(y + i * 8);
+        bf16x8 o, r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int g = (c + e) / cpg;
+            const float mean = stats[(n * G + g) * 2] * inv_cnt;
+            const float rstd = rsqrtf(stats[(n * G + g) * 2 + 1] * inv_cnt - mean * mean + eps);
+            float d = (float)d8[e];
+            if (relu && !((float)y8[e] > 0.f)) d = 0.f;
+            const float xhat = ((float)x8[e] - mean) * rstd;
+            o[e] = (bf16)(rstd * (d * gamma[c + e] - gsum[(n * G + g) * 2] * inv_cnt - xhat * gsum[(n * G + g) * 2 + 1] * inv_cnt));
+            r[e] = (bf16)d;
+        }
+        *reinterpret_cast<bf16x8*>(dx + i * 8) = o;
+        if (dres) *reinterpret_cast<bf16x8*>(dres + i * 8) = r;
+    }
+}
+
+// ---- 2x2 / stride 2 average pool (tf.nn.avg_pool2d, even H and W) --------------------------------------------------------
+__global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, int64_t N, int H,
+                                                           int W, int C) {
+    const int cpr = C / 8, Ho = H / 2, Wo = W / 2;
+    const int64_t total = N * Ho * Wo * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cpr) * 8;
+        const int64_t pix = i / cpr;
+        const int xo = (int)(pix % Wo), yo = (int)((pix / Wo) % Ho);
+        const int64_t n = pix / ((int64_t)Wo * Ho);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + ((n * H + 2 * yo + dy) * W + 2 * xo + dx) * C + c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+            }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)(0.25f * acc[e]);
+        *reinterpret_cast<bf16x8*>(y + i * 8) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const bf16* __restrict__ dy, bf16* __restrict__ dx, int64_t N, int H,
+                                                           int W, int C) {
+    const int cpr = C / 8, Ho = H / 2, Wo = W / 2;
+    const int64_t total = N * H * W * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cpr) * 8;
+        const int64_t pix = i / cpr;
+        const int xx = (int)(pix % W), y = (int)((pix / W) % H);
+        const int64_t n = pix / ((int64_t)W * H);
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(dy + ((n * Ho + y / 2) * Wo + xx / 2) * C + c);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)(0.25f * (float)v[e]);
+        *reinterpret_cast<bf16x8*>(dx + i * 8) = o;
+    }
+}
+
+int gn_block_threads(int C) {                             // multiple of C/8 chunks, <= 256
+    const int cpr = C / 8;
+    int t = (256 / cpr) * cpr;
+    return t < cpr ? cpr : t;
+}
+
+}  // namespace
+
+#define CONV_CHECK_GEOM(name)                                                                                     \
+    MERLOT_CHECK(x && N > 0 && H > 0 && W > 0 && C > 0, MERLOT_ESHAPE, name ": bad geometry");                   \
+    MERLOT_CHECK((reinterpret_cast<uintptr_t>(x) & 15) == 0, MERLOT_EALIGN, name ": operands must be 16-B aligned")
+
+extern "C" int merlot_im2col3x3(const void* x, void* out, int N, int H, int W, int C, int stride, int Kp, float shift,
+                                merlot_stream_t stream) {
+    CONV_CHECK_GEOM("merlot_im2col3x3");
+    MERLOT_CHECK(out && (stride == 1 || stride == 2) && H % stride == 0 && W % stride == 0, MERLOT_ESHAPE,
+                 "merlot_im2col3x3: stride must be 1 or 2 and divide H, W");
+    MERLOT_CHECK((C % 8 == 0 || C == 3) && Kp % 8 == 0 && Kp >= 9 * C, MERLOT_ESHAPE,
+                 "merlot_im2col3x3: C must be 3 or a multiple of 8, Kp a multiple of 8 and >= 9*C");
+    const int Ho = H / stride, Wo = W / stride;
+    const int64_t total = (int64_t)N * Ho * Wo * (Kp / 8);
+    hipLaunchKernelGGL(im2col3x3_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)out,
+                       N, H, W, C, stride, Ho, Wo, Kp, shift);
+    return merlot_launch_status("merlot_im2col3x3");
+}
+
+extern "C" int merlot_col2im3x3(const void* x, void* dx, int N, int H, int W, int C, int stride, int Kp, merlot_stream_t stream) {
+    CONV_CHECK_GEOM("merlot_col2im3x3");
+    MERLOT_CHECK(dx && (stride == 1 || stride == 2) && H % stride == 0 && W % stride == 0 && C % 8 == 0 && Kp >= 9 * C && Kp % 8 == 0,
+                 MERLOT_ESHAPE, "merlot_col2im3x3: bad arguments");
+    const int64_t total = (int64_t)N * H * W * (C / 8);
+    hipLaunchKernelGGL(col2im3x3_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)dx, N,
+                       H, W, C, stride, H / stride, W / stride, Kp);
+    return merlot_launch_status("merlot_col2im3x3");
+}
+
+extern "C" int merlot_groupnorm_fwd(const void* x, const float* gamma, const float* beta, const void* res, void* y, float* stats,
+                                    int N, int H, int W, int C, int G, float eps, int relu, merlot_stream_t stream) {
+    CONV_CHECK_GEOM("merlot_groupnorm_fwd");
+    MERLOT_CHECK(gamma && beta && y && stats && G > 0 && C % G == 0 && C % 8 == 0 && C <= 2048, MERLOT_ESHAPE,
+                 "merlot_groupnorm_fwd: C must be a multiple of 8 and of G");
+    const int HW = H * W;
+    const int threads = gn_block_threads(C);
+    int split = (HW * (C / 8) + threads * 8 - 1) / (threads * 8);
+    if (split > 64) split = 64;
+    if (split < 1) split = 1;
+    const int ppb = (HW + split - 1) / split;
+    hipError_t e = hipMemsetAsync(stats, 0, sizeof(float) * 2 * (size_t)N * G, (hipStream_t)stream);
+    MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(N, split), dim3(threads), sizeof(float) * 2 * G, (hipStream_t)stream, (const bf16*)x,
+                       stats, HW, C, G, ppb);
+    const int64_t total = (int64_t)N * HW * (C / 8);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, stats, gamma,
+                       beta, (const bf16*)res, (bf16*)y, (int64_t)N, HW, C, G, eps, relu);
+    return merlot_launch_status("merlot_groupnorm_fwd");
+}
+
+extern "C" int merlot_groupnorm_bwd(const void* dy, const void* y, const void* x, const float* stats, const float* gamma,
+                                    float* dgamma, float* dbeta, float* gsum, void* dx, void* dres, int N, int H, int W, int C,
+                                    int G, float eps, int relu, merlot_stream_t stream) {
+    CONV_CHECK_GEOM("merlot_groupnorm_bwd");
+    MERLOT_CHECK(dy && stats && gamma && dgamma && dbeta && gsum && dx && (!relu || y) && G > 0 && C % G == 0 && C % 8 == 0 &&
+                     C <= 2048, MERLOT_ESHAPE, "merlot_groupnorm_bwd: bad arguments");
+    const int HW = H * W;
+    const int threads = gn_block_threads(C);
+    int split = (HW * (C / 8) + threads * 8 - 1) / (threads * 8);
+    if (split > 64) split = 64;
+    if (split < 1) split = 1;
+    const int ppb = (HW + split - 1) / split;
+    hipError_t e = hipMemsetAsync(gsum, 0, sizeof(float) * 2 * (size_t)N * G, (hipStream_t)stream);
+    MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(N, split), dim3(threads), sizeof(float) * 2 * C, (hipStream_t)stream, (const bf16*)dy,
+                       (const bf16*)y, (const bf16*)x, stats, gamma, dgamma, dbeta, gsum, HW, C, G, eps, relu, ppb);
+    const int64_t total = (int64_t)N * HW * (C / 8);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy,
+                       (const bf16*)y, (const bf16*)x, stats, gsum, gamma, (bf16*)dx, (bf16*)dres, (int64_t)N, HW, C, G, eps, relu);
+    return merlot_launch_status("merlot_groupnorm_bwd");
+}
+
+extern "C" int merlot_avgpool2_fwd(const void* x, void* y, int N, int H, int W, int C, merlot_stream_t stream) {
+    CONV_CHECK_GEOM("merlot_avgpool2_fwd");
+    MERLOT_CHECK(y && H % 2 == 0 && W % 2 == 0 && C % 8 == 0, MERLOT_ESHAPE, "merlot_avgpool2_fwd: even H, W and C % 8 == 0 required");
+    const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 8);
+    hipLaunchKernelGGL(avgpool2_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y,
+                       (int64_t)N, H, W, C);
+    return merlot_launch_status("merlot_avgpool2_fwd");
+}
+
+extern "C" int merlot_avgpool2_bwd(const void* x, void* dx, int N, int H, int W, int C, merlot_stream_t stream) {
+    CONV_CHECK_GEOM("merlot_avgpool2_bwd");                 // x = dy [N, H/2, W/2, C]; dx [N, H, W, C]
+    MERLOT_CHECK(dx && H % 2 == 0 && W % 2 == 0 && C % 8 == 0, MERLOT_ESHAPE, "merlot_avgpool2_bwd: even H, W and C % 8 == 0 required");
+    const int64_t total = (int64_t)N * H * W * (C / 8);
+    hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)dx,
+                       (int64_t)N, H, W, C);
+    return merlot_launch_status("merlot_avgpool2_bwd");
+}

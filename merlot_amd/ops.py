@@ -331,6 +331,67 @@ def adamw_step(param, grad, m, v, lr, beta1, beta2, eps, weight_decay, grad_scal
          float(eps), float(weight_decay), float(grad_scale), _p(wd_flags), state_bf16, _stream())
 
 
+# ---- ResNet-hybrid stem ------------------------------------------------------------------------------
+def im2col3x3(x, stride=1, shift=0.0):
+    """x NHWC bf16 -> (patches [N*Ho*Wo, Kp] bf16, Kp); k = (ky, kx, c), Kp = 9*C rounded up to 64 (zero columns)."""
+    _chk(x, BF16, 'x')
+    N, H, W, C = x.shape
+    assert x.is_contiguous()
+    Kp = (9 * C + 63) // 64 * 64
+    out = torch.empty((N * (H // stride) * (W // stride), Kp), device=x.device, dtype=BF16)
+    call('merlot_im2col3x3', _p(x), _p(out), N, H, W, C, int(stride), Kp, float(shift), _stream())
+    return out
+
+
+def col2im3x3(dpatches, N, H, W, C, stride=1):
+    _chk(dpatches, BF16, 'dpatches')
+    assert dpatches.is_contiguous()
+    dx = torch.empty((N, H, W, C), device=dpatches.device, dtype=BF16)
+    call('merlot_col2im3x3', _p(dpatches), _p(dx), N, H, W, C, int(stride), dpatches.shape[1], _stream())
+    return dx
+
+
+def groupnorm_fwd(x, gamma, beta, *, res=None, relu=True, groups=32, eps=1e-4):
+    _chk(x, BF16, 'x'); _chk(gamma, F32, 'gamma'); _chk(beta, F32, 'beta'); _chk(res, BF16, 'res')
+    N, H, W, C = x.shape
+    assert x.is_contiguous() and (res is None or res.is_contiguous())
+    y = torch.empty_like(x)
+    stats = torch.empty((N, groups, 2), device=x.device, dtype=F32)
+    call('merlot_groupnorm_fwd', _p(x), _p(gamma), _p(beta), _p(res), _p(y), _p(stats), N, H, W, C, groups, float(eps),
+         1 if relu else 0, _stream())
+    return y, stats
+
+
+def groupnorm_bwd(dy, y, x, stats, gamma, dgamma, dbeta, *, relu=True, want_dres=False, groups=32, eps=1e-4):
+    _chk(dy, BF16, 'dy'); _chk(x, BF16, 'x'); _chk(stats, F32, 'stats'); _chk(dgamma, F32, 'dgamma'); _chk(dbeta, F32, 'dbeta')
+    N, H, W, C = x.shape
+    assert dy.is_contiguous() and x.is_contiguous()
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    gsum = torch.empty((N, groups, 2), device=x.device, dtype=F32)
+    call('merlot_groupnorm_bwd', _p(dy), _p(y), _p(x), _p(stats), _p(gamma), _p(dgamma), _p(dbeta), _p(gsum), _p(dx), _p(dres),
+         N, H, W, C, groups, float(eps), 1 if relu else 0, _stream())
+    return dx, dres
+
+
+def avgpool2_fwd(x):
+    _chk(x, BF16, 'x')
+    N, H, W, C = x.shape
+    assert x.is_contiguous()
+    y = torch.empty((N, H // 2, W // 2, C), device=x.device, dtype=BF16)
+    call('merlot_avgpool2_fwd', _p(x), _p(y), N, H, W, C, _stream())
+    return y
+
+
+def avgpool2_bwd(dy):
+    _chk(dy, BF16, 'dy')
+    N, Ho, Wo, C = dy.shape
+    assert dy.is_contiguous()
+    dx = torch.empty((N, 2 * Ho, 2 * Wo, C), device=dy.device, dtype=BF16)
+    call('merlot_avgpool2_bwd', _p(dy), _p(dx), N, 2 * Ho, 2 * Wo, C, _stream())
+    return dx
+
+
 def probe_mfma32(a, b):
     d = torch.empty((64, 16), device=a.device, dtype=F32)
     call('merlot_probe_mfma32', _p(a), _p(b), _p(d), _stream())

@@ -341,10 +341,81 @@ def adamw_step(param, grad, m, v, lr, beta1, beta2, eps, weight_decay, grad_scal
     raise NotImplementedError("adamw emulation lives in tests/test_optimizer.py")
 
 
+def im2col3x3(x, stride=1, shift=0.0):
+    N, H, W, C = x.shape
+    Kp = (9 * C + 63) // 64 * 64
+    xs = (x.float() + shift).to(BF16).float() if shift != 0.0 else x.float()
+    xp = torch.nn.functional.pad(xs.permute(0, 3, 1, 2), [1, 1, 1, 1])
+    cols = torch.nn.functional.unfold(xp, 3, stride=stride)                       # [N, C*9, L] with (c, ky, kx) order
+    L = cols.shape[-1]
+    cols = cols.reshape(N, C, 9, L).permute(0, 3, 2, 1).reshape(N * L, 9 * C)     # -> (ky*3+kx, c)
+    out = torch.zeros(N * L, Kp, dtype=BF16)
+    out[:, :9 * C] = cols.to(BF16)
+    return out
+
+
+def col2im3x3(dpatches, N, H, W, C, stride=1):
+    L = (H // stride) * (W // stride)
+    cols = dpatches[:, :9 * C].float().reshape(N, L, 9, C).permute(0, 3, 2, 1).reshape(N, C * 9, L)
+    dx = torch.nn.functional.fold(cols, (H + 2, W + 2), 3, stride=stride)[:, :, 1:H + 1, 1:W + 1]
+    return dx.permute(0, 2, 3, 1).contiguous().to(BF16)
+
+
+def _gn_moments(x, groups):
+    N, H, W, C = x.shape
+    g = x.float().reshape(N, H * W, groups, C // groups)
+    cnt = H * W * (C // groups)
+    s1, s2 = g.sum((1, 3)), (g * g).sum((1, 3))
+    return torch.stack([s1, s2], -1), cnt
+
+
+def groupnorm_fwd(x, gamma, beta, *, res=None, relu=True, groups=32, eps=1e-4):
+    N, H, W, C = x.shape
+    stats, cnt = _gn_moments(x, groups)
+    mean = stats[..., 0] / cnt
+    var = stats[..., 1] / cnt - mean * mean
+    g = x.float().reshape(N, H * W, groups, C // groups)
+    y = ((g - mean[:, None, :, None]) * torch.rsqrt(var + eps)[:, None, :, None]).reshape(N, H, W, C) * gamma + beta
+    if res is not None:
+        y = y + res.float()
+    if relu:
+        y = torch.relu(y)
+    return y.to(BF16), stats
+
+
+def groupnorm_bwd(dy, y, x, stats, gamma, dgamma, dbeta, *, relu=True, want_dres=False, groups=32, eps=1e-4):
+    N, H, W, C = x.shape
+    cnt = H * W * (C // groups)
+    mean = stats[..., 0] / cnt
+    rstd = torch.rsqrt(stats[..., 1] / cnt - mean * mean + eps)
+    d = dy.float()
+    if relu:
+        d = d * (y.float() > 0)
+    g = x.float().reshape(N, H * W, groups, C // groups)
+    xhat = ((g - mean[:, None, :, None]) * rstd[:, None, :, None]).reshape(N, H, W, C)
+    dgamma += (d * xhat).sum((0, 1, 2))
+    dbeta += d.sum((0, 1, 2))
+    dg = (d * gamma).reshape(N, H * W, groups, C // groups)
+    xh = xhat.reshape(N, H * W, groups, C // groups)
+    m1 = dg.sum((1, 3), keepdim=True) / cnt
+    m2 = (dg * xh).sum((1, 3), keepdim=True) / cnt
+    dx = (rstd[:, None, :, None] * (dg - m1 - xh * m2)).reshape(N, H, W, C)
+    return dx.to(BF16), (d.to(BF16) if want_dres else None)
+
+
+def avgpool2_fwd(x):
+    return torch.nn.functional.avg_pool2d(x.float().permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1).contiguous().to(BF16)
+
+
+def avgpool2_bwd(dy):
+    return (0.25 * dy.float()).repeat_interleave(2, 1).repeat_interleave(2, 2).to(BF16)
+
+
 _NAMES = ['gemm_nt', 'gemm_tn', 'patch_embed_fwd', 'patch_embed_wgrad', 'ln_fwd', 'ln_bwd', 'attention_fwd',
           'attention_bwd', 'attention_colsum', 'cast_bf16', 'cast_transpose_bf16', 'colsum_bf16', 'gather_add4',
           'scatter_add_rows', 'dropout_apply', 'cls_avgpool_fwd', 'cls_avgpool_bwd', 'softmax_ce', 'l2norm_fwd',
-          'l2norm_bwd', 'gelu_fwd', 'gelu_bwd', 'mask_inputs', 'temporal_labels', 'shuffled_idx']
+          'l2norm_bwd', 'gelu_fwd', 'gelu_bwd', 'mask_inputs', 'temporal_labels', 'shuffled_idx', 'im2col3x3', 'col2im3x3',
+          'groupnorm_fwd', 'groupnorm_bwd', 'avgpool2_fwd', 'avgpool2_bwd']
 
 
 def install(monkeypatch):

@@ -1,0 +1,62 @@
+"""GPU: the HIP kernels of the ResNet-hybrid stem against their torch emulation (tests/emu_ops.py), which
+the CPU host tests in turn check against the oracle.  bf16 outputs: rel-L2 <= 6e-3; im2col / col2im / pooling exact
+up to one bf16 rounding of a sum."""
+import pytest
+import torch
+
+import emu_ops as emu
+from common import rel_l2
+
+pytestmark = pytest.mark.gpu
+BF16 = torch.bfloat16
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from merlot_amd import ops as real
+    return real
+
+
+@pytest.mark.parametrize('N,H,W,C,stride', [(2, 8, 8, 32, 1), (3, 16, 12, 64, 2), (2, 64, 64, 3, 2), (1, 14, 14, 256, 1)])
+def test_im2col_and_col2im(ops, N, H, W, C, stride):
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(N, H, W, C, generator=g).to(BF16)
+    shift = -0.5 if C == 3 else 0.0
+    got = ops.im2col3x3(x.cuda(), stride, shift).cpu()
+    ref = emu.im2col3x3(x, stride, shift)
+    assert got.shape == ref.shape and torch.equal(got, ref)
+    if C % 8 == 0:
+        dp = torch.randn(ref.shape, generator=g).to(BF16)
+        dx = ops.col2im3x3(dp.cuda(), N, H, W, C, stride).cpu()
+        assert rel_l2(dx, emu.col2im3x3(dp, N, H, W, C, stride)) < 3e-3
+
+
+@pytest.mark.parametrize('N,H,W,C,relu,res', [(3, 8, 8, 32, True, False), (2, 14, 14, 256, False, False),
+                                               (2, 7, 9, 1024, True, True), (4, 16, 16, 64, True, False)])
+def test_groupnorm_forward_backward(ops, N, H, W, C, relu, res):
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(N, H, W, C, generator=g) * 2 + 0.3).to(BF16)
+    gamma = 1 + 0.1 * torch.randn(C, generator=g)
+    beta = 0.1 * torch.randn(C, generator=g)
+    r = torch.randn(N, H, W, C, generator=g).to(BF16) if res else None
+    y, stats = ops.groupnorm_fwd(x.cuda(), gamma.cuda(), beta.cuda(), res=r.cuda() if res else None, relu=relu)
+    y_ref, stats_ref = emu.groupnorm_fwd(x, gamma, beta, res=r, relu=relu)
+    assert rel_l2(stats.cpu(), stats_ref) < 1e-5
+    assert rel_l2(y.cpu(), y_ref) < 6e-3
+    dy = torch.randn(N, H, W, C, generator=g).to(BF16)
+    dga, dbe = torch.zeros(C).cuda(), torch.zeros(C).cuda()
+    dx, dres = ops.groupnorm_bwd(dy.cuda(), y, x.cuda(), stats, gamma.cuda(), dga, dbe, relu=relu, want_dres=res)
+    dga_r, dbe_r = torch.zeros(C), torch.zeros(C)
+    dx_ref, dres_ref = emu.groupnorm_bwd(dy, y.cpu(), x, stats.cpu(), gamma, dga_r, dbe_r, relu=relu, want_dres=res)
+    assert rel_l2(dx.cpu(), dx_ref) < 8e-3
+    assert rel_l2(dga.cpu(), dga_r) < 2e-3 and rel_l2(dbe.cpu(), dbe_r) < 2e-3
+    if res:
+        assert torch.equal(dres.cpu(), dres_ref)
+
+
+def test_avgpool2(ops):
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(3, 12, 8, 64, generator=g).to(BF16)
+    assert rel_l2(ops.avgpool2_fwd(x.cuda()).cpu(), emu.avgpool2_fwd(x)) < 3e-3
+    dy = torch.randn(3, 6, 4, 64, generator=g).to(BF16)
+    assert torch.equal(ops.avgpool2_bwd(dy.cuda()).cpu(), emu.avgpool2_bwd(dy))
