@@ -336,6 +336,185 @@ class PatchEmbedFn(torch.autograd.Function):
         return None, None, None, None
 
 
+class ResNetStemFn(torch.autograd.Function):
+    """ResNet-hybrid stem (utils/vision_transformer.py:114-170, 206-223): image NHWC bf16 ->
+    [n_img*h1*w1, H] bf16 tokens, the drop-in for PatchEmbedFn when `resnet_layers` is set.
+
+    Convolutions run on the MFMA GEMMs: 1x1 directly on the [N*H*W, C] activations, 3x3 on an im2col matrix
+    (`merlot_im2col3x3`, dgrad through `merlot_col2im3x3`); GroupNorm + ReLU (+ the bottleneck's residual add) and the
+    2x2 average pools are the kernels of csrc/conv.hip.  Kernels are weight-standardised (:52-56) from the fp32 masters
+    every step -- a few MB of parameters, done with torch ops on the device -- and the standardisation is
+    back-propagated into the master gradient.  Activations saved for the backward: conv inputs (or their im2col
+    matrices), conv outputs, GroupNorm statistics and outputs.
+    """
+
+    @staticmethod
+    def _std_kernel(w_hwio):
+        kh, kw, ci, co = w_hwio.shape
+        k = w_hwio.reshape(kh * kw * ci, co)
+        mean = k.mean(0, keepdim=True)
+        rstd = torch.rsqrt(((k - mean) ** 2).mean(0, keepdim=True) + 1e-5)
+        khat = (k - mean) * rstd                                      # [K, Co] fp32
+        K = kh * kw * ci
+        Kp = (K + 63) // 64 * 64
+        wb = torch.zeros((co, Kp), device=k.device, dtype=BF16)       # NT operand [Co, Kp]
+        wb[:, :K] = khat.t().to(BF16)
+        wbT = torch.zeros((Kp, (co + 63) // 64 * 64), device=k.device, dtype=BF16)   # dgrad operand [Kp, Co(+pad)]
+        wbT[:K, :co] = khat.to(BF16)
+        return khat, rstd, wb, wbT
+
+    @staticmethod
+    def forward(ctx, image, store, cfg, anchor):
+        vs = 'vision_backbone/vision_transformer'
+        rs = f'{vs}/resnet50lite'
+        tape = []
+
+        def conv(x, name, stride=1, shift=0.0):
+            w = store.p(name + '/kernel')
+            kh = w.shape[0]
+            co = w.shape[3]
+            khat, rstd, wb, wbT = ResNetStemFn._std_kernel(w)
+            N, Hh, Ww, C = x.shape
+            if kh == 1:
+                a = x.reshape(N * Hh * Ww, C)
+                Ho, Wo = Hh, Ww
+            else:
+                a = ops.im2col3x3(x, stride, shift)
+                Ho, Wo = Hh // stride, Ww // stride
+            y = ops.gemm_nt(a, wb).view(N, Ho, Wo, co)
+            tape.append(('conv', name, a, khat, rstd, wbT, (N, Hh, Ww, C), stride, kh))
+            return y
+
+        def gn(x, name, relu=True, res=None):
+            g_, b_ = store.p(name + '/gamma'), store.p(name + '/beta')
+            y, stats = ops.groupnorm_fwd(x, g_, b_, res=res, relu=relu)
+            tape.append(('gn', name, x, y if relu else None, stats, relu, res is not None))
+            return y
+
+        def pool(x):
+            tape.append(('pool',))
+            return ops.avgpool2_fwd(x)
+
+        x = gn(conv(image, f'{rs}/stem/conv2d', 2, -0.5), f'{rs}/stem/GroupNorm_stem0')     # image - 0.5 (:193) in the gather
+        x = gn(conv(x, f'{rs}/stem/conv2d_1'), f'{rs}/stem/GroupNorm_stem1')
+        x = gn(conv(x, f'{rs}/stem/conv2d_2'), f'{rs}/stem/GroupNorm_stem2')
+        c = pool(x)
+        for i, blocks in enumerate(cfg['resnet_layers']):
+            gs = f'{rs}/block_group{i + 1}'
+            k = [0]
+
+            def nm():
+                n_ = '' if k[0] == 0 else f'_{k[0]}'
+                k[0] += 1
+                return f'{gs}/conv2d{n_}', f'{gs}/GroupNorm{n_}'
+            for bi in range(blocks):
+                st = (1 if i == 0 else 2) if bi == 0 else 1
+                tape.append(('block_begin', bi == 0, st))
+                shortcut = c
+                if bi == 0:
+                    cn, gnn = nm()
+                    sc_in = pool(c) if st > 1 else c
+                    shortcut = gn(conv(sc_in, cn), gnn, relu=False)
+                tape.append(('main_begin',))
+                cn, gnn = nm()
+                h = gn(conv(c, cn), gnn)
+                cn, gnn = nm()
+                h = gn(conv(h, cn), gnn)
+                if st > 1:
+                    h = pool(h)
+                cn, gnn = nm()
+                c = gn(conv(h, cn), gnn, relu=True, res=shortcut)       # relu(gn(conv) + shortcut), :92-93
+                tape.append(('block_end',))
+        N, h1, w1, C = c.shape
+        lin = store.lin(f'{vs}/conv_postresnet_proj')
+        a = c.reshape(N * h1 * w1, C)
+        out = ops.gemm_nt(a, lin.wb, bias=lin.b)
+        ctx.tape, ctx.store, ctx.lin, ctx.a_final, ctx.c_shape = tape, store, lin, a, (N, h1, w1, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        store, tape, lin = ctx.store, ctx.tape, ctx.lin
+        dy = dy.contiguous()
+        ops.colsum_bf16(dy, lin.gb)
+        ops.gemm_tn(dy, ctx.a_final, lin.gw)
+        N, h1, w1, C = ctx.c_shape
+        d = ops.gemm_nt(dy, lin.wbT).view(N, h1, w1, C)
+
+        def conv_bwd(entry, dyc, need_dx=True):
+            _, name, a, khat, rstd, wbT, xshape, stride, kh = entry
+            Nn, Hh, Ww, Cc = xshape
+            co = khat.shape[1]
+            dyf = dyc.reshape(-1, co)
+            dk = torch.zeros((co + (co % 2), a.shape[1]), device=dyf.device, dtype=F32)
+            ops.gemm_tn(dyf, a, dk, accumulate=False, m=co + (co % 2))                 # dKhat^T [Co, Kp]
+            dkh = dk[:co, :khat.shape[0]].t()                                           # [K, Co]
+            # weight standardisation backward: khat = (k - mean) * rstd per output channel
+            dw = rstd * (dkh - dkh.mean(0, keepdim=True) - khat * (dkh * khat).mean(0, keepdim=True))
+            store.g(name + '/kernel').add_(dw.reshape(store.g(name + '/kernel').shape))
+            if not need_dx:
+                return None
+            kp_co = wbT.shape[1]
+            if kp_co != co:                                                             # pad the reduction dim to 64
+                dyp = torch.zeros((dyf.shape[0], kp_co), device=dyf.device, dtype=BF16)
+                dyp[:, :co] = dyf
+                dyf = dyp
+            dp = ops.gemm_nt(dyf, wbT)                                                  # [T, Kp]
+            if kh == 1:
+                return dp[:, :Cc].reshape(Nn, Hh, Ww, Cc) if dp.shape[1] != Cc else dp.view(Nn, Hh, Ww, Cc)
+            return ops.col2im3x3(dp, Nn, Hh, Ww, Cc, stride)
+
+        def gn_bwd(entry, dyg):
+            _, name, x, y, stats, relu, has_res = entry
+            dx, dres = ops.groupnorm_bwd(dyg.contiguous(), y, x, stats, store.p(name + '/gamma'), store.g(name + '/gamma'),
+                                         store.g(name + '/beta'), relu=relu, want_dres=has_res)
+            return dx, dres
+
+        # walk the tape backwards; the bottleneck blocks need their two branches' gradients joined
+        i = len(tape) - 1
+
+        def pop():
+            nonlocal i
+            e = tape[i]
+            i -= 1
+            return e
+
+        def add(a_, b_):
+            return (a_.float() + b_.float()).to(BF16)
+
+        while i >= 0 and tape[i][0] == 'block_end':
+            pop()
+            # main branch, last to first: gn(res) <- conv <- [pool] <- gn <- conv <- gn <- conv
+            e = pop(); d_h, d_short = gn_bwd(e, d)
+            d_h = conv_bwd(pop(), d_h)
+            if tape[i][0] == 'pool':
+                pop(); d_h = ops.avgpool2_bwd(d_h.contiguous())
+            e = pop(); d_h, _ = gn_bwd(e, d_h)
+            d_h = conv_bwd(pop(), d_h)
+            e = pop(); d_h, _ = gn_bwd(e, d_h)
+            d_c = conv_bwd(pop(), d_h)
+            assert pop()[0] == 'main_begin'
+            # shortcut branch
+            if tape[i][0] == 'gn':                                                       # projection shortcut
+                e = pop(); d_s, _ = gn_bwd(e, d_short)
+                d_s = conv_bwd(pop(), d_s)
+                if tape[i][0] == 'pool':
+                    pop(); d_s = ops.avgpool2_bwd(d_s.contiguous())
+            else:
+                d_s = d_short
+            assert pop()[0] == 'block_begin'
+            d = add(d_c, d_s)
+        assert pop()[0] == 'pool'
+        d = ops.avgpool2_bwd(d.contiguous())
+        for j in range(3):                                                               # the three stem convolutions
+            e = pop(); d, _ = gn_bwd(e, d)
+            d = conv_bwd(pop(), d, need_dx=(j < 2))
+        assert i == -1
+        store.notify_ready('vision_backbone/vision_transformer/resnet50lite')
+        ctx.tape = None
+        return None, None, None, None
+
+
 class L2NormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

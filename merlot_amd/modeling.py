@@ -102,8 +102,8 @@ class MerlotModel(object):
         dev = params.device
         self.device = dev
 
-        if cfg.get('resnet_layers'):
-            raise NotImplementedError("resnet-hybrid stem is a `next` row (SURVEY.md 8f #2); set resnet_layers: []")
+        if cfg.get('resnet_layers') and cfg['patch_size'] != 16:
+            raise ValueError("the ResNet-hybrid stem reduces by 16 (utils/vision_transformer.py:208)")
         if cfg.get('num_imgs', 1) != 1 or cfg.get('num_texts', 1) != 1:
             raise NotImplementedError("num_imgs / num_texts > 1 (VCR path) is out of scope")
         if cfg.get('disable_pairwise_lang_attn', False):
@@ -164,7 +164,10 @@ class MerlotModel(object):
         ncls = cfg.get('num_cls_emb', 2)
         Sv = h1 * w1 + ncls
         vs = 'vision_backbone/vision_transformer'
-        conv = L.PatchEmbedFn.apply(image, st.lin(f'{vs}/conv2d', need_T=False), Pz, self._anchor)
+        if cfg.get('resnet_layers'):                                              # utils/vision_transformer.py:206-223
+            conv = L.ResNetStemFn.apply(image, st, cfg, self._anchor)
+        else:
+            conv = L.PatchEmbedFn.apply(image, st.lin(f'{vs}/conv2d', need_T=False), Pz, self._anchor)
         idx_conv, idx_cls, idx_pos = self._vit_prologue_indices(N, h1, w1, ncls)
         conv_inv = (torch.arange(N, device=dev)[:, None] * Sv + ncls + torch.arange(h1 * w1, device=dev)[None]).reshape(-1)
         x = L.gather_add(conv, idx_conv,

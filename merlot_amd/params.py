@@ -49,6 +49,34 @@ def _stack_entries(scope, nl, H, I):
     return e
 
 
+def resnet_entries(cfg, vs, width=64):
+    """Variables of the ResNet-hybrid stem (utils/vision_transformer.py:114-170, 206-223) in creation order, named as the
+    reference's scopes name them (conv2d, conv2d_1, ... / GroupNorm, GroupNorm_1, ... per block_group).  Convolution
+    kernels keep TF's HWIO layout (they are weight-standardised into a [Co, K] bf16 operand at use)."""
+    layers = cfg.get('resnet_layers', [])
+    rs = f'{vs}/resnet50lite'
+    e = []
+    for j, (ci, co) in enumerate([(3, width // 2), (width // 2, width // 2), (width // 2, width)]):
+        e += [(f'{rs}/stem/conv2d' + (f'_{j}' if j else '') + '/kernel', (3, 3, ci, co), 'conv_hwio'),
+              (f'{rs}/stem/GroupNorm_stem{j}/gamma', (co,), 'ones'), (f'{rs}/stem/GroupNorm_stem{j}/beta', (co,), 'zeros')]
+    cin = width
+    for i, blocks in enumerate(layers):
+        f = width * (2 ** i)
+        gs = f'{rs}/block_group{i + 1}'
+        k = 0
+        for bi in range(blocks):
+            convs = ([(1, cin, 4 * f)] if bi == 0 else []) + [(1, cin, f), (3, f, f), (1, f, 4 * f)]
+            for kh, ci, co in convs:
+                sfx = f'_{k}' if k else ''
+                e += [(f'{gs}/conv2d{sfx}/kernel', (kh, kh, ci, co), 'conv_hwio'),
+                      (f'{gs}/GroupNorm{sfx}/gamma', (co,), 'ones'), (f'{gs}/GroupNorm{sfx}/beta', (co,), 'zeros')]
+                k += 1
+            cin = 4 * f
+    e += [(f'{vs}/conv_postresnet_proj/kernel', (cfg['hidden_size'], cin), 'conv'),
+          (f'{vs}/conv_postresnet_proj/bias', (cfg['hidden_size'],), 'zeros')]
+    return e
+
+
 def param_entries(cfg):
     """[(internal name, shape, init kind)] in arena order."""
     H, I, V = cfg['hidden_size'], cfg['intermediate_size'], cfg['vocab_size']
@@ -58,8 +86,11 @@ def param_entries(cfg):
     vs = 'vision_backbone/vision_transformer'
     nl_vit = cfg.get('num_vision_transformer_hidden_layers', cfg['num_hidden_layers'])
     nl_enc = max(cfg['num_hidden_layers'], cfg.get('num_lang_transformer_hidden_layers', 0))
-    e = [(f'{vs}/conv2d/kernel', (H, P * P * 3), 'conv'), (f'{vs}/conv2d/bias', (H,), 'zeros'),
-         (f'{vs}/pos_embs/pos_embs', (1, 64, 64, H), 'normal'), (f'{vs}/pos_embs/cls_emb', (1, ncls, H), 'normal'),
+    if cfg.get('resnet_layers'):
+        e = resnet_entries(cfg, vs)
+    else:
+        e = [(f'{vs}/conv2d/kernel', (H, P * P * 3), 'conv'), (f'{vs}/conv2d/bias', (H,), 'zeros')]
+    e += [(f'{vs}/pos_embs/pos_embs', (1, 64, 64, H), 'normal'), (f'{vs}/pos_embs/cls_emb', (1, ncls, H), 'normal'),
          (f'{vs}/LayerNorm_ctx_patches_pre_ln/gamma', (H,), 'ones'),
          (f'{vs}/LayerNorm_ctx_patches_pre_ln/beta', (H,), 'zeros')]
     e += _stack_entries(vs, nl_vit, H, I)
@@ -149,6 +180,8 @@ class ParamStore(object):
                 t = torch.zeros(shape)
             elif kind == 'conv':
                 t = torch.randn(shape, generator=g).clamp_(-2, 2) * math.sqrt(1.0 / shape[1])
+            elif kind == 'conv_hwio':                                        # variance_scaling, fan_in = kh*kw*ci
+                t = torch.randn(shape, generator=g).clamp_(-2, 2) * math.sqrt(1.0 / (shape[0] * shape[1] * shape[2]))
             else:
                 t = torch.randn(shape, generator=g).clamp_(-2, 2) * std      # truncated normal, transformer.py:166-168
             self.p(name).copy_(t)
@@ -230,6 +263,13 @@ class ParamStore(object):
                     used.add(f'{base}/{nm}/{leaf}')
                     parts.append(t.t() if leaf == 'kernel' else t)
                 dst.copy_(torch.cat(parts, 0))
+            elif '/resnet50lite/' in name:
+                used.add(name)
+                dst.copy_(torch.as_tensor(tf_weights[name]).float().reshape(dst.shape))   # HWIO kernels / GroupNorm, as is
+            elif name.endswith('conv_postresnet_proj/kernel'):
+                t = torch.as_tensor(tf_weights[name]).float()            # [1, 1, C, H]
+                used.add(name)
+                dst.copy_(t.reshape(-1, H).t())
             elif name.endswith('conv2d/kernel'):
                 t = torch.as_tensor(tf_weights[name]).float()            # HWIO [P,P,3,H]
                 used.add(name)
@@ -255,6 +295,10 @@ class ParamStore(object):
                 for i, nm in enumerate(['query_layer', 'key_layer', 'value_layer']):
                     part = t[i * H:(i + 1) * H]
                     out[f'{base}/{nm}/{leaf}'] = part.t().contiguous() if leaf == 'kernel' else part.clone()
+            elif '/resnet50lite/' in name:
+                out[name] = t.clone()
+            elif name.endswith('conv_postresnet_proj/kernel'):
+                out[name] = t.t().reshape(1, 1, -1, H).contiguous()
             elif name.endswith('conv2d/kernel'):
                 out[name] = t.t().reshape(P, P, 3, H).contiguous()
             elif name.endswith('/kernel'):

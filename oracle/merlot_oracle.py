@@ -119,6 +119,36 @@ def transformer(hidden_state, mask, w, scope, num_layers, num_heads, return_attn
 # ResNet-hybrid stem (utils/vision_transformer.py:8-170, utils/model_utils.py:133-222): what merlot.yaml:30
 # (`resnet_layers: [3, 4, 9]`) and the released checkpoints use.  NHWC tensors as in the reference.
 # ----------------------------------------------------------------------------------------------
+# bf16 policy for the stem: the reference's `use_bfloat16: True` graph holds every activation between the stem's ops
+# (and the standardised kernels, utils/vision_transformer.py:58-59) in bf16.  23 such layers in sequence move the
+# result by ~4 % relative to the fp32 graph (measured), so implementations that follow that policy are compared with
+# THIS variant: `with bf16_stem(): ...` rounds at the same places, everything else stays fp32.
+_BF16_STEM = [False]
+
+
+class bf16_stem(object):
+    def __enter__(self):
+        _BF16_STEM.append(True)
+
+    def __exit__(self, *a):
+        _BF16_STEM.pop()
+
+
+class _RoundBoth(torch.autograd.Function):
+    """bf16 tensor in a bf16 graph: the value is rounded going forward and so is its gradient coming back."""
+    @staticmethod
+    def forward(ctx, t):
+        return t.to(torch.bfloat16).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).float()
+
+
+def _q(t):
+    return _RoundBoth.apply(t) if _BF16_STEM[-1] else t
+
+
 def group_norm(x, w, scope, num_groups=32, eps=1e-4):
     """utils/model_utils.py:133-222 with mean_close_to_zero=True: one-pass moments E[x^2] - E[x]^2 per (sample,
     group) over (H, W, C/groups), then per-channel gamma / beta."""
@@ -128,7 +158,7 @@ def group_norm(x, w, scope, num_groups=32, eps=1e-4):
     mean = g.sum((1, 2, 4), keepdim=True) / cnt                                   # :198-201
     var = (g * g).sum((1, 2, 4), keepdim=True) / cnt - mean * mean
     y = ((g - mean) * torch.rsqrt(var + eps)).reshape(N, Hh, Ww, C)               # :205
-    return y * w[scope + '/gamma'] + w[scope + '/beta']                           # :219
+    return _q(y * w[scope + '/gamma'] + w[scope + '/beta'])                       # :219 (:220-221 cast back)
 
 
 def standardize_kernel(k):
@@ -141,13 +171,13 @@ def standardize_kernel(k):
 def conv2d_fixed_padding(x, kernel, strides=1):
     """utils/vision_transformer.py:31-63: weight-standardised conv, no bias; stride 1 -> SAME, stride > 1 -> explicit
     (k-1)//2 low / rest high padding then VALID (fixed_padding, :8-19)."""
-    k = standardize_kernel(kernel)
+    k = _q(standardize_kernel(kernel))                                            # :58-59
     ks = k.shape[0]
     lo = (ks - 1) // 2
     hi_ = ks - 1 - lo
-    xc = torch.nn.functional.pad(x.permute(0, 3, 1, 2), [lo, hi_, lo, hi_])      # SAME for odd k at stride 1 == this
+    xc = torch.nn.functional.pad(_q(x).permute(0, 3, 1, 2), [lo, hi_, lo, hi_])  # SAME for odd k at stride 1 == this
     out = torch.nn.functional.conv2d(xc, k.permute(3, 2, 0, 1), None, stride=strides)
-    return out.permute(0, 2, 3, 1)
+    return _q(out.permute(0, 2, 3, 1))
 
 
 def _avg_pool(x, k):
