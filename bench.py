@@ -20,6 +20,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 TRAIN_GFLOP_PER_SEGMENT = 170.4          # 56.79 fwd x 3, num_chunks=16, 224^2, n=4
+# --resnet-stem: lite_resnet50 [3,4,9] + conv_postresnet_proj = 10.041 GFLOP/frame forward instead of the 0.231 of the
+# patch conv (2*MACs over the convolutions of utils/vision_transformer.py:114-170, 213-223 at 224^2)
+TRAIN_GFLOP_PER_SEGMENT_RESNET = 170.4 + 3.0 * (10.041 - 0.231)
 PEAK_BF16_TFLOPS = 2500.0                # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
@@ -46,6 +49,10 @@ def cpu_baseline_worker(threads):
     from oracle import merlot_oracle as mo
     torch.set_num_threads(threads)
     config = NeatConfig.from_yaml(os.path.join(ROOT, 'merlot_amd', 'configs', 'pretrain_4seg_224.yaml'))
+    train_gflop = TRAIN_GFLOP_PER_SEGMENT
+    if args.resnet_stem:
+        config.model['resnet_layers'] = [3, 4, 9]
+        train_gflop = TRAIN_GFLOP_PER_SEGMENT_RESNET
     cfg = dict(config.model)
     cfg['hidden_dropout_prob'] = 0.0
     w = mo.init_weights(cfg, 0, perturb=False)
@@ -118,6 +125,8 @@ def main():
     ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--examples', type=int, default=32, help='examples (x16 segments) per GPU per step')
+    ap.add_argument('--resnet-stem', action='store_true',
+                    help='NOT the headline config: swap the patch stem for the ResNet-hybrid stem of merlot.yaml:30 (resnet_layers [3, 4, 9])')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--cpu-baseline-worker', type=int, default=0, help=argparse.SUPPRESS)
@@ -147,6 +156,10 @@ def main():
         ctx = DistContext()
 
     config = NeatConfig.from_yaml(os.path.join(ROOT, 'merlot_amd', 'configs', 'pretrain_4seg_224.yaml'))
+    train_gflop = TRAIN_GFLOP_PER_SEGMENT
+    if args.resnet_stem:
+        config.model['resnet_layers'] = [3, 4, 9]
+        train_gflop = TRAIN_GFLOP_PER_SEGMENT_RESNET
     trainer = Trainer(config, device, ctx, seed=0)
     batch = synthetic_batch(config, args.examples, device, seed=1234 + rank)
     seg_per_gpu = args.examples * config.data['num_chunks']
@@ -191,16 +204,18 @@ def main():
             'metric': 'frame-caption segments/sec/node (4-seg, 224^2, bf16)', 'value': value, 'unit': 'segments/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': 'merlot.yaml 4-segment full ViT-B/16 (patch stem) + 12-layer joint + 12-layer text-only, '
+            'config': {'workload': ('merlot.yaml 4-segment ResNet-hybrid [3,4,9] + ViT-B/16' if args.resnet_stem else
+                                    'merlot.yaml 4-segment full ViT-B/16 (patch stem)') + ' + 12-layer joint + 12-layer text-only, '
                                    '224^2 frames, 32-token captions, fwd+bwd+DP all-reduce+AdamW, dropout 0.1',
                        'segments_per_gpu_per_step': seg_per_gpu, 'examples_per_gpu': args.examples,
                        'num_chunks': config.data['num_chunks'], 'parallelism': f'dp{world}', 'grad_reduce': 'sum',
+                       'stem': 'resnet-hybrid [3,4,9] (merlot.yaml:30)' if args.resnet_stem else 'patch 16x16 (north_star)',
                        'final_loss': loss},
-            'model_flops_utilization': value * TRAIN_GFLOP_PER_SEGMENT / 1e3 / (world * PEAK_BF16_TFLOPS),
+            'model_flops_utilization': value * train_gflop / 1e3 / (world * PEAK_BF16_TFLOPS),
             'forward_only': {'value': world * seg_per_gpu * fwd_steps / fwd_elapsed, 'unit': 'segments/s',
                              'ms_per_pass': 1e3 * fwd_elapsed / fwd_steps, 'passes': fwd_steps,
                              'model_flops_utilization': world * seg_per_gpu * fwd_steps / fwd_elapsed *
-                             (TRAIN_GFLOP_PER_SEGMENT / 3.0) / 1e3 / (world * PEAK_BF16_TFLOPS)},
+                             (train_gflop / 3.0) / 1e3 / (world * PEAK_BF16_TFLOPS)},
         }
         if timer is not None:
             summ = timer.summary()
@@ -217,7 +232,7 @@ def main():
                 res['roofline_wgrad'] = {'kernel': 'merlot_gemm_bf16_tn = gemm_tn_ring_kernel + tn_reduce_kernel', 'achieved': f2 / t2 / 1e12, 'unit': 'TFLOP/s',
                                          'frac': f2 / t2 / 1e12 / PEAK_BF16_TFLOPS, 'launches': n2,
                                          'share_of_step_time': t2 / elapsed}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.resnet_stem:
             res['cpu_baseline'] = cpu_baseline()
         print(json.dumps(res), flush=True)
     if world > 1 or force_dist:
