@@ -217,8 +217,8 @@ int merlot_im2col3x3(const void* x, void* out, int N, int H, int W, int C, int s
 int merlot_col2im3x3(const void* dpatches, void* dx, int N, int H, int W, int C, int stride, int Kp,
                      merlot_stream_t stream);
 /* y = [relu]( (x - mean) * rsqrt(var + eps) * gamma + beta [+ res] ), moments per (sample, group) over (H, W, C/G) from
- * one pass (var = E[x^2] - E[x]^2, :196-201).  stats: f32 [N, G, 2] = {sum, sum of squares}, written here, kept for
- * the backward.  res may be NULL. */
+ * one pass (var = E[x^2] - E[x]^2, :196-201).  stats: f32 [N, G, 2] = {mean, rsqrt(var + eps)}, written here, kept
+ * for the backward.  res may be NULL. */
 int merlot_groupnorm_fwd(const void* x, const float* gamma, const float* beta, const void* res, void* y, float* stats,
                          int N, int H, int W, int C, int G, float eps, int relu, merlot_stream_t stream);
 /* dy' = relu ? dy * (y > 0) : dy.  dgamma / dbeta (f32 [C]) are ACCUMULATED; gsum: f32 [N, G, 2] scratch; dx bf16;

@@ -126,13 +126,23 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16* __restrict__ 
     for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) atomicAdd(stats + (int64_t)n * 2 * G + i, gred[i]);
 }
 
-// y = [relu]( (x - mean) * rstd * gamma + beta [+ res] ), mean / var from the sums (var = E[x^2] - E[x]^2)
+// {sum, sum of squares} -> {mean, rstd} in place (var = E[x^2] - E[x]^2, the reference's one-pass form)
+__global__ void gn_finalize_kernel(float* __restrict__ stats, int64_t n_groups, float inv_cnt, float eps) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_groups) {
+        const float mean = stats[2 * i] * inv_cnt;
+        const float var = stats[2 * i + 1] * inv_cnt - mean * mean;
+        stats[2 * i] = mean;
+        stats[2 * i + 1] = rsqrtf(var + eps);
+    }
+}
+
+// y = [relu]( (x - mean) * rstd * gamma + beta [+ res] )
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16* __restrict__ x, const float* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const bf16* __restrict__ res, bf16* __restrict__ y, int64_t N, int HW,
                                                        int C, int G, float eps, int relu) {
     const int cpr = C / 8, cpg = C / G;
-    const float inv_cnt = 1.0f / ((float)HW * (float)cpg);
     const int64_t total = N * HW * cpr;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % cpr) * 8;
@@ -144,9 +154,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int g = (c + e) / cpg;
-            const float mean = stats[(n * G + g) * 2] * inv_cnt;
-            const float var = stats[(n * G + g) * 2 + 1] * inv_cnt - mean * mean;
-            float f = ((float)v[e] - mean) * rsqrtf(var + eps) * gamma[c + e] + beta[c + e];
+            const float mean = stats[(n * G + g) * 2], rstd = stats[(n * G + g) * 2 + 1];
+            float f = ((float)v[e] - mean) * rstd * gamma[c + e] + beta[c + e];
             if (res) f += (float)r8[e];
             if (relu) f = fmaxf(f, 0.f);
             o[e] = (bf16)f;
@@ -166,7 +175,6 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const bf16* __restric
     extern __shared__ float sm[];                          // [C][2] per-channel partials of this block
     const int n = blockIdx.x;
     const int cpr = C / 8, cpg = C / G;
-    const float inv_cnt = 1.0f / ((float)HW * (float)cpg);
     for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) sm[i] = 0.f;
     __syncthreads();
     const int p0 = blockIdx.y * pos_per_block, p1 = min(HW, p0 + pos_per_block);
@@ -176,8 +184,8 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const bf16* __restric
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int g = (chunk * 8 + e) / cpg;
-        mean[e] = stats[((int64_t)n * G + g) * 2] * inv_cnt;
-        rstd[e] = rsqrtf(stats[((int64_t)n * G + g) * 2 + 1] * inv_cnt - mean[e] * mean[e] + eps);
+        mean[e] = stats[((int64_t)n * G + g) * 2];
+        rstd[e] = stats[((int64_t)n * G + g) * 2 + 1];
     }
     if (prow < pstep) {
         for (int p = p0 + prow; p < p1; p += pstep) {
@@ -231,8 +239,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const bf16* __restric
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int g = (c + e) / cpg;
-            const float mean = stats[(n * G + g) * 2] * inv_cnt;
-            const float rstd = rsqrtf(stats[(n * G + g) * 2 + 1] * inv_cnt - mean * mean + eps);
+            const float mean = stats[(n * G + g) * 2], rstd = stats[(n * G + g) * 2 + 1];
             float d = (float)d8[e];
             if (relu && !((float)y8[e] > 0.f)) d = 0.f;
             const float xhat = ((float)x8[e] - mean) * rstd;
@@ -330,7 +337,10 @@ extern "C" int merlot_groupnorm_fwd(const void* x, const float* gamma, const flo
                  "merlot_groupnorm_fwd: C must be a multiple of 8 and of G");
     const int HW = H * W;
     const int threads = gn_block_threads(C);
-    int split = (HW * (C / 8) + threads * 8 - 1) / (threads * 8);
+    // enough blocks to fill the chip (>= ~2048) but no more: every block ends in atomics (2G here, 4C in the backward)
+    int split = (2048 + N - 1) / N;
+    const int max_split = (HW * (C / 8) + threads * 4 - 1) / (threads * 4);
+    if (split > max_split) split = max_split;
     if (split > 64) split = 64;
     if (split < 1) split = 1;
     const int ppb = (HW + split - 1) / split;
@@ -338,6 +348,8 @@ extern "C" int merlot_groupnorm_fwd(const void* x, const float* gamma, const flo
     MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(gn_stats_kernel, dim3(N, split), dim3(threads), sizeof(float) * 2 * G, (hipStream_t)stream, (const bf16*)x,
                        stats, HW, C, G, ppb);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(((int64_t)N * G + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats,
+                       (int64_t)N * G, 1.0f / ((float)HW * (float)(C / G)), eps);
     const int64_t total = (int64_t)N * HW * (C / 8);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, stats, gamma,
                        beta, (const bf16*)res, (bf16*)y, (int64_t)N, HW, C, G, eps, relu);
@@ -352,7 +364,10 @@ extern "C" int merlot_groupnorm_bwd(const void* dy, const void* y, const void* x
                      C <= 2048, MERLOT_ESHAPE, "merlot_groupnorm_bwd: bad arguments");
     const int HW = H * W;
     const int threads = gn_block_threads(C);
-    int split = (HW * (C / 8) + threads * 8 - 1) / (threads * 8);
+    // enough blocks to fill the chip (>= ~2048) but no more: every block ends in atomics (2G here, 4C in the backward)
+    int split = (2048 + N - 1) / N;
+    const int max_split = (HW * (C / 8) + threads * 4 - 1) / (threads * 4);
+    if (split > max_split) split = max_split;
     if (split > 64) split = 64;
     if (split < 1) split = 1;
     const int ppb = (HW + split - 1) / split;

@@ -480,7 +480,7 @@ class ResNetStemFn(torch.autograd.Function):
             return e
 
         def add(a_, b_):
-            return (a_.float() + b_.float()).to(BF16)
+            return a_ + b_                               # one bf16 kernel (fp32 inside), not three passes
 
         while i >= 0 and tape[i][0] == 'block_end':
             pop()

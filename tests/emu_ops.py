@@ -371,11 +371,12 @@ def _gn_moments(x, groups):
 
 def groupnorm_fwd(x, gamma, beta, *, res=None, relu=True, groups=32, eps=1e-4):
     N, H, W, C = x.shape
-    stats, cnt = _gn_moments(x, groups)
-    mean = stats[..., 0] / cnt
-    var = stats[..., 1] / cnt - mean * mean
+    sums, cnt = _gn_moments(x, groups)
+    mean = sums[..., 0] / cnt
+    rstd = torch.rsqrt(sums[..., 1] / cnt - mean * mean + eps)
+    stats = torch.stack([mean, rstd], -1)
     g = x.float().reshape(N, H * W, groups, C // groups)
-    y = ((g - mean[:, None, :, None]) * torch.rsqrt(var + eps)[:, None, :, None]).reshape(N, H, W, C) * gamma + beta
+    y = ((g - mean[:, None, :, None]) * rstd[:, None, :, None]).reshape(N, H, W, C) * gamma + beta
     if res is not None:
         y = y + res.float()
     if relu:
@@ -386,8 +387,7 @@ def groupnorm_fwd(x, gamma, beta, *, res=None, relu=True, groups=32, eps=1e-4):
 def groupnorm_bwd(dy, y, x, stats, gamma, dgamma, dbeta, *, relu=True, want_dres=False, groups=32, eps=1e-4):
     N, H, W, C = x.shape
     cnt = H * W * (C // groups)
-    mean = stats[..., 0] / cnt
-    rstd = torch.rsqrt(stats[..., 1] / cnt - mean * mean + eps)
+    mean, rstd = stats[..., 0], stats[..., 1]
     d = dy.float()
     if relu:
         d = d * (y.float() > 0)
