@@ -104,8 +104,10 @@ def test_constructor_errors_mirror_reference(emu):
         MerlotModel(cfg, True, False, b['image'], b['input_ids'][:, :3], params=st)        # image/ids batch mismatch
     with pytest.raises(ValueError):
         MerlotModel(tiny_config(num_chunks_in_group=3), True, False, b['image'], b['input_ids'], params=st)
-    with pytest.raises(NotImplementedError):
-        MerlotModel(tiny_config(resnet_layers=[3, 4, 9]), True, False, b['image'], b['input_ids'], params=st)
+    with pytest.raises(NotImplementedError):                                                # VCR-style duplication
+        MerlotModel(tiny_config(num_texts=4), True, False, b['image'], b['input_ids'], params=st)
+    with pytest.raises(ValueError):                                                         # hybrid stem needs P = 16
+        MerlotModel(tiny_config(resnet_layers=[1, 1, 1], patch_size=8), True, False, b['image'], b['input_ids'], params=st)
     with pytest.raises(ValueError):
         MerlotModel(cfg, True, False, b['image'], b['input_ids'])                          # no params store
 
