@@ -1439,6 +1439,8 @@ int launch_persist(GemmNTArgs& a, int epilogue, int out_f32, int kind, hipStream
 // removed from the build; ids kept stable)
 using RingC = ring::Cfg<4, 2, 2, 4, 32, 4>;   // 256x256, BK 32, 4 stages, 128 KB, 8 waves
 using RingK = ring::Cfg<2, 4, 2, 2, 32, 3>;   // 128x256, BK 32, 3 stages, 72 KB (2 blocks/CU)
+using RingN64 = ring::Cfg<4, 1, 2, 2, 32, 3>;   // 256x64,  4 waves, 60 KB: narrow outputs (ResNet-stem 1x1 / 3x3 with 32..64 filters)
+using RingN128 = ring::Cfg<4, 1, 2, 4, 32, 3>;  // 256x128, 4 waves, 72 KB
 
 int nt_config_override() {
     static int v = -2;
@@ -1470,10 +1472,17 @@ int gemm_nt_dispatch(GemmNTArgs& a, int epilogue, int out_f32, bool patch, hipSt
             return e ? atoi(e) : 21;
         }();
         cfg = (tiles * 100 >= rounds * 256 * 85) ? persist_id : 11;
+        // narrow outputs (the ResNet-stem convolutions with 32..128 filters): a 256-wide tile would compute 2-8x the
+        // columns that exist; these launches are HBM-bound and reach ~5 TB/s on 256x64 / 256x128 tiles
+        // (scripts/exp_stem_gemm.py)
+        if (a.N <= 64 || (a.N <= 128 && a.K <= 512)) cfg = 14;
+        else if (a.N <= 128) cfg = 15;
     }
     switch (cfg) {
         case 3: return launch_ring<RingC>(a, epilogue, out_f32, s);
         case 11: return launch_ring<RingK>(a, epilogue, out_f32, s);
+        case 14: return launch_ring<RingN64>(a, epilogue, out_f32, s);
+        case 15: return launch_ring<RingN128>(a, epilogue, out_f32, s);
         case 20: return launch_persist(a, epilogue, out_f32, 0, s);
         case 21: return launch_persist(a, epilogue, out_f32, a.K / RingP::BK >= 4 ? 1 : 0, s);
         default: break;
