@@ -1,21 +1,21 @@
-// bf16 MFMA GEMMs for gfx950 (CDNA4): the NT form (activations x weights, dgrad) and the TN form
-// (weight gradients), plus the implicit-im2col patch-embed variants.
+// bf16 MFMA GEMMs for gfx950 (CDNA4): the NT form (activations x weights, dgrad) and the TN form (weight gradients).
+// See DESIGN.md 3.1 for the measurements behind every choice.
 //
-// Design (see DESIGN.md "GEMM"):
-//   * 128x128 block tile, BK = 64, 4 waves (2x2), each wave a 64x64 sub-tile = 2x2 MFMA 32x32x16 bf16
-//     accumulators (64 fp32 regs/lane).
-//   * LDS tile image: [128 rows][128 B] with the 16-byte chunk index XOR-swizzled by (row>>1)&7 so a
-//     ds_read_b128 lane group (16 lanes = 16 distinct rows mod 16, same chunk) hits 16 distinct 16-B slots.
-//   * NT operands are staged HBM->LDS by `global_load_lds_dwordx4` (no VGPR round trip); the swizzle is
-//     applied on the per-lane SOURCE address, the LDS destination stays lane-linear.  Two LDS buffers,
-//     tile t+1 streams in while tile t is multiplied; one barrier per K step.
-//   * the MFMA is issued with operands swapped (D[n][m] = sum_k Bt[n][k] A[m][k]) so every lane owns one
-//     output row m and 4 consecutive columns n per accumulator quad -> 8/16-byte epilogue stores.
-//   * TN (wgrad) stages through registers: each lane loads dwords (2 adjacent columns) of 8 consecutive
-//     reduction rows, transposes them in registers and writes the same swizzled LDS image.  Split-R over
-//     the grid with fp32 atomics fills the 256 CUs when M*N is only a few dozen tiles.
-//   * block -> tile map is XCD-aware: the 8 XCDs each walk a contiguous band of row tiles, all column
-//     tiles of a row tile adjacent, so an A row band is fetched from HBM once per XCD L2.
+// Kernels in this file
+//   gemm_nt_persist_dyn_kernel   production NT for large problems: persistent 256x256 tiles, 8 waves, BK 32, one
+//                                continuous 3-stage LDS-DMA ring across tiles, dynamic per-XCD tile claims, interior
+//                                tiles through fast_tile_epilogue (bias once per tile, prefetched auxiliary operand).
+//   gemm_nt_persist_kernel       same with static tile striding (K < 128, and the A/B reference for the claims).
+//   gemm_nt_ring_kernel<Cfg>     non-persistent ring kernel: 128x256 (ragged tile counts, 2 WG/CU), 256x64 and
+//                                256x128 (narrow outputs), 256x256 (experiments).
+//   gemm_tn_ring_kernel<Cfg>     wgrad: operands as stored ([R][M], [R][N]) through ds_read_b64_tr_b16, split-R
+//                                partials to a caller-owned workspace + tn_reduce_kernel (no atomics).
+//   gemm_nt_kernel / gemm_tn_kernel   first-generation 128x128, 2-buffer kernels: implicit-im2col patch embed
+//                                (gather in the LDS-DMA source address), tails and shapes the ring kernels refuse.
+// Common to all: v_mfma_f32_32x32x16_bf16 issued with swapped operands (a lane owns one output row and 4 consecutive
+// columns per accumulator quad), LDS tile images [rows][BK] with the 16-B chunk index XOR-swizzled (applied on the
+// per-lane SOURCE address of `global_load_lds_dwordx4`; the LDS destination stays lane-linear), counted
+// `s_waitcnt vmcnt(N)` + raw `s_barrier`, XCD-aware block -> tile maps, row-contiguous epilogues staged through LDS.
 #include <atomic>
 #include <cstdlib>
 
@@ -1072,19 +1072,6 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_dyn_kernel(const GemmNTAr
         const unsigned int t2 = (sq / (unsigned int)n_x) * (unsigned int)nwg + (unsigned int)band0 + sq % (unsigned int)n_x;
         return t2 < (unsigned int)ntiles ? (int)t2 : ntiles;
     };
-    // De-phase the workgroups.  Every tile costs the same, so workgroups launched together reach their epilogues
-    // together: 256 CUs then store 32 MiB at once, the stores back up behind HBM and every CU idles, after which HBM
-    // idles while every CU computes -- measured as "epilogue time == write time, nothing overlapped".  Starting the
-    // 8 workgroups that share a position modulo 8 within their XCD an eighth of a tile apart spreads the stores over
-    // the whole tile period (dynamic claims make the late starters simply take fewer tiles).
-    if (!(p.dbg & 64)) {
-        const int phase = ((int)blockIdx.x >> 3) & 7;
-        if (phase) {
-            const long long t0 = __builtin_amdgcn_s_memtime();
-            const long long wait = (long long)phase * nk * 150;      // ~1/8 tile: a K-step takes ~1200 clocks
-            while ((long long)__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
-        }
-    }
     bool claims_open = true;
     if (tid == 0) {
         const int c = claim();
@@ -1111,14 +1098,10 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_dyn_kernel(const GemmNTAr
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         for (int kt = 0; kt < nk; ++kt, ++g) {
-            if (ld_step - g == S - 1) {
-                if ((p.dbg & 16) && kt < 2 && tile != slot)
-                    ring::wait_vmcnt<63>();              // experiments: do not wait for the previous epilogue's stores
-                else
-                    ring::wait_vmcnt<(S - 2) * C::LOADS>();
-            } else {
+            if (ld_step - g == S - 1)
+                ring::wait_vmcnt<(S - 2) * C::LOADS>();
+            else
                 ring::wait_vmcnt<0>();
-            }
             __builtin_amdgcn_s_barrier();
             stage_next();
             const char* la = dsm + (g % S) * C::STAGE_BYTES;

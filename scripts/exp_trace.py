@@ -15,7 +15,7 @@ bias = torch.zeros(N, device=dev)
 aux = torch.empty(T, N, device=dev, dtype=torch.bfloat16)
 os.environ['MERLOT_NT_CFG_DYN'] = '21'
 TR = 32
-for name, dbg in (('staggered', 512), ('lock-step', 512 + 64)):
+for name, dbg in (('timeline', 512),):
     for epi in ('none', 'gelu'):
         fn = (lambda: ops.gemm_nt(a, b, bias=bias)) if epi == 'none' else \
             (lambda: ops.gemm_nt(a, b, bias=bias, epilogue=ops.EPI_GELU, aux_out=aux))
