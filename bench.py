@@ -49,10 +49,6 @@ def cpu_baseline_worker(threads):
     from oracle import merlot_oracle as mo
     torch.set_num_threads(threads)
     config = NeatConfig.from_yaml(os.path.join(ROOT, 'merlot_amd', 'configs', 'pretrain_4seg_224.yaml'))
-    train_gflop = TRAIN_GFLOP_PER_SEGMENT
-    if args.resnet_stem:
-        config.model['resnet_layers'] = [3, 4, 9]
-        train_gflop = TRAIN_GFLOP_PER_SEGMENT_RESNET
     cfg = dict(config.model)
     cfg['hidden_dropout_prob'] = 0.0
     w = mo.init_weights(cfg, 0, perturb=False)
@@ -84,6 +80,7 @@ def cpu_baseline_worker(threads):
 def cpu_baseline():
     """run the bounded CPU sample in a child with a hard timeout so the default bench run always ends in minutes."""
     import subprocess
+    why = 'oracle sample did not finish within the time bound on this host'
     for threads in (min(usable_cores(), 32), 8):
         try:
             out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', str(threads)],
@@ -91,10 +88,11 @@ def cpu_baseline():
             for line in reversed(out.stdout.strip().splitlines()):
                 if line.startswith('{'):
                     return json.loads(line)
+            if out.returncode != 0:                  # a crash must not masquerade as a timeout
+                why = 'oracle worker failed: ' + (out.stderr.strip().splitlines() or ['?'])[-1][:200]
         except subprocess.TimeoutExpired:
             continue
-    return {'value': None, 'unit': 'segments/s', 'cores': usable_cores(), 'kind': 'port',
-            'sample': 'oracle sample did not finish within the time bound on this host'}
+    return {'value': None, 'unit': 'segments/s', 'cores': usable_cores(), 'kind': 'port', 'sample': why}
 
 
 def measured_traffic():
