@@ -26,8 +26,7 @@ class AdamOptimizer(object):
     def __init__(self, store, learning_rate, num_train_steps, num_warmup_steps, weight_decay_rate=1e-4,
                  param_overrides=None, epsilon=1e-6, beta_1=0.9, beta_2=0.98, use_bfloat16_adam=False, clip_norm=0.0,
                  grad_reduce='sum', world_size=1, **_ignored):
-        if clip_norm and clip_norm > 0.0:
-            raise NotImplementedError("clip_norm > 0 is not implemented (merlot.yaml uses 0.0)")
+        self.clip_norm = float(clip_norm or 0.0)
         self.store = store
         self.lr, self.nts, self.nws = learning_rate, num_train_steps, num_warmup_steps
         self.eps, self.b1, self.b2 = epsilon, beta_1, beta_2
@@ -71,6 +70,17 @@ class AdamOptimizer(object):
                     if k[0] > 0:
                         flags[s_ // 64:e_ // 64] = 1
                 self._wd_flags = flags.to(store.device)
+
+    def clip_local_gradients(self):
+        """tf.clip_by_global_norm(grads, clip_norm) (utils/optimization.py:233-237): grads * clip / max(||grads||, clip),
+        applied to THIS replica's gradients BEFORE the cross-replica sum (the reference clips, then CrossShardOptimizer
+        reduces, :241-245) -- the trainer therefore defers the all-reduce until after this call when clip_norm > 0.
+        Returns the global norm (device scalar)."""
+        g = self.store.grad                                   # arena padding is zero: it does not change the norm
+        norm = torch.linalg.vector_norm(g, dtype=torch.float64).float()   # 2e8 addends: accumulate in fp64
+        if self.clip_norm > 0.0:
+            g.mul_(self.clip_norm / torch.clamp(norm, min=self.clip_norm))
+        return norm
 
     def current_lr(self):
         return self.lr * learning_rate_scale(self.step_count, self.nts, self.nws)

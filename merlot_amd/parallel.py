@@ -61,9 +61,12 @@ class DistContext(object):
 class GradReducer(object):
     """Bucketed, overlapped all-reduce of the ParamStore gradient arena."""
 
-    def __init__(self, store, ctx, expected_passes=None):
+    def __init__(self, store, ctx, expected_passes=None, defer=False):
+        """defer=True: nothing is launched from inside the backward; `finish()` reduces the whole arena (needed when the
+        local gradients are clipped by their global norm before the cross-replica sum, utils/optimization.py:233-245)."""
         self.store = store
         self.ctx = ctx
+        self.defer = defer
         self.expected = dict(expected_passes or {})
         self._seen = {}
         self._done = []          # [(start, end)]
@@ -82,7 +85,7 @@ class GradReducer(object):
         return r
 
     def _on_ready(self, group):
-        if self.ctx.world_size == 1 and not FORCE:
+        if self.defer or (self.ctx.world_size == 1 and not FORCE):
             return
         c = self._seen.get(group, 0) + 1
         self._seen[group] = c

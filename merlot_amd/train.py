@@ -53,7 +53,8 @@ class Trainer(object):
         if dist_ctx is not None and (world > 1 or FORCE):
             # encoder weights receive gradients from the joint AND the text-only pass before they may be reduced
             self.reducer = GradReducer(self.store, dist_ctx,
-                                       expected_passes={'encoder': 2, 'encoder/LayerNorm_ln_final': 2, '*': 1})
+                                       expected_passes={'encoder': 2, 'encoder/LayerNorm_ln_final': 2, '*': 1},
+                                       defer=self.opt.clip_norm > 0.0)
         self.step_idx = 0
 
     def forward_only(self, features):
@@ -66,6 +67,8 @@ class Trainer(object):
         self.store.zero_grad()
         out = self.model_fn(features, None, 'train', {'store': self.store, 'dist': self.dist, 'seed': self.step_idx + 1})
         out['loss'].backward()
+        if self.opt.clip_norm > 0.0:                         # clip the local gradients, then sum across replicas
+            out['grad_norm'] = self.opt.clip_local_gradients()
         if self.reducer is not None:
             self.reducer.finish()
         self.opt.step()

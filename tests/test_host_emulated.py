@@ -235,3 +235,24 @@ def test_resnet_hybrid_stem_autograd_wiring_exact_in_fp32(emu, monkeypatch):
     for k, v in w.items():
         if v.grad is not None:
             assert rel_l2(gt[k], v.grad) < 2e-3, (k, rel_l2(gt[k], v.grad))
+
+
+def test_clip_by_global_norm_matches_reference_rule():
+    """utils/optimization.py:233-237 (tf.clip_by_global_norm): g * clip / max(||g||, clip) over ALL gradients at once."""
+    from merlot_amd import ParamStore
+    from merlot_amd.optimization import AdamOptimizer
+    cfg = tiny_config()
+    st = ParamStore(cfg, 'cpu', seed=0)
+    g = torch.Generator().manual_seed(5)
+    for scale, clip in ((3.0, 1.0), (1e-4, 1.0)):
+        for name in st.names():
+            st.g(name).copy_(torch.randn(st.g(name).shape, generator=g) * scale)
+        ref = {n: st.g(n).clone() for n in st.names()}
+        norm_ref = float(np.sqrt(sum(float((v.double() ** 2).sum()) for v in ref.values())))
+        opt = AdamOptimizer.__new__(AdamOptimizer)
+        opt.store, opt.clip_norm = st, clip
+        norm = float(opt.clip_local_gradients())
+        assert abs(norm - norm_ref) < 1e-4 * norm_ref
+        factor = clip / max(norm_ref, clip)
+        for n in st.names():
+            assert torch.allclose(st.g(n), ref[n] * factor, rtol=1e-5, atol=1e-8), n
