@@ -39,7 +39,7 @@ def main():
         a, b = rnd(T, M), rnd(T, N)
         out = torch.zeros((M, N), device='cuda')
         t = timeit(lambda: ops.gemm_tn(a, b, out, accumulate=True))
-        print(f"gemm_tn {name:6s} M={M} N={N} R={T}: {t*1e6:8.1f} us  {2*T*N*M/t/1e12:7.1f} TF (atomics)")
+        print(f"gemm_tn {name:6s} M={M} N={N} R={T}: {t*1e6:8.1f} us  {2*T*N*M/t/1e12:7.1f} TF")
     # attention
     for (B, S, nm) in [(seg, 198, 'vit'), (seg // 4, 328, 'joint'), (seg // 16, 512, 'text')]:
         qkv = rnd(B * S, 2304)
