@@ -505,9 +505,38 @@ __device__ __forceinline__ void staged_epilogue(const GemmNTArgs& p, f32x16 (&ac
     constexpr int RSTRIDE = COLS * 4 + 16;           // +16 B: the 8 rows of a ds_write_b128 lane group tile all 32 banks
     constexpr int LPR = COLS / 8;                    // lanes per row in the row-contiguous phase
     constexpr int RPP = 64 / LPR;                    // rows per pass
+    constexpr int PPB = 32 / RPP;                    // passes per 32-row block
+    constexpr int NPASS = C::FM * PPB;
+    constexpr bool HAS_AUX = (EPI == MERLOT_EPI_RESIDUAL) || (EPI == MERLOT_EPI_DGELU);
     const int hi = lane >> 5;
+    const int rr = lane / LPR, c0 = (lane % LPR) * 8;
+    const int n = n_base + c0;                       // this lane's 8 columns, the same in every pass
     const bool aligned = ((p.ldc & 7) == 0) && ((p.ld_aux_in & 7) == 0) && ((p.ld_aux_out & 7) == 0) &&
-                         ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0);
+                         ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) && ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(p.aux_in) & 15) == 0) && ((reinterpret_cast<uintptr_t>(p.aux_out) & 15) == 0);
+    // fast path (wave-uniform): every row and column of this wave's slab exists and every operand is 16-B aligned.
+    // Then nothing below waits on a fresh global load: bias is read once, the auxiliary operand of ALL passes is
+    // requested up front (the old code re-loaded bias after every store -- it may alias C -- and loaded each auxiliary
+    // row segment where it was consumed: one dependent L2/HBM round trip per pass).
+    const bool fast = aligned && !(p.N & 1) && !(OUT_F32 && p.accumulate) && m_base + C::FM * 32 <= p.M &&
+                      n_base + COLS <= p.N && NPASS <= 16;
+    f32x4 b0, b1;
+    bf16x8 aux[NPASS <= 16 ? NPASS : 1];
+    if (fast) {
+        if (p.bias) {
+            b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
+            b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b0[e] = b1[e] = 0.f;
+        }
+        if (HAS_AUX) {
+#pragma unroll
+            for (int q = 0; q < NPASS; ++q)
+                aux[q] = *reinterpret_cast<const bf16x8*>(p.aux_in + (int64_t)(m_base + (q / PPB) * 32 + (q % PPB) * RPP + rr) * p.ld_aux_in + n);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
 #pragma unroll
     for (int fi = 0; fi < C::FM; ++fi) {
         // phase 1: accumulators -> LDS slab [32 rows][COLS] fp32
@@ -525,13 +554,66 @@ __device__ __forceinline__ void staged_epilogue(const GemmNTArgs& p, f32x16 (&ac
         __builtin_amdgcn_wave_barrier();
         // phase 2: row segments
 #pragma unroll
-        for (int ps = 0; ps < 32 / RPP; ++ps) {
-            const int r = ps * RPP + lane / LPR;
-            const int c0 = (lane % LPR) * 8;
+        for (int ps = 0; ps < PPB; ++ps) {
+            const int r = ps * RPP + rr;
             const int m = m_base + fi * 32 + r;
-            const int n = n_base + c0;
             const f32x4 x0 = *reinterpret_cast<const f32x4*>(stage + r * RSTRIDE + c0 * 4);
             const f32x4 x1 = *reinterpret_cast<const f32x4*>(stage + r * RSTRIDE + c0 * 4 + 16);
+            if (fast) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = x0[e] + b0[e];
+                    v[4 + e] = x1[e] + b1[e];
+                }
+                if (EPI == MERLOT_EPI_GELU) {
+                    if (p.aux_out) {
+                        bf16x8 u8;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) u8[e] = (bf16)v[e];
+                        *reinterpret_cast<bf16x8*>(p.aux_out + (int64_t)m * p.ld_aux_out + n) = u8;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) gelu_fast2(v[e], v[e + 1]);
+                } else if (EPI == MERLOT_EPI_DGELU) {
+                    const bf16x8 u8 = aux[fi * PPB + ps];
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        float g0, g1;
+                        gelu_grad_fast2((float)u8[e], (float)u8[e + 1], g0, g1);
+                        v[e] *= g0;
+                        v[e + 1] *= g1;
+                    }
+                } else if (EPI == MERLOT_EPI_RESIDUAL) {
+                    if (p.drop_thresh) {
+                        bool keep[8];
+                        dropout_keep_n<8>(p.drop_seed, (uint64_t)m * (uint64_t)p.N + (uint64_t)n, p.drop_thresh, keep);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = keep[e] ? v[e] * p.drop_scale : 0.f;
+                    }
+                    const bf16x8 r8 = aux[fi * PPB + ps];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
+                }
+                if (OUT_F32) {
+                    float* c = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n;
+                    f32x4 o0, o1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o0[e] = v[e];
+                        o1[e] = v[4 + e];
+                    }
+                    *reinterpret_cast<f32x4*>(c) = o0;
+                    *reinterpret_cast<f32x4*>(c + 4) = o1;
+                } else {
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+                    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + n) = o;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                continue;
+            }
             if (m >= p.M || n >= p.N) continue;
             float v[8];
 #pragma unroll
@@ -542,13 +624,7 @@ __device__ __forceinline__ void staged_epilogue(const GemmNTArgs& p, f32x16 (&ac
             if (aligned && n + 7 < p.N) {
                 epilogue_row8<EPI, OUT_F32>(p, m, n, v);
             } else {                                  // ragged right edge / unaligned leading dims: per-quad path
-                float q0[4] = {v[0] / p.alpha, v[1] / p.alpha, v[2] / p.alpha, v[3] / p.alpha};
-                float q1[4] = {v[4] / p.alpha, v[5] / p.alpha, v[6] / p.alpha, v[7] / p.alpha};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    q0[e] = x0[e];
-                    q1[e] = x1[e];
-                }
+                float q0[4] = {x0[0], x0[1], x0[2], x0[3]}, q1[4] = {x1[0], x1[1], x1[2], x1[3]};
                 const bool vec_ok = ((p.ldc & 3) == 0) && ((p.ld_aux_in & 3) == 0) && ((p.ld_aux_out & 3) == 0);
                 nt_epilogue_quad<EPI, OUT_F32>(p, m, n, q0, vec_ok);
                 if (n + 4 < p.N) nt_epilogue_quad<EPI, OUT_F32>(p, m, n + 4, q1, vec_ok);
