@@ -127,6 +127,11 @@ int merlot_cast_f32_bf16(const float* src, void* dst, int64_t n, merlot_stream_t
 /* dst[C, ld_dst] (bf16) : dst[c, r] = src[r, c] for the f32 matrix src[R,C]; ld_dst >= R */
 int merlot_cast_transpose_f32_bf16(const float* src, void* dst, int64_t R, int64_t C, int64_t ld_dst,
                                    merlot_stream_t stream);
+/* the same for many matrices in one launch.  jobs: device int64 [njobs][6] = {src offset (elements from src_base), dst
+ * offset (elements from dst_base), R, C, ld_dst, index of the job's first 64x64 tile}, sorted by first tile;
+ * total_tiles = sum over jobs of ceil(R/64)*ceil(C/64). */
+int merlot_cast_transpose_batched(const float* src_base, void* dst_base, const void* jobs, int njobs,
+                                  int64_t total_tiles, merlot_stream_t stream);
 /* out[N] (+)= sum_t x[t, n]   (bias gradients) ; x bf16 */
 int merlot_colsum_bf16(const void* x, int64_t ld, float* out, int64_t T, int64_t N, int accumulate,
                        merlot_stream_t stream);

@@ -43,6 +43,37 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
     }
 }
 
+// many transposes in ONE launch: job j = {src offset, dst offset, R, C, ld_dst, first tile}; a block finds its job in
+// the (short) table by binary search on the first-tile column.  Used for the per-step refresh of every Linear's
+// transposed bf16 copy (~130 matrices: one launch instead of 130 launch latencies).
+__global__ __launch_bounds__(256) void cast_transpose_batched_kernel(const float* __restrict__ src_base, bf16* __restrict__ dst_base,
+                                                                     const int64_t* __restrict__ jobs, int njobs) {
+    __shared__ float tile[64][65];
+    int lo = 0, hi = njobs - 1;
+    const int64_t b = blockIdx.x;
+    while (lo < hi) {                                    // last job whose first tile <= b
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid * 6 + 5] <= b) lo = mid; else hi = mid - 1;
+    }
+    const int64_t* j = jobs + lo * 6;
+    const float* src = src_base + j[0];
+    bf16* dst = dst_base + j[1];
+    const int64_t R = j[2], C = j[3], ld_dst = j[4];
+    const int64_t t = b - j[5];
+    const int64_t tiles_c = (C + 63) / 64;
+    const int64_t r0 = (t / tiles_c) * 64, c0 = (t % tiles_c) * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int64_t r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? src[r * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int64_t c = c0 + i, r = r0 + tx;
+        if (c < C && r < R) dst[c * ld_dst + r] = (bf16)tile[tx][i];
+    }
+}
+
 // ---- bias gradient: out[n] (+)= sum_t x[t][n] ------------------------------------------------------
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x, int64_t ld, float* __restrict__ out,
                                                      int64_t T, int64_t N, int64_t rows_per_block) {
@@ -386,6 +417,15 @@ extern "C" int merlot_cast_transpose_f32_bf16(const float* src, void* dst, int64
     hipLaunchKernelGGL(cast_transpose_kernel, dim3(cdiv(C, 64), cdiv(R, 64)), dim3(256), 0, STREAM, src, (bf16*)dst, R, C,
                        ld_dst);
     return merlot_launch_status("merlot_cast_transpose_f32_bf16");
+}
+
+extern "C" int merlot_cast_transpose_batched(const float* src_base, void* dst_base, const void* jobs, int njobs,
+                                             int64_t total_tiles, merlot_stream_t stream) {
+    MERLOT_CHECK(src_base && dst_base && jobs && njobs > 0 && total_tiles > 0 && total_tiles < (1ll << 31), MERLOT_ESHAPE,
+                 "merlot_cast_transpose_batched: bad args");
+    hipLaunchKernelGGL(cast_transpose_batched_kernel, dim3((unsigned)total_tiles), dim3(256), 0, STREAM, src_base, (bf16*)dst_base,
+                       (const int64_t*)jobs, njobs);
+    return merlot_launch_status("merlot_cast_transpose_batched");
 }
 
 extern "C" int merlot_colsum_bf16(const void* x, int64_t ld, float* out, int64_t T, int64_t N, int accumulate,

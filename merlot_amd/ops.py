@@ -199,6 +199,12 @@ def cast_transpose_bf16(src, dst=None, ld_dst=None):
     return dst
 
 
+def cast_transpose_batched(src_base, dst_base, jobs, total_tiles):
+    """jobs: device int64 [n, 6] (see include/merlot_hip.h); one launch for all transposed bf16 copies."""
+    _chk(src_base, F32, 'src_base'); _chk(dst_base, BF16, 'dst_base'); _chk(jobs, torch.int64, 'jobs')
+    call('merlot_cast_transpose_batched', _p(src_base), _p(dst_base), _p(jobs), jobs.shape[0], int(total_tiles), _stream())
+
+
 def colsum_bf16(x, out, accumulate=True, n=None):
     _chk(x, BF16, 'x'); _chk(out, F32, 'out')
     T = x.shape[0]

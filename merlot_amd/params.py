@@ -137,7 +137,8 @@ class ParamStore(object):
         self.master = torch.zeros(off, device=self.device, dtype=torch.float32)
         self.grad = torch.zeros(off, device=self.device, dtype=torch.float32)
         self.bf16 = torch.zeros(off, device=self.device, dtype=torch.bfloat16)
-        self._t = {}            # name -> bf16 transposed copy
+        self._tflat = self._tjobs = None      # flat buffer of transposed bf16 copies + device job table
+        self._ttiles = self._tjobs_n = 0
         self._lins = {}
         self._lns = {}
         self.version = -1       # bumped by refresh(); compared with master_version
@@ -189,31 +190,42 @@ class ParamStore(object):
 
     # ---- bf16 working copies -------------------------------------------------------------------------
     def refresh(self, force=False):
-        """Re-derive every bf16 working copy from the fp32 masters (call after each optimizer step)."""
+        """Re-derive every bf16 working copy from the fp32 masters (call after each optimizer step): one cast launch for
+        the whole arena and ONE batched transpose launch for the transposed copies of all registered Linears."""
         if self.version == self.master_version and not force:
             return
         ops.cast_bf16(self.master, self.bf16)
-        for name, lin in self._lins.items():
-            self._make_transposed(name, lin)
+        if self._lins:
+            if self._tjobs is None or self._tjobs_n != len(self._lins):
+                self._build_transpose_jobs()
+            ops.cast_transpose_batched(self.master, self._tflat, self._tjobs, self._ttiles)
         self.version = self.master_version
 
+    def _t_shape(self, name):
+        out_dim, in_dim = self.offsets[name][2]
+        ld = _align(out_dim, 128) if name == 'word_embeddings/word_embeddings' else out_dim   # padded reduction dim (LM-head dgrad)
+        return in_dim, out_dim, ld
+
+    def _build_transpose_jobs(self):
+        """flat bf16 buffer holding every transposed copy + the device job table of merlot_cast_transpose_batched."""
+        rows, off, tiles = [], 0, 0
+        views = {}
+        for name in self._lins:
+            in_dim, out_dim, ld = self._t_shape(name)
+            views[name] = (off, in_dim, ld)
+            rows.append([self.offsets[name][0], off, out_dim, in_dim, ld, tiles])
+            tiles += ((out_dim + 63) // 64) * ((in_dim + 63) // 64)
+            off += _align(in_dim * ld, 64)
+        self._tflat = torch.zeros(off, device=self.device, dtype=torch.bfloat16)
+        self._tjobs = torch.tensor(rows, dtype=torch.int64).to(self.device)
+        self._ttiles, self._tjobs_n = tiles, len(self._lins)
+        for name, (o, in_dim, ld) in views.items():
+            self._lins[name].wbT = self._tflat[o:o + in_dim * ld].view(in_dim, ld)
+
     def _make_transposed(self, name, lin):
-        w = self.p(name)
-        out_dim, in_dim = w.shape
-        if name == 'word_embeddings/word_embeddings':
-            vpad = _align(out_dim, 128)                      # padded reduction dim for the LM-head dgrad
-            t = self._t.get(name)
-            if t is None:
-                t = torch.zeros((in_dim, vpad), device=self.device, dtype=torch.bfloat16)
-                self._t[name] = t
-            ops.cast_transpose_bf16(w, t, ld_dst=vpad)
-        else:
-            t = self._t.get(name)
-            if t is None:
-                t = torch.empty((in_dim, out_dim), device=self.device, dtype=torch.bfloat16)
-                self._t[name] = t
-            ops.cast_transpose_bf16(w, t)
-        lin.wbT = t
+        """a Linear registered after the last refresh: rebuild the table (rare) and fill every copy."""
+        self._build_transpose_jobs()
+        ops.cast_transpose_batched(self.master, self._tflat, self._tjobs, self._ttiles)
 
     def lin(self, scope, need_T=True, bias=True):
         """Linear handle for `<scope>/kernel` (+ `<scope>/bias`)."""

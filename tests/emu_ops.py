@@ -411,11 +411,16 @@ def avgpool2_bwd(dy):
     return (0.25 * dy.float()).repeat_interleave(2, 1).repeat_interleave(2, 2).to(BF16)
 
 
+def cast_transpose_batched(src_base, dst_base, jobs, total_tiles):
+    for so, do, R, C, ld, _ in jobs.tolist():
+        dst_base[do:do + C * ld].view(C, ld)[:, :R] = src_base[so:so + R * C].view(R, C).t().to(BF16)
+
+
 _NAMES = ['gemm_nt', 'gemm_tn', 'patch_embed_fwd', 'patch_embed_wgrad', 'ln_fwd', 'ln_bwd', 'attention_fwd',
           'attention_bwd', 'attention_colsum', 'cast_bf16', 'cast_transpose_bf16', 'colsum_bf16', 'gather_add4',
           'scatter_add_rows', 'dropout_apply', 'cls_avgpool_fwd', 'cls_avgpool_bwd', 'softmax_ce', 'l2norm_fwd',
           'l2norm_bwd', 'gelu_fwd', 'gelu_bwd', 'mask_inputs', 'temporal_labels', 'shuffled_idx', 'im2col3x3', 'col2im3x3',
-          'groupnorm_fwd', 'groupnorm_bwd', 'avgpool2_fwd', 'avgpool2_bwd']
+          'groupnorm_fwd', 'groupnorm_bwd', 'avgpool2_fwd', 'avgpool2_bwd', 'cast_transpose_batched']
 
 
 def install(monkeypatch):
