@@ -178,11 +178,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
             tile_load_regs<64>(vbase, p.ld, (kt + 1) * 64, S - 1, vreg, tid);
         }
         if (!wave_active) continue;
+        // keys kt*64+32 .. kt*64+63 all beyond S (e.g. S = 198: the last tile holds 6 keys): skip that half entirely
+        const bool half = kt * 64 + 32 >= S;
 
         f32x16 st[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             st[kb] = zero16();
+            if (kb == 1 && half) continue;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ldsK + h2_off(64, kb * 32 + (lane & 31), 2 * kk + hi));
@@ -192,7 +195,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
         float mloc = -INFINITY;
         if (ragged) {
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb) {
+                if (kb == 1 && half) continue;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + kb * 32 + 8 * g);
@@ -203,6 +207,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
                         mloc = fmaxf(mloc, t);
                     }
                 }
+            }
         } else {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -227,24 +232,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
         float lsum = 0.f;
         bf16x8 pf[2][2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < 2; ++kb) {
+            if (kb == 1 && half) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float pv = fast_exp2(st[kb][r] - m_run);
                 lsum += pv;
                 pf[kb][r >> 3][r & 7] = (bf16)pv;
             }
+        }
         lsum += __shfl_xor(lsum, 32, 64);
         l_run += lsum;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb) {
+                if (kb == 1 && half) continue;
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
                     const bf16x8 vf = tr_frag<64>(ldsV, kb * 32 + hf * 16 + 4 * hi, db * 32, lane);
                     o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][hf], o[db], 0, 0, 0);
                 }
+            }
     }
 
     if (wave_active && qw0 + (lane & 31) < S) {
