@@ -360,10 +360,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
             tile_load_regs<64>(vbase, p.ld, (kt + 1) * 64, S - 1, vreg, tid);
         }
         if (!wave_active) continue;
+        const bool half = kt * 64 + 32 >= S;         // second 32 keys of this tile all beyond S: skip them
 
         bf16x8 dsf[2][2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
+            if (kb == 1 && half) continue;
             f32x16 st = zero16(), dp = zero16();
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
@@ -392,12 +394,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb) {
+                if (kb == 1 && half) continue;
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
                     const bf16x8 ktf = tr_frag<64>(ldsK, kb * 32 + hf * 16 + 4 * hi, db * 32, lane);
                     dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf[kb][hf], dq[db], 0, 0, 0);
                 }
+            }
     }
     if (wave_active && qw0 + (lane & 31) < S) {
         bf16* drow = p.dqkv + ((int64_t)b * S + q) * p.lddqkv + h * 64;
@@ -480,8 +484,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs p)
             tile_load_regs<64>(dobase, p.lddo, (qt + 1) * 64, S - 1, oreg, tid);
         }
         if (!wave_active) continue;
+        const bool half = qt * 64 + 32 >= S;         // second 32 queries of this tile all beyond S: skip them
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
+            if (qb == 1 && half) continue;
             f32x16 st = zero16(), dp = zero16();
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
