@@ -68,16 +68,19 @@ int merlot_gemm_bf16_tn(const void* A, int64_t lda, const void* B, int64_t ldb, 
                         int64_t M, int64_t N, int64_t R, float alpha, int accumulate, void* workspace,
                         int64_t workspace_bytes, merlot_stream_t stream);
 
-/* Patch-embed 16x16/16 conv as an implicit-im2col GEMM (utils/vision_transformer.py:193-205).
- * image: bf16 NHWC [n_img, H, W, 3] in [0,1]; Wt: bf16 [hidden, P*P*3] with k=(py,px,c);
- * bias_folded: f32 [hidden] = conv bias - 0.5*sum_k W (the `image - 0.5`, :193, folded);
- * out: bf16 [n_img*(H/P)*(W/P), hidden]. */
-int merlot_patch_embed_fwd(const void* image, int n_img, int H, int W, int P, const void* Wt, const float* bias_folded,
-                           void* out, int hidden, merlot_stream_t stream);
-/* dWt[hidden, P*P*3] (f32) (+)= sum_rows dY[row, hidden] * patch[row, k]  (raw pixel values; the caller
- * subtracts 0.5 * colsum(dY)[hidden] for the `image - 0.5` shift).  dY bf16. */
-int merlot_patch_embed_wgrad(const void* image, int n_img, int H, int W, int P, const void* dY, float* dWt,
-                             int hidden, int accumulate, merlot_stream_t stream);
+/* Patch-embed 16x16/16 conv (utils/vision_transformer.py:193-205) as im2col + MFMA GEMM.
+ * image: bf16 NHWC [n_img, H, W, 3] in [0,1]; patches: bf16 [n_img*(H/P)*(W/P), P*P*3], k = (py,px,c) = HWIO flattening,
+ * value = pixel + shift (the `image - 0.5` of :193 is applied here). */
+int merlot_im2col_patches(const void* image, void* patches, int n_img, int H, int W, int P, float shift,
+                          merlot_stream_t stream);
+/* out[rows, hidden] (bf16) = patches(image - 0.5) . Wt^T + bias.  Wt: bf16 [hidden, P*P*3]; `patches` is a caller-owned
+ * buffer (see above) that this call FILLS and the weight gradient re-uses. */
+int merlot_patch_embed_fwd(const void* image, int n_img, int H, int W, int P, const void* Wt, const float* bias,
+                           void* patches, void* out, int hidden, merlot_stream_t stream);
+/* dWt[hidden, K] (f32) (+)= sum_rows dY[row, hidden] * patches[row, k]  (K = P*P*3; workspace as for
+ * merlot_gemm_bf16_tn(hidden, K, rows)). */
+int merlot_patch_embed_wgrad(const void* patches, int64_t rows, int K, const void* dY, float* dWt, int hidden,
+                             int accumulate, void* workspace, int64_t workspace_bytes, merlot_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm (utils/model_utils.py:113-130): fp32 statistics, population variance, eps inside rsqrt.

@@ -57,6 +57,29 @@ __global__ __launch_bounds__(256) void im2col3x3_kernel(const bf16* __restrict__
     }
 }
 
+// ---- patch im2col: out[(n,ph,pw)][(py,px,c)] = image[n][ph*P+py][pw*P+px][c] + shift, non-overlapping PxP patches ----------
+// (utils/vision_transformer.py:193-205: `image - 0.5`, 16x16/16 VALID conv; k order = HWIO flattening).  A patch row is
+// P segments of 3P contiguous bf16 (96 B at P = 16): one lane moves 16 B.
+__global__ __launch_bounds__(256) void im2col_patch_kernel(const bf16* __restrict__ img, bf16* __restrict__ out, int N, int H,
+                                                          int W, int P, int h1, int w1, float shift) {
+    const int seg = 3 * P / 8;                            // 16-B chunks per patch row segment (6 at P = 16)
+    const int cpr = P * seg;                              // chunks per output row
+    const int64_t total = (int64_t)N * h1 * w1 * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / cpr;
+        const int ch = (int)(i - row * cpr);
+        const int py = ch / seg, cx = ch - py * seg;
+        const int pw = (int)(row % w1), ph = (int)((row / w1) % h1);
+        const int64_t n = row / ((int64_t)w1 * h1);
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(img + ((n * H + ph * P + py) * W + pw * P) * 3 + cx * 8);
+        if (shift != 0.f) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] + shift);
+        }
+        *reinterpret_cast<bf16x8*>(out + row * (3 * P * P) + py * 3 * P + cx * 8) = v;
+    }
+}
+
 // ---- col2im (input gradient of the 3x3 convolution): dx[n][y][x][c] = sum over taps of dP[(n,yo,xo)][(ky,kx,c)] ----------
 __global__ __launch_bounds__(256) void col2im3x3_kernel(const bf16* __restrict__ dp, bf16* __restrict__ dx, int N, int H,
                                                         int W, int C, int s, int Ho, int Wo, int Kp) {
@@ -318,6 +341,20 @@ extern "C" int merlot_im2col3x3(const void* x, void* out, int N, int H, int W, i
     hipLaunchKernelGGL(im2col3x3_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)out,
                        N, H, W, C, stride, Ho, Wo, Kp, shift);
     return merlot_launch_status("merlot_im2col3x3");
+}
+
+extern "C" int merlot_im2col_patches(const void* image, void* patches, int n_img, int H, int W, int P, float shift,
+                                     merlot_stream_t stream) {
+    MERLOT_CHECK(image && patches && n_img > 0, MERLOT_ESHAPE, "merlot_im2col_patches: null operand");
+    MERLOT_CHECK(P == 16, MERLOT_ESHAPE, "patch embed: only patch_size 16 is supported (got %d)", P);
+    MERLOT_CHECK(H % P == 0 && W % P == 0, MERLOT_ESHAPE, "patch embed: H, W must be multiples of P");
+    MERLOT_CHECK((W * 3) % 8 == 0 && (reinterpret_cast<uintptr_t>(image) & 15) == 0, MERLOT_EALIGN,
+                 "patch embed: W*3 must be a multiple of 8 and the image 16-B aligned");
+    const int h1 = H / P, w1 = W / P;
+    const int64_t total = (int64_t)n_img * h1 * w1 * P * (3 * P / 8);
+    hipLaunchKernelGGL(im2col_patch_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)image,
+                       (bf16*)patches, n_img, H, W, P, h1, w1, shift);
+    return merlot_launch_status("merlot_im2col_patches");
 }
 
 extern "C" int merlot_col2im3x3(const void* x, void* dx, int N, int H, int W, int C, int stride, int Kp, merlot_stream_t stream) {

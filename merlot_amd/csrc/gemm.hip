@@ -10,8 +10,7 @@
 //                                256x128 (narrow outputs), 256x256 (experiments).
 //   gemm_tn_ring_kernel<Cfg>     wgrad: operands as stored ([R][M], [R][N]) through ds_read_b64_tr_b16, split-R
 //                                partials to a caller-owned workspace + tn_reduce_kernel (no atomics).
-//   gemm_nt_kernel / gemm_tn_kernel   first-generation 128x128, 2-buffer kernels: implicit-im2col patch embed
-//                                (gather in the LDS-DMA source address), tails and shapes the ring kernels refuse.
+//   gemm_nt_kernel / gemm_tn_kernel   first-generation 128x128, 2-buffer kernels: tails and shapes the ring kernels refuse.
 // Common to all: v_mfma_f32_32x32x16_bf16 issued with swapped operands (a lane owns one output row and 4 consecutive
 // columns per accumulator quad), LDS tile images [rows][BK] with the 16-B chunk index XOR-swizzled (applied on the
 // per-lane SOURCE address of `global_load_lds_dwordx4`; the LDS destination stays lane-linear), counted
@@ -28,10 +27,6 @@ constexpr int BM = 128;
 constexpr int BN = 128;
 constexpr int BK = 64;
 constexpr int TILE_BYTES = 128 * 128;  // 128 rows x 64 bf16
-
-struct PatchGeom {
-    int H, W, P, h1, w1;  // image height/width, patch, grid
-};
 
 struct GemmNTArgs {
     const bf16* A;
@@ -51,7 +46,6 @@ struct GemmNTArgs {
     int accumulate;
     int ntm, ntn;
     int dbg;              // experiments only: 1 = skip epilogue, 2 = skip main loop
-    PatchGeom pg;
 };
 
 struct GemmTNArgs {
@@ -64,7 +58,6 @@ struct GemmTNArgs {
     int use_atomics;
     int ntm, ntn, splits, rchunk;
     int dbg;
-    PatchGeom pg;
 };
 
 // XCD-aware bijective remap: hardware places block b on XCD b % 8; give each XCD a contiguous id range.
@@ -74,20 +67,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-// element offset of patch-matrix entry (row, k) inside the NHWC bf16 image; k = (py, px, c), P == 16.
-__device__ __forceinline__ int64_t patch_row_base(const PatchGeom& g, int row) {
-    const int per_img = g.h1 * g.w1;
-    const int n = row / per_img;
-    const int rem = row - n * per_img;
-    const int ph = rem / g.w1;
-    const int pw = rem - ph * g.w1;
-    return ((int64_t)(n * g.H + ph * g.P) * g.W + pw * g.P) * 3;
-}
-__device__ __forceinline__ int patch_k_off(const PatchGeom& g, int k) {
-    const int run = g.P * 3;  // 48 contiguous elements per patch row
-    const int py = k / run;
-    return py * g.W * 3 + (k - py * run);
-}
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + (((chunk ^ (row >> 1)) & 7) << 4); }
 
@@ -198,7 +177,7 @@ __device__ __forceinline__ void nt_epilogue_quad(const GemmNTArgs& p, int m, int
 // ------------------------------------------------------------------------------------------------
 // NT kernel
 // ------------------------------------------------------------------------------------------------
-template <int EPI, bool OUT_F32, bool PATCH>
+template <int EPI, bool OUT_F32>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNTArgs p) {
     __shared__ __attribute__((aligned(1024))) char smem[4 * TILE_BYTES];
     const int tid = threadIdx.x;
@@ -212,20 +191,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNTArgs p) {
     // ---- per-lane staging sources: 4 x 1 KiB pieces of the A tile and of the B tile per wave
     const bf16* a_src[4];
     const bf16* b_src[4];
-    int a_chunk[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = (wave * 4 + i) * 8 + (lane >> 3);
         const int chunk = ((lane & 7) ^ (row >> 1)) & 7;  // logical chunk stored at physical slot lane&7
         const int ga = min(m0 + row, p.M - 1);
         const int gb = min(n0 + row, p.N - 1);
-        if (PATCH) {
-            a_src[i] = p.A + patch_row_base(p.pg, ga);
-            a_chunk[i] = chunk * 8;
-        } else {
-            a_src[i] = p.A + (int64_t)ga * p.lda + chunk * 8;
-            a_chunk[i] = 0;
-        }
+        a_src[i] = p.A + (int64_t)ga * p.lda + chunk * 8;
         b_src[i] = p.B + (int64_t)gb * p.ldb + chunk * 8;
     }
 
@@ -234,10 +206,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNTArgs p) {
         char* lb = la + TILE_BYTES;
         const int k0 = kt * BK;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bf16* sa = PATCH ? a_src[i] + patch_k_off(p.pg, k0 + a_chunk[i]) : a_src[i] + k0;
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(sa), LDS_PTR(la + i * 1024), 16, 0, 0);
-        }
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(a_src[i] + k0), LDS_PTR(la + i * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_global_load_lds(GLOBAL_PTR(b_src[i] + k0), LDS_PTR(lb + i * 1024), 16, 0, 0);
@@ -294,7 +264,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNTArgs p) {
 // ------------------------------------------------------------------------------------------------
 // TN kernel (weight gradients): C[m][n] += alpha * sum_r A[r][m] B[r][n]
 // ------------------------------------------------------------------------------------------------
-template <bool PATCH_B>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTNArgs p) {
     __shared__ __attribute__((aligned(1024))) char smem[4 * TILE_BYTES];
     const int tid = threadIdx.x;
@@ -315,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTNArgs p) {
     const int am = min(m0 + 2 * lane, p.M - 2);
     const int bn = min(n0 + 2 * lane, p.N - 2);
     const bf16* a_col = p.A + am;
-    const bf16* b_col = PATCH_B ? p.B + patch_k_off(p.pg, bn) : p.B + bn;
+    const bf16* b_col = p.B + bn;
 
     uint32_t xa[2][8], xb[2][8];
     auto load = [&](int st) {
@@ -327,8 +296,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTNArgs p) {
                 const int r = r0 + i;
                 if (r < r_end) {
                     xa[g][i] = *reinterpret_cast<const uint32_t*>(a_col + (int64_t)r * p.lda);
-                    const bf16* bp = PATCH_B ? b_col + patch_row_base(p.pg, r) : b_col + (int64_t)r * p.ldb;
-                    xb[g][i] = *reinterpret_cast<const uint32_t*>(bp);
+                    xb[g][i] = *reinterpret_cast<const uint32_t*>(b_col + (int64_t)r * p.ldb);
                 } else {
                     xa[g][i] = 0u;
                     xb[g][i] = 0u;
@@ -1397,13 +1365,13 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
     }
 }
 
-template <int EPI, bool PATCH>
+template <int EPI>
 int launch_nt(const GemmNTArgs& a, int out_f32, hipStream_t s) {
     const int grid = a.ntm * a.ntn;
     if (out_f32)
-        hipLaunchKernelGGL((gemm_nt_kernel<EPI, true, PATCH>), dim3(grid), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((gemm_nt_kernel<EPI, true>), dim3(grid), dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL((gemm_nt_kernel<EPI, false, PATCH>), dim3(grid), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((gemm_nt_kernel<EPI, false>), dim3(grid), dim3(256), 0, s, a);
     return merlot_launch_status("merlot_gemm_bf16_nt");
 }
 
@@ -1510,13 +1478,7 @@ int nt_config_override() {
     return v;
 }
 
-int gemm_nt_dispatch(GemmNTArgs& a, int epilogue, int out_f32, bool patch, hipStream_t s) {
-    if (patch) {
-        a.ntm = cdiv(a.M, BM);
-        a.ntn = cdiv(a.N, BN);
-        MERLOT_CHECK(epilogue == MERLOT_EPI_NONE, MERLOT_ESHAPE, "patch embed supports EPI_NONE only");
-        return launch_nt<MERLOT_EPI_NONE, true>(a, out_f32, s);
-    }
+int gemm_nt_dispatch(GemmNTArgs& a, int epilogue, int out_f32, hipStream_t s) {
     if (const char* e = getenv("MERLOT_DBG")) a.dbg = atoi(e);
     int cfg = nt_config_override();
     if (const char* e = getenv("MERLOT_NT_CFG_DYN")) cfg = atoi(e);     // re-read every call (experiments only)
@@ -1549,16 +1511,16 @@ int gemm_nt_dispatch(GemmNTArgs& a, int epilogue, int out_f32, bool patch, hipSt
     a.ntm = cdiv(a.M, BM);
     a.ntn = cdiv(a.N, BN);
     switch (epilogue) {
-        case MERLOT_EPI_NONE: return launch_nt<MERLOT_EPI_NONE, false>(a, out_f32, s);
-        case MERLOT_EPI_GELU: return launch_nt<MERLOT_EPI_GELU, false>(a, out_f32, s);
-        case MERLOT_EPI_RESIDUAL: return launch_nt<MERLOT_EPI_RESIDUAL, false>(a, out_f32, s);
-        case MERLOT_EPI_DGELU: return launch_nt<MERLOT_EPI_DGELU, false>(a, out_f32, s);
+        case MERLOT_EPI_NONE: return launch_nt<MERLOT_EPI_NONE>(a, out_f32, s);
+        case MERLOT_EPI_GELU: return launch_nt<MERLOT_EPI_GELU>(a, out_f32, s);
+        case MERLOT_EPI_RESIDUAL: return launch_nt<MERLOT_EPI_RESIDUAL>(a, out_f32, s);
+        case MERLOT_EPI_DGELU: return launch_nt<MERLOT_EPI_DGELU>(a, out_f32, s);
     }
     merlot_set_error("merlot_gemm_bf16_nt: unknown epilogue %d", epilogue);
     return MERLOT_ESHAPE;
 }
 
-int tn_launch(GemmTNArgs& a, int accumulate, bool patch_b, bool v2, hipStream_t s) {
+int tn_launch(GemmTNArgs& a, int accumulate, hipStream_t s) {
     a.ntm = cdiv(a.M, BM);
     a.ntn = cdiv(a.N, BN);
     const int tiles = a.ntm * a.ntn;
@@ -1576,10 +1538,7 @@ int tn_launch(GemmTNArgs& a, int accumulate, bool patch_b, bool v2, hipStream_t 
         MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "merlot_gemm_bf16_tn: memset failed: %s", hipGetErrorString(e));
     }
     const int grid = tiles * splits;
-    if (patch_b)
-        hipLaunchKernelGGL((gemm_tn_kernel<true>), dim3(grid), dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL((gemm_tn_kernel<false>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(grid), dim3(256), 0, s, a);
     return merlot_launch_status("merlot_gemm_bf16_tn");
 }
 
@@ -1657,8 +1616,8 @@ bool tn_ring_ok(const GemmTNArgs& a) {
            (a.N % 8 == 0) && (a.ldc % 4 == 0) && (((uintptr_t)a.A | (uintptr_t)a.B | (uintptr_t)a.C) & 15) == 0;
 }
 
-int gemm_tn_dispatch(GemmTNArgs& a, int accumulate, bool patch_b, float* ws, int64_t ws_bytes, hipStream_t s) {
-    if (patch_b || !tn_ring_ok(a)) return tn_launch(a, accumulate, patch_b, false, s);
+int gemm_tn_dispatch(GemmTNArgs& a, int accumulate, float* ws, int64_t ws_bytes, hipStream_t s) {
+    if (!tn_ring_ok(a)) return tn_launch(a, accumulate, s);
     // main part: the first floor(R/32)*32 reduction rows through the ring kernel; the (< 32 row) tail, if any,
     // through the register-staged kernel accumulating on top.
     const int R = a.R;
@@ -1671,7 +1630,7 @@ int gemm_tn_dispatch(GemmTNArgs& a, int accumulate, bool patch_b, float* ws, int
     t.A = a.A + (int64_t)r_main * a.lda;
     t.B = a.B + (int64_t)r_main * a.ldb;
     t.R = R - r_main;
-    return tn_launch(t, 1, false, false, s);
+    return tn_launch(t, 1, s);
 }
 
 }  // namespace
@@ -1703,7 +1662,7 @@ extern "C" int merlot_gemm_bf16_nt(const void* A, int64_t lda, const void* Bt, i
     a.drop_scale = 1.0f / (1.0f - dropout_p);
     a.drop_seed = dropout_seed;
     a.accumulate = accumulate;
-    return gemm_nt_dispatch(a, epilogue, out_f32, false, (hipStream_t)stream);
+    return gemm_nt_dispatch(a, epilogue, out_f32, (hipStream_t)stream);
 }
 
 extern "C" int64_t merlot_gemm_bf16_tn_workspace_bytes(int64_t M, int64_t N, int64_t R) {
@@ -1723,42 +1682,32 @@ extern "C" int merlot_gemm_bf16_tn(const void* A, int64_t lda, const void* B, in
     a.A = (const bf16*)A; a.B = (const bf16*)B; a.C = C;
     a.lda = lda; a.ldb = ldb; a.ldc = ldc;
     a.M = (int)M; a.N = (int)N; a.R = (int)R; a.alpha = alpha;
-    return gemm_tn_dispatch(a, accumulate, false, (float*)workspace, workspace_bytes, (hipStream_t)stream);
+    return gemm_tn_dispatch(a, accumulate, (float*)workspace, workspace_bytes, (hipStream_t)stream);
 }
 
-static int check_patch(int n_img, int H, int W, int P, int hidden) {
-    MERLOT_CHECK(P == 16, MERLOT_ESHAPE, "patch embed: only patch_size 16 is supported (got %d)", P);
-    MERLOT_CHECK(n_img > 0 && H % P == 0 && W % P == 0, MERLOT_ESHAPE, "patch embed: H, W must be multiples of P");
-    MERLOT_CHECK((W * 3) % 8 == 0, MERLOT_EALIGN, "patch embed: W*3 must be a multiple of 8");
-    MERLOT_CHECK(hidden > 1, MERLOT_ESHAPE, "patch embed: bad hidden");
-    return MERLOT_OK;
-}
+// Patch-embed 16x16/16 convolution = explicit im2col (merlot_im2col_patches, csrc/conv.hip: the `image - 0.5` of
+// utils/vision_transformer.py:193 is applied in the gather) + the production GEMMs on the [rows, 768] patch matrix.
+extern "C" int merlot_im2col_patches(const void* image, void* patches, int n_img, int H, int W, int P, float shift,
+                                     merlot_stream_t stream);
 
-extern "C" int merlot_patch_embed_fwd(const void* image, int n_img, int H, int W, int P, const void* Wt,
-                                      const float* bias_folded, void* out, int hidden, merlot_stream_t stream) {
-    int rc = check_patch(n_img, H, W, P, hidden);
+extern "C" int merlot_patch_embed_fwd(const void* image, int n_img, int H, int W, int P, const void* Wt, const float* bias,
+                                      void* patches, void* out, int hidden, merlot_stream_t stream) {
+    MERLOT_CHECK(Wt && out && patches && hidden > 1, MERLOT_ESHAPE, "merlot_patch_embed_fwd: null operand / bad hidden");
+    int rc = merlot_im2col_patches(image, patches, n_img, H, W, P, -0.5f, stream);
     if (rc) return rc;
     GemmNTArgs a{};
-    a.A = (const bf16*)image; a.B = (const bf16*)Wt; a.C = out;
-    a.lda = 0; a.ldb = P * P * 3; a.ldc = hidden;
+    a.A = (const bf16*)patches; a.B = (const bf16*)Wt; a.C = out;
+    a.lda = P * P * 3; a.ldb = P * P * 3; a.ldc = hidden;
     a.M = n_img * (H / P) * (W / P); a.N = hidden; a.K = P * P * 3;
-    a.alpha = 1.f; a.bias = bias_folded;
-    a.pg = PatchGeom{H, W, P, H / P, W / P};
-    return gemm_nt_dispatch(a, MERLOT_EPI_NONE, 0, true, (hipStream_t)stream);
+    a.alpha = 1.f; a.bias = bias;
+    return gemm_nt_dispatch(a, MERLOT_EPI_NONE, 0, (hipStream_t)stream);
 }
 
-extern "C" int merlot_patch_embed_wgrad(const void* image, int n_img, int H, int W, int P, const void* dY, float* dWt,
-                                        int hidden, int accumulate, merlot_stream_t stream) {
-    int rc = check_patch(n_img, H, W, P, hidden);
-    if (rc) return rc;
-    // dWt[hidden][k] = sum_rows dY[row][hidden] * patch[row][k]   (the -0.5 shift is applied by the caller
-    // through the bias gradient: d/dW of (x-0.5)W = x^T dY - 0.5 * colsum(dY))
-    GemmTNArgs a{};
-    a.A = (const bf16*)dY; a.B = (const bf16*)image; a.C = dWt;
-    a.lda = hidden; a.ldb = 0; a.ldc = P * P * 3;
-    a.M = hidden; a.N = P * P * 3; a.R = n_img * (H / P) * (W / P); a.alpha = 1.f;
-    a.pg = PatchGeom{H, W, P, H / P, W / P};
-    return gemm_tn_dispatch(a, accumulate, true, nullptr, 0, (hipStream_t)stream);
+extern "C" int merlot_patch_embed_wgrad(const void* patches, int64_t rows, int K, const void* dY, float* dWt, int hidden,
+                                        int accumulate, void* workspace, int64_t workspace_bytes, merlot_stream_t stream) {
+    // dWt[hidden][k] = sum_rows dY[row][hidden] * patches[row][k]: the wgrad GEMM on the saved patch matrix
+    MERLOT_CHECK(patches && dY && dWt && rows > 0 && K > 0 && hidden > 1, MERLOT_ESHAPE, "merlot_patch_embed_wgrad: bad arguments");
+    return merlot_gemm_bf16_tn(dY, hidden, patches, K, dWt, K, hidden, K, rows, 1.f, accumulate, workspace, workspace_bytes, stream);
 }
 
 extern "C" int merlot_probe_persist_trace(void* dst, int64_t bytes, merlot_stream_t stream) {

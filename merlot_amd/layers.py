@@ -315,24 +315,22 @@ class ClsAvgPoolFn(torch.autograd.Function):
 
 
 class PatchEmbedFn(torch.autograd.Function):
-    """image NHWC bf16 -> [n_img*h1*w1, H] bf16 (utils/vision_transformer.py:193-205); image gets no gradient."""
+    """image NHWC bf16 -> [n_img*h1*w1, H] bf16 (utils/vision_transformer.py:193-205): im2col(image - 0.5) + MFMA GEMM;
+    the patch matrix is kept for the weight gradient.  The image gets no gradient."""
 
     @staticmethod
     def forward(ctx, image, lin, patch, anchor):
-        # fold the `image - 0.5` into the bias: (x - 0.5) W = x W - 0.5 * sum_k W[:, k]   (bf16 weights, fp32 sum)
-        bias_folded = lin.b - 0.5 * lin.wb.float().sum(1)
-        ctx.image, ctx.lin, ctx.patch = image, lin, patch
-        return ops.patch_embed_fwd(image, lin.wb, bias_folded.contiguous(), patch)
+        out, patches = ops.patch_embed_fwd(image, lin.wb, lin.b, patch)
+        ctx.patches, ctx.lin = patches, lin
+        return out
 
     @staticmethod
     def backward(ctx, dy):
         lin = ctx.lin
         dy = dy.contiguous()
-        db = torch.zeros_like(lin.gb)
-        ops.colsum_bf16(dy, db, accumulate=False)
-        lin.gb.add_(db)
-        ops.patch_embed_wgrad(ctx.image, dy, lin.gw, ctx.patch, accumulate=True)
-        lin.gw.sub_(0.5 * db[:, None])           # the -0.5 shift of every pixel
+        ops.colsum_bf16(dy, lin.gb)
+        ops.patch_embed_wgrad(ctx.patches, dy, lin.gw, accumulate=True)
+        ctx.patches = None
         return None, None, None, None
 
 

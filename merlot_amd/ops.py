@@ -102,21 +102,27 @@ def gemm_tn(a, b, out, *, accumulate=True, alpha=1.0, m=None, n=None):
     return out
 
 
-def patch_embed_fwd(image, wt, bias_folded, patch):
-    _chk(image, BF16, 'image'); _chk(wt, BF16, 'wt'); _chk(bias_folded, F32, 'bias')
+def patch_embed_fwd(image, wt, bias, patch):
+    """-> (out [rows, hidden] bf16, patches [rows, P*P*3] bf16 = im2col(image - 0.5), kept for the weight gradient)."""
+    _chk(image, BF16, 'image'); _chk(wt, BF16, 'wt'); _chk(bias, F32, 'bias')
     n, H, W, c = image.shape
     assert c == 3 and image.is_contiguous()
     hidden = wt.shape[0]
-    out = torch.empty((n * (H // patch) * (W // patch), hidden), device=image.device, dtype=BF16)
-    call('merlot_patch_embed_fwd', _p(image), n, H, W, patch, _p(wt), _p(bias_folded), _p(out), hidden, _stream())
-    return out
+    rows = n * (H // patch) * (W // patch)
+    patches = torch.empty((rows, patch * patch * 3), device=image.device, dtype=BF16)
+    out = torch.empty((rows, hidden), device=image.device, dtype=BF16)
+    call('merlot_patch_embed_fwd', _p(image), n, H, W, patch, _p(wt), _p(bias), _p(patches), _p(out), hidden, _stream())
+    return out, patches
 
 
-def patch_embed_wgrad(image, dy, dwt, patch, accumulate=True):
-    _chk(image, BF16, 'image'); _chk(dy, BF16, 'dy'); _chk(dwt, F32, 'dwt')
-    n, H, W, _ = image.shape
-    assert dy.is_contiguous() and dwt.is_contiguous()
-    call('merlot_patch_embed_wgrad', _p(image), n, H, W, patch, _p(dy), _p(dwt), dwt.shape[0], 1 if accumulate else 0,
+def patch_embed_wgrad(patches, dy, dwt, accumulate=True):
+    _chk(patches, BF16, 'patches'); _chk(dy, BF16, 'dy'); _chk(dwt, F32, 'dwt')
+    assert dy.is_contiguous() and dwt.is_contiguous() and patches.is_contiguous()
+    rows, K = patches.shape
+    hidden = dwt.shape[0]
+    nbytes = LIB.query('merlot_gemm_bf16_tn_workspace_bytes', hidden, K, rows)
+    ws = torch.empty(nbytes // 4, device=dy.device, dtype=F32) if nbytes else None
+    call('merlot_patch_embed_wgrad', _p(patches), rows, K, _p(dy), _p(dwt), hidden, 1 if accumulate else 0, _p(ws), nbytes,
          _stream())
 
 

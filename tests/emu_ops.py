@@ -64,12 +64,13 @@ def _patches(image, P):
     return image.float().reshape(n, h1, P, w1, P, 3).permute(0, 1, 3, 2, 4, 5).reshape(n * h1 * w1, P * P * 3)
 
 
-def patch_embed_fwd(image, wt, bias_folded, patch):
-    return (_patches(image, patch) @ wt.float().t() + bias_folded).to(BF16)
+def patch_embed_fwd(image, wt, bias, patch):
+    patches = (_patches(image, patch) - 0.5).to(BF16)
+    return (patches.float() @ wt.float().t() + bias).to(BF16), patches
 
 
-def patch_embed_wgrad(image, dy, dwt, patch, accumulate=True):
-    v = dy.float().t() @ _patches(image, patch)
+def patch_embed_wgrad(patches, dy, dwt, accumulate=True):
+    v = dy.float().t() @ patches.float()
     if accumulate:
         dwt += v
     else:

@@ -149,15 +149,18 @@ def test_patch_embed(ops):
         img = torch.rand((n, H, W, 3), generator=g).to(BF16)
         wt = rnd((768, 768), g, 0.03)
         bias = torch.randn(768, generator=g) * 0.1
-        ref = E.patch_embed_fwd(img, wt, bias, 16).float()
-        got = ops.patch_embed_fwd(img.cuda(), wt.cuda(), bias.cuda(), 16)
-        assert rel_l2(got, ref) < 6e-3
+        ref, pref = E.patch_embed_fwd(img, wt, bias, 16)
+        got, patches = ops.patch_embed_fwd(img.cuda(), wt.cuda(), bias.cuda(), 16)
+        assert torch.equal(patches.cpu(), pref)                      # im2col(image - 0.5) is bit-exact
+        assert rel_l2(got, ref.float()) < 6e-3
         dy = rnd((ref.shape[0], 768), g)
         dref = torch.zeros((768, 768))
-        E.patch_embed_wgrad(img, dy, dref, 16, accumulate=False)
+        E.patch_embed_wgrad(pref, dy, dref, accumulate=False)
         dw = torch.zeros((768, 768)).cuda()
-        ops.patch_embed_wgrad(img.cuda(), dy.cuda(), dw, 16, accumulate=False)
+        ops.patch_embed_wgrad(patches, dy.cuda(), dw, accumulate=False)
         assert rel_l2(dw, dref) < 2e-3
+        ops.patch_embed_wgrad(patches, dy.cuda(), dw, accumulate=True)
+        assert rel_l2(dw, 2 * dref) < 2e-3
 
 
 # ---- LayerNorm ---------------------------------------------------------------------------------------------
