@@ -250,6 +250,12 @@ int merlot_probe_tr16(const void* tile, void* out, merlot_stream_t stream);
 int merlot_probe_persist_trace(void* dst, int64_t bytes, merlot_stream_t stream);
 int merlot_probe_cu_hog(int blocks, int lds_bytes, int64_t cycles, void* sink, merlot_stream_t stream);
 
+/* ---- host-side byte work (no GPU, no stream) ---------------------------------------------------------------------
+ * CRC-32C (Castagnoli) of `n` bytes, extending `crc` (0 to start).  Used by the TF tensor-bundle checkpoint reader/writer
+ * (the files utils/model_utils.py:388-413 and model/modeling.py:724-738 initialise from) and by the TFRecord framing
+ * (data/process.py:236-256).  Returns the unmasked checksum in the low 32 bits; force_sw != 0 selects the table path. */
+int64_t merlot_crc32c(uint64_t crc, const void* data, int64_t n, int force_sw);
+
 #ifdef __cplusplus
 }
 #endif

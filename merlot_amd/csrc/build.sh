@@ -17,6 +17,10 @@ if [ ! -f build/capi.o ] || [ capi.cpp -nt build/capi.o ] || [ ../../include/mer
   ( g++ -O2 -fPIC -std=c++17 -c capi.cpp -o build/capi.o ) &
   pids+=($!)
 fi
+if [ ! -f build/hostio.o ] || [ hostio.cpp -nt build/hostio.o ] || [ ../../include/merlot_hip.h -nt build/hostio.o ]; then
+  ( g++ -O2 -fPIC -std=c++17 -c hostio.cpp -o build/hostio.o ) &
+  pids+=($!)
+fi
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT build/gemm.o build/attention.o build/layernorm.o build/elementwise.o build/index.o build/probe.o build/conv.o build/capi.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT build/gemm.o build/attention.o build/layernorm.o build/elementwise.o build/index.o build/probe.o build/conv.o build/capi.o build/hostio.o
 echo "built $(realpath $OUT)"

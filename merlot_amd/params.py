@@ -260,48 +260,72 @@ class ParamStore(object):
             self.grad_ready_hook(group)
 
     # ---- TF-name interchange ---------------------------------------------------------------------------
-    def load_tf_weights(self, tf_weights):
-        """tf_weights: {TF variable name: tensor in TF layout} (see oracle.merlot_oracle.variable_shapes)."""
+    def view(self, flat, name):
+        """the slice of an arena-shaped flat tensor (master, grad, an optimizer slot) that belongs to `name`."""
+        o, n, shp = self.offsets[name]
+        return flat[o:o + n].view(shp)
+
+    def tf_names(self, name):
+        """the TF variable names an arena entry is stored under in a reference checkpoint (q/k/v are fused here)."""
+        if name.endswith('/qkv/kernel') or name.endswith('/qkv/bias'):
+            base, leaf = name.rsplit('/qkv/', 1)
+            return [f'{base}/{nm}/{leaf}' for nm in ('query_layer', 'key_layer', 'value_layer')]
+        return [name]
+
+    def load_tf_weights(self, tf_weights, strict=True, getter=None, suffix=''):
+        """tf_weights: {TF variable name (+ suffix): tensor in TF layout} (see oracle.merlot_oracle.variable_shapes).
+        strict=False is `tf.train.init_from_checkpoint` with the assignment map of utils/model_utils.py:388-413: only
+        the variables the checkpoint holds are overwritten.  getter/suffix select another arena-shaped destination
+        (e.g. the optimizer's `<name>/adam_m` slots).  -> names in tf_weights that nothing consumed."""
         H = self.cfg['hidden_size']
         P = self.cfg['patch_size']
+        getter = getter or self.p
         used = set()
+        self.initialized_from_checkpoint = getattr(self, 'initialized_from_checkpoint', set())
+
+        def fetch(tf_name):
+            key = tf_name + suffix
+            if key not in tf_weights:
+                if strict:
+                    raise KeyError(key)
+                return None
+            used.add(key)
+            self.initialized_from_checkpoint.add(key)
+            t = tf_weights[key]
+            return (t if isinstance(t, torch.Tensor) else torch.as_tensor(t)).float()
+
         for name in self.names():
-            dst = self.p(name)
+            dst = getter(name)
             if name.endswith('/qkv/kernel') or name.endswith('/qkv/bias'):
-                base, leaf = name.rsplit('/qkv/', 1)
-                parts = []
-                for nm in ['query_layer', 'key_layer', 'value_layer']:
-                    t = torch.as_tensor(tf_weights[f'{base}/{nm}/{leaf}']).float()
-                    used.add(f'{base}/{nm}/{leaf}')
-                    parts.append(t.t() if leaf == 'kernel' else t)
-                dst.copy_(torch.cat(parts, 0))
-            elif '/resnet50lite/' in name:
-                used.add(name)
-                dst.copy_(torch.as_tensor(tf_weights[name]).float().reshape(dst.shape))   # HWIO kernels / GroupNorm, as is
+                leaf = name.rsplit('/', 1)[1]
+                for i, tf_name in enumerate(self.tf_names(name)):
+                    t = fetch(tf_name)
+                    if t is not None:
+                        dst[i * H:(i + 1) * H].copy_(t.t() if leaf == 'kernel' else t)
+                continue
+            t = fetch(name)
+            if t is None:
+                continue
+            if '/resnet50lite/' in name:
+                dst.copy_(t.reshape(dst.shape))                          # HWIO kernels / GroupNorm, as is
             elif name.endswith('conv_postresnet_proj/kernel'):
-                t = torch.as_tensor(tf_weights[name]).float()            # [1, 1, C, H]
-                used.add(name)
-                dst.copy_(t.reshape(-1, H).t())
+                dst.copy_(t.reshape(-1, H).t())                          # [1, 1, C, H]
             elif name.endswith('conv2d/kernel'):
-                t = torch.as_tensor(tf_weights[name]).float()            # HWIO [P,P,3,H]
-                used.add(name)
-                dst.copy_(t.reshape(P * P * 3, H).t())
+                dst.copy_(t.reshape(P * P * 3, H).t())                   # HWIO [P,P,3,H]
             elif name.endswith('/kernel'):
-                t = torch.as_tensor(tf_weights[name]).float()            # [in, out]
-                used.add(name)
-                dst.copy_(t.t())
+                dst.copy_(t.t())                                         # [in, out]
             else:
-                used.add(name)
-                dst.copy_(torch.as_tensor(tf_weights[name]).float().reshape(dst.shape))
+                dst.copy_(t.reshape(dst.shape))
         self.master_version += 1
         return sorted(set(tf_weights.keys()) - used)
 
-    def _export(self, getter):
+    def _export(self, getter, keep_dtype=False):
         H = self.cfg['hidden_size']
         P = self.cfg['patch_size']
         out = {}
         for name in self.names():
-            t = getter(name).detach().float().cpu()
+            t = getter(name).detach().cpu()
+            t = t if keep_dtype else t.float()
             if name.endswith('/qkv/kernel') or name.endswith('/qkv/bias'):
                 base, leaf = name.rsplit('/qkv/', 1)
                 for i, nm in enumerate(['query_layer', 'key_layer', 'value_layer']):

@@ -8,6 +8,7 @@ from .modeling import model_fn_builder, draw_mask_noise
 from .optimization import build_optimizer_from_config
 from .parallel import GradReducer
 from .params import ParamStore
+from . import checkpoint as ckpt_io
 
 
 def synthetic_batch(config, examples, device, seed=1234, num_chunks=None):
@@ -56,6 +57,22 @@ class Trainer(object):
                                        expected_passes={'encoder': 2, 'encoder/LayerNorm_ln_final': 2, '*': 1},
                                        defer=self.opt.clip_norm > 0.0)
         self.step_idx = 0
+        # model/modeling.py:724-738: variables the init checkpoint also holds (weights and, since this is the training
+        # graph, the Adam slots) start from it; global_step does not.
+        self.initialized_variable_names = {}
+        init_checkpoint = config.model.get('init_checkpoint', None)
+        if init_checkpoint:
+            self.initialized_variable_names = ckpt_io.init_from_checkpoint(self.store, init_checkpoint, self.opt)
+
+    def save(self, model_dir=None):
+        """`model.ckpt-<global_step>` in the TF bundle format the reference's Estimator writes to device.output_dir."""
+        return ckpt_io.save_checkpoint(model_dir or self.config.device['output_dir'], self.store, self.opt)
+
+    def restore(self, model_dir_or_prefix=None):
+        """Estimator auto-resume from the latest checkpoint of output_dir (weights, Adam slots, global_step)."""
+        self.step_idx = ckpt_io.restore_checkpoint(model_dir_or_prefix or self.config.device['output_dir'], self.store,
+                                                   self.opt)
+        return self.step_idx
 
     def forward_only(self, features):
         """one forward pass (ViT, text-only, masking, joint, the three losses) with the training graph's ops but no
