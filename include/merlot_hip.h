@@ -250,6 +250,28 @@ int merlot_probe_tr16(const void* tile, void* out, merlot_stream_t stream);
 int merlot_probe_persist_trace(void* dst, int64_t bytes, merlot_stream_t stream);
 int merlot_probe_cu_hog(int blocks, int lds_bytes, int64_t cycles, void* sink, merlot_stream_t stream);
 
+/* ---- input pipeline: frame preprocessing ---------------------------------------------------------
+ * One job per frame: decoded JPEG (HWC uint8, device) -> convert_image_dtype * resize_images(method, align_corners=True)
+ * to [scaled_h, scaled_w] -> crop at (offset_y, offset_x) -> zero-pad to [out_h, out_w] -> where(is_finite) ->
+ * brightness / contrast augment + clip -> bf16 (model/dataloader.py:72-97, utils/model_utils.py:758-940).  The random
+ * quantities (scale, offsets, method, augment choice and factors) are drawn by the host and arrive in the job. */
+typedef struct {
+    int64_t src_offset;           /* bytes into `src` of this frame's image */
+    int32_t src_h, src_w;
+    int32_t scaled_h, scaled_w;
+    int32_t method;               /* tf.image.ResizeMethod: 0 bilinear, 1 nearest, 2 bicubic, 3 area */
+    int32_t offset_y, offset_x;
+    int32_t aug_kind;             /* 0 none, 1 brightness, 2 contrast */
+    float factor[3];
+    float reserved;
+} merlot_image_job_t;
+int64_t merlot_image_frames_workspace_bytes(int n_img, int out_h, int out_w);
+/* jobs_host / jobs_dev: the same n_img-entry table in host memory (validated before any launch) and device memory (read
+ * by the kernels).  dst: bf16 [n_img, out_h, out_w, 3]. */
+int merlot_image_frames(const uint8_t* src, int64_t src_bytes, const merlot_image_job_t* jobs_host,
+                        const merlot_image_job_t* jobs_dev, int n_img, void* dst, int out_h, int out_w, void* workspace,
+                        int64_t workspace_bytes, merlot_stream_t stream);
+
 /* ---- host-side byte work (no GPU, no stream) ---------------------------------------------------------------------
  * CRC-32C (Castagnoli) of `n` bytes, extending `crc` (0 to start).  Used by the TF tensor-bundle checkpoint reader/writer
  * (the files utils/model_utils.py:388-413 and model/modeling.py:724-738 initialise from) and by the TFRecord framing

@@ -7,7 +7,7 @@ OUT=../libmerlot_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable"
 mkdir -p build
 pids=()
-for f in gemm attention layernorm elementwise index probe conv; do
+for f in gemm attention layernorm elementwise index probe conv image; do
   if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ ../../include/merlot_hip.h -nt build/$f.o ]; then
     ( $HIPCC $FLAGS -c $f.hip -o build/$f.o ) &
     pids+=($!)
@@ -22,5 +22,5 @@ if [ ! -f build/hostio.o ] || [ hostio.cpp -nt build/hostio.o ] || [ ../../inclu
   pids+=($!)
 fi
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT build/gemm.o build/attention.o build/layernorm.o build/elementwise.o build/index.o build/probe.o build/conv.o build/capi.o build/hostio.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT build/gemm.o build/attention.o build/layernorm.o build/elementwise.o build/index.o build/probe.o build/conv.o build/image.o build/capi.o build/hostio.o
 echo "built $(realpath $OUT)"

@@ -1,0 +1,417 @@
+"""Input pipeline counterpart: TFRecords written by the reference's data/process.py:236-256 ->
+the `features` dict `model_fn` consumes (model/modeling.py:685-703), without TensorFlow.
+
+Mirror of model/dataloader.py:
+  `_decode_record` (:33-54)        TFRecord framing + tf.train.Example wire format, parsed here (host, Python)
+  `_dataset_parser` (:57-126)      per example: JPEG decode (host, PIL/libjpeg), then ONE GPU launch pair per batch for
+                                   convert_image_dtype + random-scale resize (4 methods) + crop + pad + brightness /
+                                   contrast augment + bf16 cast (csrc/image.hip, `merlot_image_frames`); text side on host
+  `input_fn_builder` (:129-280)    file listing / per-rank sharding, shuffle buffer, batching (drop_remainder),
+                                   `_process_example`: chunk shuffling, shuffled_idx_img (HIP `merlot_shuffled_idx`),
+                                   frame flattening, optional transpose_input
+All randomness is drawn on the host from one seeded numpy Generator per pipeline (`draw_*`), so a run is reproducible
+and tests can inject the exact draws the reference graph consumed.  There is no CPU fallback for the frame kernels.
+"""
+import glob
+import io
+import queue
+import struct
+import threading
+
+import numpy as np
+import torch
+
+from . import checkpoint as _ck
+from . import ops
+from .lib import LIB
+
+START, NEXTCAPTION_START = 2, 5                         # utils/encode/encoder.py:18,21
+
+# model/dataloader.py:20-32: key -> (kind, default); VarLen features default to an empty list
+CHUNK_K2F = {
+    'image/encoded': ('bytes', b''), 'image/format': ('bytes', b'jpeg'), 'image/key/sha256': ('bytes', b''),
+    'image/height': ('int64', 1), 'image/width': ('int64', 1), 'youtube_id': ('bytes', b''),
+    'tokenized_cleaned_asr': ('varlen', None), 'tokenized_raw_asr': ('varlen', None), 'is_eoc': ('int64', 1),
+    'mean_time': ('float', 1.0), 'chunk_num': ('int64', 1),
+}
+
+JOB_DTYPE = np.dtype([('src_offset', '<i8'), ('src_h', '<i4'), ('src_w', '<i4'), ('scaled_h', '<i4'), ('scaled_w', '<i4'),
+                      ('method', '<i4'), ('offset_y', '<i4'), ('offset_x', '<i4'), ('aug_kind', '<i4'),
+                      ('factor', '<f4', (3,)), ('reserved', '<f4')])
+assert JOB_DTYPE.itemsize == 56
+
+
+class RecordError(ValueError):
+    pass
+
+
+# ---- TFRecord framing (tensorflow/core/lib/io/record_writer.cc): u64 length, masked crc32c(length), data, masked crc32c(data)
+def read_tfrecords(path, verify=True):
+    with open(path, 'rb') as f:
+        while True:
+            head = f.read(12)
+            if not head:
+                return
+            if len(head) != 12:
+                raise RecordError(f'{path}: truncated record header')
+            n, = struct.unpack('<Q', head[:8])
+            if verify and _ck.mask_crc(_ck.crc32c(head[:8])) != struct.unpack('<I', head[8:])[0]:
+                raise RecordError(f'{path}: corrupt record length')
+            body = f.read(n + 4)
+            if len(body) != n + 4:
+                raise RecordError(f'{path}: truncated record')
+            if verify and _ck.mask_crc(_ck.crc32c(body[:n])) != struct.unpack('<I', body[n:])[0]:
+                raise RecordError(f'{path}: corrupt record data')
+            yield body[:n]
+
+
+class TFRecordWriter(object):
+    def __init__(self, path):
+        self.f = open(path, 'wb')
+
+    def write(self, data):
+        head = struct.pack('<Q', len(data))
+        self.f.write(head + struct.pack('<I', _ck.mask_crc(_ck.crc32c(head))))
+        self.f.write(data + struct.pack('<I', _ck.mask_crc(_ck.crc32c(data))))
+
+    def close(self):
+        self.f.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+# ---- tf.train.Example (tensorflow/core/example/{example,feature}.proto) ------------------------------------------------
+def parse_example(buf):
+    """serialized tf.train.Example -> {key: ('bytes'|'float'|'int64', list)}."""
+    out = {}
+    for f, _, features in _ck._proto_fields(buf):
+        if f != 1:
+            continue
+        for f2, _, entry in _ck._proto_fields(features):            # map<string, Feature> entries
+            if f2 != 1:
+                continue
+            key, feat = None, b''
+            for f3, _, v in _ck._proto_fields(entry):
+                if f3 == 1:
+                    key = v.decode('utf-8')
+                elif f3 == 2:
+                    feat = v
+            kind, vals = None, []
+            for f4, _, lst in _ck._proto_fields(feat):
+                if f4 == 1:
+                    kind, vals = 'bytes', [v for f5, _, v in _ck._proto_fields(lst) if f5 == 1]
+                elif f4 == 2:
+                    kind = 'float'
+                    for f5, wt, v in _ck._proto_fields(lst):
+                        if f5 == 1 and wt == 2:                     # packed
+                            vals.extend(struct.unpack(f'<{len(v) // 4}f', v))
+                        elif f5 == 1:
+                            vals.append(struct.unpack('<f', struct.pack('<I', v))[0])
+                elif f4 == 3:
+                    kind = 'int64'
+                    for f5, wt, v in _ck._proto_fields(lst):
+                        if f5 == 1 and wt == 2:
+                            pos = 0
+                            while pos < len(v):
+                                x, pos = _ck._get_varint(v, pos)
+                                vals.append(_ck._signed(x))
+                        elif f5 == 1:
+                            vals.append(_ck._signed(v))
+            if key is not None:
+                out[key] = (kind, vals)
+    return out
+
+
+def _ld(field, payload):
+    out = bytearray([(field << 3) | 2])
+    _ck._put_varint(out, len(payload))
+    return bytes(out) + bytes(payload)
+
+
+def encode_example(features):
+    """{key: bytes | [bytes] | int | [int] | float | [float] (np.float32 scalars / lists count as float)} -> bytes,
+    with the packed encodings protobuf emits for tf.train.Example."""
+    entries = b''
+    for key in sorted(features):
+        v = features[key]
+        v = list(v) if isinstance(v, (list, tuple, np.ndarray)) else [v]
+        if v and isinstance(v[0], (bytes, bytearray)):
+            lst = _ld(1, b''.join(_ld(1, x) for x in v))
+        elif v and isinstance(v[0], (float, np.floating)):
+            lst = _ld(2, _ld(1, struct.pack(f'<{len(v)}f', *v)))
+        else:
+            packed = bytearray()
+            for x in v:
+                _ck._put_varint(packed, int(x))
+            lst = _ld(3, _ld(1, packed) if v else b'')
+        entries += _ld(1, _ld(1, key.encode('utf-8')) + _ld(2, lst))
+    return _ld(1, entries)
+
+
+def decode_record(record, num_chunks):
+    """model/dataloader.py:33-54: -> list of per-chunk dicts (FixedLen features as scalars with the reference's
+    defaults, VarLen as int lists)."""
+    ex = parse_example(record)
+    chunks = []
+    for i in range(num_chunks):
+        cur = {}
+        for k, (kind, default) in CHUNK_K2F.items():
+            got = ex.get(f'c{i:02d}/{k}')
+            if kind == 'varlen':
+                cur[k] = list(got[1]) if got is not None else []
+            elif got is None or not got[1]:
+                cur[k] = default
+            else:
+                if len(got[1]) != 1:
+                    raise RecordError(f'c{i:02d}/{k}: expected one value, found {len(got[1])}')
+                cur[k] = got[1][0]
+        chunks.append(cur)
+    return chunks
+
+
+# ---- per-example parsing ---------------------------------------------------------------------------------------------
+def encode_string(b, string_len):
+    """utils/model_utils.py:628-637"""
+    raw = np.frombuffer(bytes(b), np.uint8).astype(np.int32)[:string_len]
+    out = np.zeros(string_len, np.int32)
+    out[:raw.shape[0]] = raw
+    return out
+
+
+def decode_jpeg(data):
+    """tf.image.decode_jpeg(x, channels=3) -> uint8 [h, w, 3] (host libjpeg through PIL)."""
+    from PIL import Image
+    img = Image.open(io.BytesIO(data))
+    return np.asarray(img.convert('RGB'), dtype=np.uint8)
+
+
+def draw_example_noise(rng, num_chunks, config):
+    """the random draws `_dataset_parser` consumes for one example, in graph order per frame (utils/model_utils.py:877,
+    906-907, 834 `apply_with_random_selector`, :832-836 augment index + bernoulli, :778/:788 factors) + do_clean."""
+    lo, hi = config.get('random_scale_min', 0.95), config.get('random_scale_max', 1.05)
+    strength = 0.4
+    d = 0.8 * strength
+    frames = []
+    for _ in range(num_chunks):
+        n = {'scale': np.float32(rng.uniform(lo, hi)), 'u_y': np.float32(rng.uniform()), 'u_x': np.float32(rng.uniform()),
+             'method': int(rng.integers(0, 4)), 'do_augment': False, 'kind': 0, 'factor': np.ones(3, np.float32)}
+        if config.get('augment_prob', 0.0) > 0.0:
+            n['kind'] = int(rng.integers(0, 2))                       # categorical over ['brightness', 'contrast']
+            n['do_augment'] = bool(rng.uniform() < config['augment_prob'])
+            n['factor'] = rng.uniform(1.0 - d, 1.0 + d, 3).astype(np.float32)
+        frames.append(n)
+    return {'frames': frames, 'do_clean': bool(rng.uniform() < config.get('clean_asr_prob', 0.5))}
+
+
+def resize_geometry(height, width, desired, scale_factor, u_y, u_x):
+    """utils/model_utils.py:880-908 in fp32, as the graph computes it -> scaled_h, scaled_w, offset_y, offset_x."""
+    F = np.float32
+    dh, dw = desired
+    h, w = F(height), F(width)
+    scaled_y, scaled_x = int(F(scale_factor) * F(dh)), int(F(scale_factor) * F(dw))
+    image_scale = min(F(scaled_x) / w, F(scaled_y) / h)
+    image_scale = max(image_scale, F(64.0) / min(h, w))
+    scaled_h, scaled_w = int(h * image_scale), int(w * image_scale)
+    off_y = int(max(F(0.0), F(scaled_h - dh)) * F(u_y))
+    off_x = int(max(F(0.0), F(scaled_w - dw)) * F(u_x))
+    return scaled_h, scaled_w, off_y, off_x
+
+
+def parse_example_host(record, config, noise):
+    """host half of `_dataset_parser` (model/dataloader.py:57-126): everything except the frame arithmetic.
+    -> dict(youtube_id, chunk_num, mean_time, input_ids, is_eoc, video_src_ids, frames_u8 [list of HWC uint8], jobs)."""
+    num_chunks = config['num_chunks']
+    desired = tuple(config['image_size'])
+    chunks = decode_record(record, num_chunks)
+    feats = {
+        'youtube_id': np.stack([encode_string(c['youtube_id'], 64) for c in chunks], 0),
+        'chunk_num': np.array([c['chunk_num'] for c in chunks], np.int32),
+        'mean_time': np.array([c['mean_time'] for c in chunks], np.float32),
+    }
+    frames, jobs = [], np.zeros(num_chunks, JOB_DTYPE)
+    for i, c in enumerate(chunks):
+        img = decode_jpeg(c['image/encoded'])
+        n = noise['frames'][i]
+        sh, sw, oy, ox = resize_geometry(img.shape[0], img.shape[1], desired, n['scale'], n['u_y'], n['u_x'])
+        # utils/model_utils.py:829-830 binds the transform late: every switch_case branch runs the LAST transform
+        # (contrast); the drawn index only matters with `augment_fix_selection: True` (not a reference key).
+        kind = n['kind'] if config.get('augment_fix_selection', False) else 1
+        jobs[i] = (0, img.shape[0], img.shape[1], sh, sw, n['method'], oy, ox, (1 + kind) if n['do_augment'] else 0,
+                   n['factor'], 0.0)
+        frames.append(img)
+    feats['frames_u8'], feats['jobs'] = frames, jobs
+    do_clean = noise['do_clean']
+    key = 'tokenized_cleaned_asr' if do_clean else 'tokenized_raw_asr'
+    Lc = config.get('chunk_text_len', 32)
+    ids = np.zeros((num_chunks, Lc), np.int32)
+    for i, c in enumerate(chunks):
+        row = ([START if do_clean else NEXTCAPTION_START] + [int(t) for t in c[key]])[:Lc]
+        ids[i, :len(row)] = row
+    feats['input_ids'] = ids
+    feats['is_eoc'] = np.array([bool(c['is_eoc']) for c in chunks[:-1]] + [True])
+    feats['video_src_ids'] = np.cumsum(np.concatenate([[0], feats['is_eoc'][:-1].astype(np.int32)])).astype(np.int32)
+    return feats
+
+
+def frames_to_device(frames_u8, jobs, out_hw, device, stream_tensors=None):
+    """all frames of a batch -> bf16 [n, H, W, 3] on `device` with one upload and one `merlot_image_frames` call."""
+    jobs = jobs.copy()
+    off = 0
+    for i, f in enumerate(frames_u8):
+        jobs['src_offset'][i] = off
+        off += (f.nbytes + 15) // 16 * 16
+    flat = torch.empty(off, dtype=torch.uint8).pin_memory() if torch.cuda.is_available() else torch.empty(off, dtype=torch.uint8)
+    fnp = flat.numpy()
+    for i, f in enumerate(frames_u8):
+        o = int(jobs['src_offset'][i])
+        fnp[o:o + f.nbytes] = f.reshape(-1)
+    src = flat.to(device, non_blocking=True)
+    jobs_host = torch.from_numpy(jobs.view(np.uint8).reshape(-1).copy())
+    return ops.image_frames(src, jobs_host, jobs_host.to(device, non_blocking=True), len(frames_u8), out_hw[0], out_hw[1])
+
+
+# ---- batch-level processing (model/dataloader.py:202-268) -------------------------------------------------------------
+def draw_batch_noise(rng, batch_size, num_chunks, config):
+    n = config['num_chunks_in_group']
+    B = batch_size * num_chunks // n
+    p = config.get('image_shuffle_prob', 0.5)
+    out = {'u_chunks': rng.uniform(size=(batch_size, num_chunks)).astype(np.float32)}
+    if p >= 1e-6:
+        probs = np.array([1.0 - p, 1e-6] + [p / (n - 1)] * (n - 1), np.float64)
+        out['num_shuffle'] = rng.choice(n + 1, size=B, p=probs / probs.sum()).astype(np.int32)
+        out['u_sel'] = rng.uniform(size=(B, n)).astype(np.float32)
+        out['u_perm'] = rng.uniform(size=(B, n)).astype(np.float32)
+    return out
+
+
+def shuffle_chunks_index(video_src_ids, u):
+    """model/dataloader.py:203-213"""
+    bsz, nchunk = video_src_ids.shape
+    mapping = np.argsort(u, -1, kind='stable')
+    new_id = np.take_along_axis(mapping, video_src_ids.astype(np.int64), 1)
+    trg = new_id * nchunk + np.arange(nchunk, dtype=np.int64)[None]
+    return np.argsort(trg, 1, kind='stable')
+
+
+def collate(examples, config, noise, device, is_training=True):
+    """`dataset.batch(batch_size)` + `_process_example` -> the features dict of model_fn, on `device`."""
+    bs = len(examples)
+    nc = config['num_chunks']
+    H, W = config['image_size']
+    host = {k: np.stack([e[k] for e in examples], 0) for k in
+            ('youtube_id', 'chunk_num', 'mean_time', 'input_ids', 'is_eoc', 'video_src_ids')}
+    frames = [f for e in examples for f in e['frames_u8']]
+    jobs = np.concatenate([e['jobs'] for e in examples])
+    order = np.arange(bs * nc).reshape(bs, nc)
+    if is_training and config.get('shuffle_chunks', False):
+        idx = shuffle_chunks_index(host['video_src_ids'], noise['u_chunks'])
+        for k in host:
+            host[k] = np.take_along_axis(host[k], idx.reshape(idx.shape + (1,) * (host[k].ndim - 2)), 1)
+        order = np.take_along_axis(order, idx, 1)
+    flat_order = order.reshape(-1)
+    images = frames_to_device([frames[i] for i in flat_order], jobs[flat_order], (H, W), device)
+    feats = {k: torch.from_numpy(np.ascontiguousarray(v)).to(device) for k, v in host.items()}
+    feats['images'] = images.reshape(bs, nc, H, W, 3)
+    if not is_training:                                     # `_process_example` is only mapped when training (:262-263)
+        return feats
+    n = config['num_chunks_in_group']
+    B = bs * nc // n
+    if config.get('image_shuffle_prob', 0.5) < 1e-6:
+        feats['shuffled_idx_img'] = torch.arange(n, dtype=torch.int32, device=device).repeat(B)
+    else:
+        feats['shuffled_idx_img'] = ops.shuffled_idx(torch.from_numpy(noise['num_shuffle']).to(device),
+                                                     torch.from_numpy(noise['u_sel']).to(device),
+                                                     torch.from_numpy(noise['u_perm']).to(device), B, n, 16)
+    feats['images'] = images                                # [bs * nc, H, W, 3]
+    if config.get('transpose_input', False):
+        feats['images'] = images.permute(1, 2, 3, 0).contiguous()
+    return feats
+
+
+class InputPipeline(object):
+    """`input_fn_builder(config, is_training)(params)` as a Python iterator of feature dicts.
+
+    Files: `data.train_file` / `data.val_file` glob; with world_size > 1 each rank reads `files[rank::world_size]` (the
+    multi-host branch, :160-166), otherwise all files, shuffled when training.  Records stream through a shuffle buffer
+    of `shuffle_buffer_size` (256), are parsed by `num_threads` host threads (JPEG decode releases the GIL) and batched
+    with drop_remainder; training repeats forever.  One background thread keeps `prefetch` batches ahead."""
+
+    def __init__(self, config, is_training, batch_size, device, rank=0, world_size=1, seed=0, prefetch=2):
+        self.merged = dict(config.data)
+        self.merged.update(config.model)
+        self.is_training, self.batch_size, self.device = is_training, batch_size, device
+        pattern = config.data['train_file'] if is_training else config.data['val_file']
+        files = sorted(f for p in str(pattern).split(',') for f in glob.glob(p))
+        if not files:
+            raise RecordError(f'no input files match {pattern}')
+        if world_size > 1:
+            if len(files) // world_size < 1:
+                raise RecordError(f'{len(files)} files cannot be sharded over {world_size} ranks')
+            files = files[rank::world_size]
+        self.files = files
+        self.rng = np.random.default_rng([seed, rank])
+        self.num_threads = max(1, min(int(config.data.get('num_threads', 64)), 16))
+        self.buffer_size = int(config.data.get('shuffle_buffer_size', 256))
+        self.prefetch = prefetch
+
+    def _records(self):
+        while True:
+            files = list(self.files)
+            if self.is_training:
+                self.rng.shuffle(files)
+            for f in files:
+                for r in read_tfrecords(f):
+                    yield r
+            if not self.is_training:
+                return
+
+    def _shuffled(self):
+        if not self.is_training:
+            yield from self._records()
+            return
+        buf = []
+        for r in self._records():
+            if len(buf) < self.buffer_size:
+                buf.append(r)
+                continue
+            i = int(self.rng.integers(0, len(buf)))
+            out, buf[i] = buf[i], r
+            yield out
+
+    def _host_batches(self):
+        from concurrent.futures import ThreadPoolExecutor
+        nc = self.merged['num_chunks']
+        with ThreadPoolExecutor(self.num_threads) as pool:
+            batch = []
+            for rec in self._shuffled():
+                batch.append((rec, draw_example_noise(self.rng, nc, self.merged)))
+                if len(batch) == self.batch_size:
+                    examples = list(pool.map(lambda a: parse_example_host(a[0], self.merged, a[1]), batch))
+                    yield examples, draw_batch_noise(self.rng, self.batch_size, nc, self.merged)
+                    batch = []
+
+    def __iter__(self):
+        q = queue.Queue(self.prefetch)
+        stop = object()
+
+        def work():
+            try:
+                for item in self._host_batches():
+                    q.put(item)
+                q.put(stop)
+            except BaseException as e:                    # surface loader errors in the consumer
+                q.put(e)
+
+        threading.Thread(target=work, daemon=True).start()
+        while True:
+            item = q.get()
+            if item is stop:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            examples, noise = item
+            yield collate(examples, self.merged, noise, self.device, self.is_training)

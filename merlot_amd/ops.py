@@ -414,3 +414,19 @@ def probe_tr16(tile):
     out = torch.empty_like(tile)
     call('merlot_probe_tr16', _p(tile), _p(out), _stream())
     return out
+
+
+# ---- input pipeline: frame preprocessing --------------------------------------------------------------
+def image_frames(src, jobs_host, jobs_dev, n_img, out_h, out_w):
+    """decoded frames (uint8, device, concatenated) + job table -> bf16 [n_img, out_h, out_w, 3] (csrc/image.hip)."""
+    _chk(src, torch.uint8, 'src'); _chk(jobs_dev, torch.uint8, 'jobs_dev')
+    if jobs_host.device.type != 'cpu' or jobs_host.dtype != torch.uint8 or jobs_host.numel() != n_img * 56:
+        raise ValueError('jobs_host: expected a CPU uint8 tensor holding n_img merlot_image_job_t entries')
+    if jobs_dev.numel() != jobs_host.numel():
+        raise ValueError('jobs_dev must mirror jobs_host')
+    nbytes = LIB.query('merlot_image_frames_workspace_bytes', n_img, out_h, out_w)
+    ws = torch.empty(nbytes // 4, device=src.device, dtype=F32)
+    out = torch.empty((n_img, out_h, out_w, 3), device=src.device, dtype=BF16)
+    call('merlot_image_frames', _p(src), src.numel(), jobs_host.data_ptr(), _p(jobs_dev), n_img, _p(out), out_h, out_w,
+         _p(ws), nbytes, _stream())
+    return out

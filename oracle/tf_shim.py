@@ -111,6 +111,9 @@ class T(torch.Tensor):
     def numpy_(self):
         return self.detach().cpu().numpy()
 
+    def set_shape(self, shape):
+        assert [int(d) for d in shape] == list(self.size()), (shape, self.size())
+
 
 def _w(x):
     return x.as_subclass(T) if isinstance(x, torch.Tensor) and not isinstance(x, T) else x
@@ -734,6 +737,60 @@ def random_categorical(logits, num_samples, dtype=None, seed=None, name=None):
     return _w(out)
 
 
+# input pipeline (utils/model_utils.py:742-940 run on these) ------------------------------------------------------
+class _Dead(object):
+    """the untaken output of control_flow_ops.switch: ops that receive it produce it"""
+    def __repr__(self):
+        return '<dead tensor>'
+
+
+DEAD = _Dead()
+
+
+def cf_switch(data, pred, dtype=None, name=None):
+    taken = bool(_t(pred))
+    return (DEAD if taken else data, data if taken else DEAD)
+
+
+def cf_merge(inputs, name=None):
+    for i, x in enumerate(inputs):
+        if x is not DEAD:
+            return x, i
+    raise RuntimeError('merge of dead tensors only')
+
+
+def tf_cond(pred, true_fn=None, false_fn=None, name=None):
+    return true_fn() if bool(_t(pred)) else false_fn()
+
+
+def switch_case(branch_index, branch_fns, default=None, name=None):
+    return branch_fns[int(_t(branch_index))]()
+
+
+def image_resize_images(images, size, method=0, align_corners=False, preserve_aspect_ratio=False, name=None):
+    """tf.image.resize_images on one [h, w, c] fp32 image: the TF-1.15 kernels restated in oracle/input_oracle.py."""
+    from . import input_oracle
+    if images is DEAD:
+        return DEAD
+    assert align_corners and not preserve_aspect_ratio, "only the align_corners=True form the reference uses"
+    x = _t(images)
+    assert x.dim() == 3 and x.dtype == torch.float32
+    out = input_oracle.resize_images(x.detach().numpy(), [int(_t(v)) for v in size], int(method))
+    return _w(torch.from_numpy(np.ascontiguousarray(out)))
+
+
+def image_pad_to_bounding_box(image, offset_height, offset_width, target_height, target_width):
+    from . import input_oracle
+    out = input_oracle.pad_to_bounding_box(_t(image).detach().numpy(), int(offset_height), int(offset_width),
+                                           int(target_height), int(target_width))
+    return _w(torch.from_numpy(out))
+
+
+def io_decode_raw(input_bytes, out_type=torch.uint8, **_):
+    assert out_type == torch.uint8
+    return _w(torch.from_numpy(np.frombuffer(bytes(input_bytes), np.uint8).copy()))
+
+
 # gradients / misc graph-mode API ------------------------------------------------------------------------------
 def gradients(ys, xs, **_):
     ys = ys if isinstance(ys, (list, tuple)) else [ys]
@@ -915,9 +972,12 @@ def build_modules():
                  embedding_lookup=embedding_lookup, l2_normalize=l2_normalize)
     tf.layers = _mod('tensorflow.layers', dense=dense, conv2d=conv2d_layer, Conv2D=Conv2DLayer)
     tf.pad = tf_pad
-    # referenced only in default arguments of input-pipeline functions that are never called here
     tf.image = _mod('tensorflow.image', ResizeMethod=types.SimpleNamespace(BILINEAR=0, NEAREST_NEIGHBOR=1,
-                                                                           BICUBIC=2, AREA=3))
+                                                                           BICUBIC=2, AREA=3),
+                    resize_images=image_resize_images, pad_to_bounding_box=image_pad_to_bounding_box)
+    tf.io = _mod('tensorflow.io', decode_raw=io_decode_raw)
+    tf.cond = tf_cond
+    tf.switch_case = switch_case
     # estimator / tpu / train scaffolding
     tf.estimator = _mod('tensorflow.estimator',
                         ModeKeys=types.SimpleNamespace(TRAIN='train', EVAL='eval', PREDICT='infer'))
@@ -951,6 +1011,8 @@ def build_modules():
         'tensorflow.compiler.tf2xla.python': _mod('tensorflow.compiler.tf2xla.python'),
         'tensorflow.compiler.tf2xla.python.xla': xla,
     }
+    mods['tensorflow.python.ops.control_flow_ops'].switch = cf_switch
+    mods['tensorflow.python.ops.control_flow_ops'].merge = cf_merge
     mods['tensorflow.python.ops'].control_flow_ops = mods['tensorflow.python.ops.control_flow_ops']
     mods['tensorflow.contrib.tpu.python.ops'].tpu_ops = mods['tensorflow.contrib.tpu.python.ops.tpu_ops']
     mods['tensorflow.contrib.tpu.python.tpu'].tpu_function = tpu_function

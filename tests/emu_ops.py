@@ -417,11 +417,32 @@ def cast_transpose_batched(src_base, dst_base, jobs, total_tiles):
         dst_base[do:do + C * ld].view(C, ld)[:, :R] = src_base[so:so + R * C].view(R, C).t().to(BF16)
 
 
+def image_frames(src, jobs_host, jobs_dev, n_img, out_h, out_w):
+    """csrc/image.hip transcribed onto the oracle's TF kernels (frame = resize + crop + pad + finite + augment -> bf16)."""
+    from merlot_amd.input_pipeline import JOB_DTYPE
+    from oracle import input_oracle as io_
+    jobs = jobs_host.numpy().view(JOB_DTYPE)
+    flat = src.cpu().numpy()
+    out = torch.empty((n_img, out_h, out_w, 3), dtype=BF16)
+    for i, j in enumerate(jobs):
+        h, w = int(j['src_h']), int(j['src_w'])
+        img = flat[int(j['src_offset']):int(j['src_offset']) + h * w * 3].reshape(h, w, 3)
+        x = io_.resize_images(io_.convert_image_dtype_u8_to_f32(img), (int(j['scaled_h']), int(j['scaled_w'])), int(j['method']))
+        x = x[int(j['offset_y']):int(j['offset_y']) + out_h, int(j['offset_x']):int(j['offset_x']) + out_w]
+        x = io_.pad_to_bounding_box(x, 0, 0, out_h, out_w)
+        x = np.where(np.isfinite(x), x, np.float32(0))
+        k = int(j['aug_kind'])
+        if k:
+            x = io_.augment(x, True, k - 1, j['factor'], fix_selection=True)     # the job already carries the effective kind
+        out[i] = torch.from_numpy(x).to(BF16)
+    return out
+
+
 _NAMES = ['gemm_nt', 'gemm_tn', 'patch_embed_fwd', 'patch_embed_wgrad', 'ln_fwd', 'ln_bwd', 'attention_fwd',
           'attention_bwd', 'attention_colsum', 'cast_bf16', 'cast_transpose_bf16', 'colsum_bf16', 'gather_add4',
           'scatter_add_rows', 'dropout_apply', 'cls_avgpool_fwd', 'cls_avgpool_bwd', 'softmax_ce', 'l2norm_fwd',
           'l2norm_bwd', 'gelu_fwd', 'gelu_bwd', 'mask_inputs', 'temporal_labels', 'shuffled_idx', 'im2col3x3', 'col2im3x3',
-          'groupnorm_fwd', 'groupnorm_bwd', 'avgpool2_fwd', 'avgpool2_bwd', 'cast_transpose_batched']
+          'groupnorm_fwd', 'groupnorm_bwd', 'avgpool2_fwd', 'avgpool2_bwd', 'cast_transpose_batched', 'image_frames']
 
 
 def install(monkeypatch):
