@@ -25,6 +25,12 @@ build container:
   bit-exact (masked ids/idx, bf16 optimizer states).
   ``tests/test_reference_shim.py`` checks this from the fixtures everywhere and
   re-runs the reference live where /root/reference exists.
+* ``tests/golden/ref_shim_input_pipeline.npz`` -- the input-pipeline functions
+  of utils/model_utils.py (resize_and_pad, lightweight_image_augment,
+  encode_string, pad_to_fixed_size, sample_bernoulli) executed the same way
+  (``tests/golden/make_input_golden.py``); ``oracle/input_oracle.py`` agrees to
+  <= 2e-7.  The four tf.image resize kernels underneath are restated from the
+  TF-1.15 sources (**parity unpinned** for those, as for every primitive).
 * ``tests/golden/sort_story_ref.npz`` / ``tokenizer_ref.npz`` -- pure-python
   reference functions (score_permutations.py, encoder.py constants) executed
   directly (``tests/golden/make_golden.py``).
