@@ -249,6 +249,10 @@ int merlot_probe_tr16(const void* tile, void* out, merlot_stream_t stream);
 /* experiment helper: copy the persistent GEMM's per-workgroup timeline (recorded when MERLOT_DBG has bit 512) */
 int merlot_probe_persist_trace(void* dst, int64_t bytes, merlot_stream_t stream);
 int merlot_probe_cu_hog(int blocks, int lds_bytes, int64_t cycles, void* sink, merlot_stream_t stream);
+/* experiment helper: matrix-pipe rate of `blocks` 8-wave workgroups issuing the 256x256 GEMM's K-step instruction mix
+ * (16 MFMA 32x32x16 per wave and iteration; mode bit 1: + its 12 ds_read_b128, bit 2: + s_barrier, bit 4: MFMA operands
+ * come from those reads).  out: int64 [blocks][4] = {shader-clock delta, 100 MHz wall-clock delta, 0, 0}. */
+int merlot_probe_mfma_rate(int blocks, int iters, int mode, void* out, void* sink, merlot_stream_t stream);
 
 /* ---- input pipeline: frame preprocessing ---------------------------------------------------------
  * One job per frame: decoded JPEG (HWC uint8, device) -> convert_image_dtype * resize_images(method, align_corners=True)

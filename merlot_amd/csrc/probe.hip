@@ -40,7 +40,80 @@ __global__ void probe_cu_hog_kernel(long long cycles, unsigned int* sink) {
     }
     if (acc == 0xffffffffu) sink[0] = acc;
 }
+// Matrix-pipe ceiling under the GEMM's own instruction mix (experiments): every wave owns 8 accumulators of 32x32 and
+// issues 16 MFMAs per iteration -- a K-step of the 256x256 kernel -- optionally with that K-step's 12 ds_read_b128
+// fragment reads (mode & 1), its s_barrier (mode & 2) and register operands refreshed from those reads (mode & 4).
+// out[block] = {s_memtime delta, s_memrealtime delta (100 MHz), 0, 0}.
+__global__ __launch_bounds__(512) void probe_mfma_rate_kernel(int iters, int mode, long long* out, float* sink) {
+    extern __shared__ __attribute__((aligned(1024))) char plds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 32768 / 4; i += blockDim.x) reinterpret_cast<float*>(plds)[i] = 0.f;
+    __syncthreads();
+    f32x16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    bf16x8 fa[2], fb[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fa[i][e] = (bf16)0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fb[i][e] = (bf16)0.f;
+    const int hi = lane >> 5;
+    const long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+        if (mode & 2) __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            if (mode & 1) {
+                bf16x8 ra[2], rb[4];
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    const int row = ((wave >> 1) * 2 + f) * 32 + (lane & 31);
+                    ra[f] = *reinterpret_cast<const bf16x8*>(plds + row * 64 + ((((2 * kk + hi) ^ (row >> 2)) & 3) << 4));
+                }
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    const int row = ((wave & 1) * 4 + f) * 32 + (lane & 31);
+                    rb[f] = *reinterpret_cast<const bf16x8*>(plds + 16384 + row * 64 + ((((2 * kk + hi) ^ (row >> 2)) & 3) << 4));
+                }
+                if (mode & 4) {
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) fa[f] = ra[f];
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) fb[f] = rb[f];
+                } else {
+                    asm volatile("" ::"v"(ra[0]), "v"(ra[1]), "v"(rb[0]), "v"(rb[1]), "v"(rb[2]), "v"(rb[3]));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i * 4 + j], 0, 0, 0);
+        }
+    }
+    const long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0];
+    if (s == 123.456f) sink[0] = s;
+    if (threadIdx.x == 0) {
+        out[blockIdx.x * 4 + 0] = t1 - t0;
+        out[blockIdx.x * 4 + 1] = r1 - r0;
+    }
+}
 }  // namespace
+
+extern "C" int merlot_probe_mfma_rate(int blocks, int iters, int mode, void* out, void* sink, merlot_stream_t stream) {
+    MERLOT_CHECK(out && sink && blocks > 0 && iters > 0, MERLOT_ESHAPE, "merlot_probe_mfma_rate: bad arguments");
+    hipLaunchKernelGGL(probe_mfma_rate_kernel, dim3(blocks), dim3(512), 32768, (hipStream_t)stream, iters, mode,
+                       (long long*)out, (float*)sink);
+    return merlot_launch_status("merlot_probe_mfma_rate");
+}
 
 extern "C" int merlot_probe_mfma32(const void* a, const void* b, float* d, merlot_stream_t stream) {
     MERLOT_CHECK(a && b && d, MERLOT_ESHAPE, "merlot_probe_mfma32: null operand");

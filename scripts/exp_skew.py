@@ -1,0 +1,38 @@
+"""A/B of the persistent NT GEMM main loop: id 21 (barrier at the top of the K-step) vs id 22 (half-step skewed
+software pipeline), full kernel and main loop only (MERLOT_DBG=1), on the step's four big shapes; results must agree
+bit for bit (same MFMA order per accumulator)."""
+import os
+import sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from merlot_amd import ops
+from exp_epi import bench
+
+dev = 'cuda'
+T = int(os.environ.get('T', 101376))
+torch.manual_seed(0)
+for name, N, K, epi in [('qkv', 2304, 768, 'none'), ('proj', 768, 768, 'residual'), ('fc1', 3072, 768, 'gelu'), ('fc2', 768, 3072, 'residual'),
+                        ('dgrad_fc1', 768, 3072, 'none'), ('dgrad_fc2', 3072, 768, 'dgelu')]:
+    a = torch.randn(T, K, device=dev).bfloat16()
+    b = (torch.randn(N, K, device=dev) * 0.02).bfloat16()
+    bias = torch.randn(N, device=dev) * 0.1
+    aux = torch.empty(T, N, device=dev, dtype=torch.bfloat16)
+    res = torch.randn(T, N, device=dev).bfloat16()
+    fn = {'none': lambda: ops.gemm_nt(a, b, bias=bias),
+          'gelu': lambda: ops.gemm_nt(a, b, bias=bias, epilogue=ops.EPI_GELU, aux_out=aux),
+          'residual': lambda: ops.gemm_nt(a, b, bias=bias, epilogue=ops.EPI_RESIDUAL, aux_in=res, dropout_p=0.1, dropout_seed=1),
+          'dgelu': lambda: ops.gemm_nt(a, b, epilogue=ops.EPI_DGELU, aux_in=res)}[epi]
+    out, row = {}, []
+    for cfg in ('21', '22'):
+        os.environ['MERLOT_NT_CFG_DYN'] = cfg
+        os.environ['MERLOT_DBG'] = '0'
+        out[cfg] = fn().clone()
+        t = bench(fn, 30)
+        os.environ['MERLOT_DBG'] = '1'
+        tl = bench(fn, 30)
+        os.environ['MERLOT_DBG'] = '0'
+        fl = 2.0 * T * N * K
+        row.append(f'id {cfg}: {t:7.1f} us {fl / t / 1e6:6.0f} TF | loop only {tl:7.1f} us {fl / tl / 1e6:6.0f} TF')
+    same = torch.equal(out['21'], out['22'])
+    print(f'{name:10s} [{T} x {N} x {K}] {epi:8s} ' + '   '.join(row) + f'   identical={same}', flush=True)
+    assert same
