@@ -1030,12 +1030,7 @@ constexpr int TRACE_TILES = 32;
 __device__ long long g_persist_trace[256 * TRACE_TILES * 4];
 __device__ unsigned int g_persist_ctr[PERSIST_SLOTS * 16];   // [slot][0..7] claims per XCD, [slot][8] departures
 
-// SKEW: the K-step is software-pipelined by half a step.  Fragments of (stage g, k 16..31) are read while the MFMAs of
-// (stage g, k 0..15) issue; the wait + s_barrier that opens stage g+1 sits in the MIDDLE of the step, followed by the
-// LDS-DMA refill of the slot just drained and the fragment reads of (stage g+1, k 0..15), which fly under the second
-// eight MFMAs of stage g.  No MFMA waits on an LDS read issued after the barrier it follows, and because a slot is
-// refilled right after its last read the three-slot ring runs THREE stages ahead.
-template <int EPI, bool OUT_F32, bool SKEW>
+template <int EPI, bool OUT_F32>
 __global__ __launch_bounds__(512) void gemm_nt_persist_dyn_kernel(const GemmNTArgs p, const int ctr_slot) {
     using C = RingP;
     extern __shared__ __attribute__((aligned(1024))) char dsm[];
@@ -1147,11 +1142,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_dyn_kernel(const GemmNTAr
     __syncthreads();
     set_tile(slot);                                      // grid <= ntiles: the first tile is the static one
 #pragma unroll
-    for (int t = 0; t < (SKEW ? S : S - 1); ++t) stage_next();
-    if (SKEW) {                                          // stage 0 landed and visible before the first fragment read
-        ring::wait_vmcnt<(S - 1) * C::LOADS>();
-        __builtin_amdgcn_s_barrier();
-    }
+    for (int t = 0; t < S - 1; ++t) stage_next();
 
     int g = 0;
     int trace_i = 0;
@@ -1167,60 +1158,27 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_dyn_kernel(const GemmNTAr
             for (int j = 0; j < C::FN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        if constexpr (SKEW) {
-            auto read_frags = [&](int stage, int kk, bf16x8 (&af)[C::FM], bf16x8 (&bfr)[C::FN]) {
-                const char* la = dsm + (stage % S) * C::STAGE_BYTES;
-                const char* lb = la + C::A_BYTES;
+        for (int kt = 0; kt < nk; ++kt, ++g) {
+            if (ld_step - g == S - 1)
+                ring::wait_vmcnt<(S - 2) * C::LOADS>();
+            else
+                ring::wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            stage_next();
+            const char* la = dsm + (g % S) * C::STAGE_BYTES;
+            const char* lb = la + C::A_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                bf16x8 af[C::FM], bfr[C::FN];
 #pragma unroll
                 for (int f = 0; f < C::FM; ++f) af[f] = *reinterpret_cast<const bf16x8*>(la + ring::kc_off<BK>(a_row[f], 2 * kk + hi));
 #pragma unroll
                 for (int f = 0; f < C::FN; ++f) bfr[f] = *reinterpret_cast<const bf16x8*>(lb + ring::kc_off<BK>(b_row[f], 2 * kk + hi));
-            };
-            auto mfma8 = [&](const bf16x8 (&af)[C::FM], const bf16x8 (&bfr)[C::FN]) {
 #pragma unroll
                 for (int fi = 0; fi < C::FM; ++fi)
 #pragma unroll
                     for (int fj = 0; fj < C::FN; ++fj)
                         acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[fj], af[fi], acc[fi][fj], 0, 0, 0);
-            };
-            bf16x8 a0[C::FM], b0[C::FN], a1[C::FM], b1[C::FN];
-            read_frags(g, 0, a0, b0);                    // the one exposed read per tile
-            for (int kt = 0; kt < nk; ++kt, ++g) {
-                read_frags(g, 1, a1, b1);
-                mfma8(a0, b0);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave has drained stage g
-                if (ld_step - g == S)
-                    ring::wait_vmcnt<(S - 2) * C::LOADS>();          // stage g+1 has landed
-                else
-                    ring::wait_vmcnt<0>();
-                __builtin_amdgcn_s_barrier();
-                stage_next();                            // refill slot g % S with stage g + S
-                if (kt + 1 < nk) read_frags(g + 1, 0, a0, b0);
-                mfma8(a1, b1);
-            }
-        } else {
-        for (int kt = 0; kt < nk; ++kt, ++g) {
-                if (ld_step - g == S - 1)
-                    ring::wait_vmcnt<(S - 2) * C::LOADS>();
-                else
-                    ring::wait_vmcnt<0>();
-                __builtin_amdgcn_s_barrier();
-                stage_next();
-                const char* la = dsm + (g % S) * C::STAGE_BYTES;
-                const char* lb = la + C::A_BYTES;
-    #pragma unroll
-                for (int kk = 0; kk < BK / 16; ++kk) {
-                    bf16x8 af[C::FM], bfr[C::FN];
-    #pragma unroll
-                    for (int f = 0; f < C::FM; ++f) af[f] = *reinterpret_cast<const bf16x8*>(la + ring::kc_off<BK>(a_row[f], 2 * kk + hi));
-    #pragma unroll
-                    for (int f = 0; f < C::FN; ++f) bfr[f] = *reinterpret_cast<const bf16x8*>(lb + ring::kc_off<BK>(b_row[f], 2 * kk + hi));
-    #pragma unroll
-                    for (int fi = 0; fi < C::FM; ++fi)
-    #pragma unroll
-                        for (int fj = 0; fj < C::FN; ++fj)
-                            acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[fj], af[fi], acc[fi][fj], 0, 0, 0);
-                }
             }
         }
         if ((p.dbg & 512) && tid == 0 && trace_i < TRACE_TILES)
@@ -1485,9 +1443,9 @@ int launch_persist_one(GemmNTArgs& a, hipStream_t s) {
     return merlot_launch_status("merlot_gemm_bf16_nt(persistent)");
 }
 
-template <int EPI, bool OUT_F32, bool SKEW>
+template <int EPI, bool OUT_F32>
 int launch_persist_dyn_one(GemmNTArgs& a, hipStream_t s) {
-    auto kern = gemm_nt_persist_dyn_kernel<EPI, OUT_F32, SKEW>;
+    auto kern = gemm_nt_persist_dyn_kernel<EPI, OUT_F32>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1505,11 +1463,10 @@ int launch_persist_dyn_one(GemmNTArgs& a, hipStream_t s) {
     return merlot_launch_status("merlot_gemm_bf16_nt(persistent, dynamic)");
 }
 
-int launch_persist(GemmNTArgs& a, int epilogue, int out_f32, int kind, hipStream_t s) {   // 0 static, 1 dynamic claims, 2 dynamic + skewed loop
+int launch_persist(GemmNTArgs& a, int epilogue, int out_f32, int kind, hipStream_t s) {   // 0 static, 1 dynamic claims
 #define PERSIST_CASE(E)                                                                                      \
     case E:                                                                                                  \
-        if (kind == 2) return out_f32 ? launch_persist_dyn_one<E, true, true>(a, s) : launch_persist_dyn_one<E, false, true>(a, s); \
-        if (kind == 1) return out_f32 ? launch_persist_dyn_one<E, true, false>(a, s) : launch_persist_dyn_one<E, false, false>(a, s); \
+        if (kind == 1) return out_f32 ? launch_persist_dyn_one<E, true>(a, s) : launch_persist_dyn_one<E, false>(a, s); \
         return out_f32 ? launch_persist_one<E, true>(a, s) : launch_persist_one<E, false>(a, s);
     switch (epilogue) {
         PERSIST_CASE(MERLOT_EPI_NONE)
@@ -1549,8 +1506,8 @@ int gemm_nt_dispatch(GemmNTArgs& a, int epilogue, int out_f32, hipStream_t s) {
         const int64_t tiles = (int64_t)cdiv(a.M, 256) * cdiv(a.N, 256);
         const int64_t rounds = (tiles + 255) / 256;
         static const int persist_id = [] {
-            const char* e = getenv("MERLOT_NT_PERSIST_ID");            // 20 static striding / 21 dynamic claims /
-            return e ? atoi(e) : 22;                                   // 22 dynamic claims + half-step skewed loop
+            const char* e = getenv("MERLOT_NT_PERSIST_ID");            // 20 static striding / 21 dynamic claims
+            return e ? atoi(e) : 21;
         }();
         cfg = (tiles * 100 >= rounds * 256 * 85) ? persist_id : 11;
         // narrow outputs (the ResNet-stem convolutions with 32..128 filters): a 256-wide tile would compute 2-8x the
@@ -1566,7 +1523,6 @@ int gemm_nt_dispatch(GemmNTArgs& a, int epilogue, int out_f32, hipStream_t s) {
         case 15: return launch_ring<RingN128>(a, epilogue, out_f32, s);
         case 20: return launch_persist(a, epilogue, out_f32, 0, s);
         case 21: return launch_persist(a, epilogue, out_f32, a.K / RingP::BK >= 4 ? 1 : 0, s);
-        case 22: return launch_persist(a, epilogue, out_f32, a.K / RingP::BK >= 4 ? 2 : 0, s);
         default: break;
     }
     a.ntm = cdiv(a.M, BM);

@@ -1,6 +1,7 @@
-"""A/B of the persistent NT GEMM main loop: id 21 (barrier at the top of the K-step) vs id 22 (half-step skewed
-software pipeline), full kernel and main loop only (MERLOT_DBG=1), on the step's four big shapes; results must agree
-bit for bit (same MFMA order per accumulator)."""
+"""A/B harness for NT GEMM configurations (CFGS=21,11,11,21 ...): full kernel and main loop only (MERLOT_DBG=1) on the
+step's big shapes, mirrored order after a warm-up; results must agree bit for bit (same MFMA order per accumulator).
+Used for the id 21 vs id 22 (half-step skewed loop, since removed) and 256x256 vs 128x256 comparisons of
+profiles/r01_i_gemm_ceiling.txt."""
 import os
 import sys
 import torch
@@ -23,7 +24,11 @@ for name, N, K, epi in [('qkv', 2304, 768, 'none'), ('proj', 768, 768, 'residual
           'residual': lambda: ops.gemm_nt(a, b, bias=bias, epilogue=ops.EPI_RESIDUAL, aux_in=res, dropout_p=0.1, dropout_seed=1),
           'dgelu': lambda: ops.gemm_nt(a, b, epilogue=ops.EPI_DGELU, aux_in=res)}[epi]
     out, row = {}, []
-    for cfg in ('21', '22'):
+    cfgs = os.environ.get('CFGS', '21,11,11,21').split(',')       # ABBA: the first measurement after new allocations
+    os.environ['MERLOT_NT_CFG_DYN'] = cfgs[0]                      # runs ~10 % slow (clock ramp), so warm up first and
+    os.environ['MERLOT_DBG'] = '0'                                 # measure every config twice in mirrored order
+    bench(fn, 60)
+    for cfg in cfgs:
         os.environ['MERLOT_NT_CFG_DYN'] = cfg
         os.environ['MERLOT_DBG'] = '0'
         out[cfg] = fn().clone()
@@ -33,6 +38,7 @@ for name, N, K, epi in [('qkv', 2304, 768, 'none'), ('proj', 768, 768, 'residual
         os.environ['MERLOT_DBG'] = '0'
         fl = 2.0 * T * N * K
         row.append(f'id {cfg}: {t:7.1f} us {fl / t / 1e6:6.0f} TF | loop only {tl:7.1f} us {fl / tl / 1e6:6.0f} TF')
-    same = torch.equal(out['21'], out['22'])
+    ks = list(out)
+    same = all(torch.equal(out[ks[0]], out[k]) for k in ks[1:])
     print(f'{name:10s} [{T} x {N} x {K}] {epi:8s} ' + '   '.join(row) + f'   identical={same}', flush=True)
     assert same
