@@ -144,7 +144,12 @@ class MerlotModel(object):
         nl_vit = cfg.get('num_vision_transformer_hidden_layers', cfg['num_hidden_layers'])
         nl_enc = max(cfg['num_hidden_layers'], cfg.get('num_lang_transformer_hidden_layers', 0))
         self._vit = StackW(st, 'vision_backbone/vision_transformer', nl_vit)
-        self._enc = StackW(st, 'encoder', nl_enc)
+        if cfg.get('share_params', True):                    # one stack, used by the text-only AND the joint pass
+            self._enc = StackW(st, 'encoder', nl_enc)
+            self._lang_enc = self._enc
+        else:                                                # model/modeling.py:357-362: separate `langonly_encoder`
+            self._enc = StackW(st, 'encoder', cfg['num_hidden_layers'])
+            self._lang_enc = StackW(st, 'langonly_encoder', cfg['num_lang_transformer_hidden_layers'])
         self.word_embedding_table = st.p('word_embeddings/word_embeddings')
         self._emb = st.lin('word_embeddings/word_embeddings', need_T=True, bias=False)
 
@@ -340,13 +345,11 @@ class MerlotModel(object):
             ids2d = self.input_ids.reshape(self.batch_size * ngroups, self.lang_chunk_length * g)
         else:
             ids2d = self.input_ids.reshape(self.batch_size, self.lang_chunk_length * self.num_chunks)
-        if not cfg.get('share_params', True):
-            raise NotImplementedError("share_params: False (separate langonly_encoder) is not supported")
         R, Sl = ids2d.shape
         emb = self.embed_words(ids2d, norm_scope_name='langonly_embeddings')
         valid = (ids2d != 0).to(torch.uint8).contiguous()
         summ = torch.zeros((R, Sl), device=self.device, dtype=F32)
-        hs = L.transformer_stack(emb.reshape(R * Sl, H), self._enc, R, Sl, valid,
+        hs = L.transformer_stack(emb.reshape(R * Sl, H), self._lang_enc, R, Sl, valid,
                                  dict(heads=cfg['num_attention_heads'],
                                       dropout_p=self.dropout_prob if self.is_training else 0.0, seed=self.seed * 4 + 1,
                                       num_layers=cfg['num_lang_transformer_hidden_layers'], colsum=summ))

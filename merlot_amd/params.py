@@ -103,7 +103,11 @@ def param_entries(cfg):
     for sc in ['langonly_embeddings', 'position_embeddings']:
         e += [(f'{sc}/position_embeddings', (cfg['max_position_embeddings'], H), 'normal'),
               (f'{sc}/LayerNorm_embed_norm/gamma', (H,), 'ones'), (f'{sc}/LayerNorm_embed_norm/beta', (H,), 'zeros')]
-    e += _stack_entries('encoder', nl_enc, H, I)
+    if cfg.get('share_params', True):                        # model/modeling.py:171-172, 357-362
+        e += _stack_entries('encoder', nl_enc, H, I)
+    else:
+        e += _stack_entries('encoder', cfg['num_hidden_layers'], H, I)
+        e += _stack_entries('langonly_encoder', cfg['num_lang_transformer_hidden_layers'], H, I)
     e += [('lm_head/projection/kernel', (H, H), 'normal'), ('lm_head/projection/bias', (H,), 'zeros'),
           ('lm_head/LayerNorm/gamma', (H,), 'ones'), ('lm_head/LayerNorm/beta', (H,), 'zeros'),
           ('lm_head/output_bias', (V,), 'zeros')]

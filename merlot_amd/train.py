@@ -53,8 +53,9 @@ class Trainer(object):
         from .parallel import FORCE
         if dist_ctx is not None and (world > 1 or FORCE):
             # encoder weights receive gradients from the joint AND the text-only pass before they may be reduced
+            shared = 2 if config.model.get('share_params', True) else 1
             self.reducer = GradReducer(self.store, dist_ctx,
-                                       expected_passes={'encoder': 2, 'encoder/LayerNorm_ln_final': 2, '*': 1},
+                                       expected_passes={'encoder': shared, 'encoder/LayerNorm_ln_final': shared, '*': 1},
                                        defer=self.opt.clip_norm > 0.0)
         self.step_idx = 0
         # model/modeling.py:724-738: variables the init checkpoint also holds (weights and, since this is the training

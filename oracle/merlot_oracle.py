@@ -624,8 +624,11 @@ def variable_shapes(cfg):
     for sc in ['langonly_embeddings', 'position_embeddings']:
         shapes[f'{sc}/position_embeddings'] = (cfg['max_position_embeddings'], H)
         ln(f'{sc}/LayerNorm_embed_norm')
-    nl_enc = max(cfg['num_hidden_layers'], cfg.get('num_lang_transformer_hidden_layers', 0))
-    stack('encoder', nl_enc)
+    if cfg.get('share_params', True):                        # model/modeling.py:171-172, 357-362
+        stack('encoder', max(cfg['num_hidden_layers'], cfg.get('num_lang_transformer_hidden_layers', 0)))
+    else:
+        stack('encoder', cfg['num_hidden_layers'])
+        stack('langonly_encoder', cfg['num_lang_transformer_hidden_layers'])
     dn('lm_head/projection', H, H)
     ln('lm_head/LayerNorm')
     shapes['lm_head/output_bias'] = (V,)

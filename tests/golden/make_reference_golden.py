@@ -223,6 +223,7 @@ def main():
     make_sort_story()
     make_inference_2d()
     make_resnet_stem()
+    make_variants()
 
 
 def make_dp2(cfg, weights, optimizer_cfg):
@@ -444,5 +445,62 @@ def make_resnet_stem():
     print('wrote ref_shim_resnet_stem.npz')
 
 
+VARIANTS = {'unshared': dict(share_params=False, num_lang_transformer_hidden_layers=1),
+            'langonly_groups': dict(langonly_num_chunks_in_group=2),
+            'block_mask': dict(disable_pairwise_lang_attn=True)}
+VARIANT_GRADS = ('encoder/layer00/query_layer/kernel', 'encoder/layer01/output/kernel', 'word_embeddings/word_embeddings',
+                 'langonly_embeddings/position_embeddings', 'langonly_encoder/layer00/intermediate/kernel',
+                 'langonly_encoder/LayerNorm_ln_final/gamma')
+
+
+def make_variants():
+    """The constructor's remaining config branches on the training graph: `share_params: False` (a separate
+    `langonly_encoder` scope, model/modeling.py:357-362, with its own depth), `langonly_num_chunks_in_group`
+    (:345-351) and `disable_pairwise_lang_attn` (:160-168)."""
+    fx = {}
+    for name, over in VARIANTS.items():
+        cfg = tiny_config(use_bfloat16=False, **over)
+        batch = synth_batch(cfg, E=2, num_chunks=4, Lc=32, seed=3)
+        weights = mo.init_weights(cfg, seed=8, perturb=True)
+        tf_shim.STATE.reset(seed=11, injected={k: npy(v) for k, v in weights.items()})
+        ref = run_reference(cfg, weights, batch, seed=11)
+        m = ref['model']
+        st = tf_shim.STATE
+        names = sorted(n for n in st.vars if 'adam_' not in n and n != 'global_step')
+        assert names == sorted(weights), sorted(set(names) ^ set(weights))
+        assert not [n for n in st.created_by_initializer if 'adam_' not in n and n != 'global_step']
+        noise = draws_to_noise(st.draws, m.B, m.L, int(m.L * cfg['masking_rate']))
+        grads = tf.gradients(ref['loss'], [st.vars[n] for n in VARIANT_GRADS if n in st.vars])
+        gnames = [n for n in VARIANT_GRADS if n in st.vars]
+        for t in weights.values():
+            t.requires_grad_(True)
+        o = mo.MerlotOracle(cfg, weights, batch['image'], batch['input_ids'], mask_input=True,
+                            shuffled_idx_img=batch['shuffled_idx_img'], noise=noise)
+        o_loss, _ = o.total_loss(batch['shuffled_idx_img'], batch['video_src_ids'])
+        o_loss.backward()
+        e_loss = abs(float(o_loss) - float(npy(ref['loss'])))
+        e_g = max(float(np.abs(npy(weights[n].grad) - npy(g)).max() / (np.abs(npy(g)).max() + 1e-30)) for n, g in zip(gnames, grads))
+        same_idx = np.array_equal(npy(o.lang_mask_info['masked_idx']), npy(m.lang_mask_info['masked_idx']))
+        print(f'variant {name}: {len(names)} variables, loss err {e_loss:.2e}, worst sampled gradient err {e_g:.2e}, masked_idx equal {same_idx}')
+        assert e_loss < 2e-5 and e_g < 2e-4 and same_idx
+        p = name + '/'
+        fx[p + 'variable_names'] = np.array(names)
+        fx[p + 'loss'] = npy(ref['loss'])
+        fx[p + 'losses'] = np.array([float(npy(ref['lang']['loss'])), float(npy(ref['contr']['loss_all'])), float(npy(ref['temporal']['loss']))])
+        fx[p + 'masked_idx'] = npy(m.lang_mask_info['masked_idx']).astype(np.int32)
+        fx[p + 'masked_ids'] = npy(m.lang_mask_info['masked_ids']).astype(np.int32)
+        fx[p + 'encoder_lang'] = head(npy(m.encoder_hidden_states['lang']).reshape(-1, 768))
+        fx[p + 'lang_trg_h'] = head(npy(m.lang_trg_h))
+        for k, v in noise.items():
+            fx[p + 'noise/' + k] = v
+        for n, g in zip(gnames, grads):
+            fx[p + 'grad/' + n] = head(npy(g))
+    np.savez_compressed(os.path.join(OUT, 'ref_shim_variants.npz'), **fx)
+    print('wrote ref_shim_variants.npz')
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'variants':
+        make_variants()
+    else:
+        main()

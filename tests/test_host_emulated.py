@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from common import tiny_config, synth_batch, rel_l2
+from common import tiny_config, synth_batch, rel_l2, head
 from oracle import merlot_oracle as mo
 
 
@@ -256,3 +256,43 @@ def test_clip_by_global_norm_matches_reference_rule():
         factor = clip / max(norm_ref, clip)
         for n in st.names():
             assert torch.allclose(st.g(n), ref[n] * factor, rtol=1e-5, atol=1e-8), n
+
+
+@pytest.mark.parametrize('name', ['unshared', 'langonly_groups'])
+def test_config_variants_match_reference_program(emu, name):
+    """the host wiring of `share_params: False` (own `langonly_encoder` weights, its own depth) and
+    `langonly_num_chunks_in_group` against what the reference program computed (tests/golden/ref_shim_variants.npz)."""
+    import os
+    from merlot_amd import MerlotModel, ParamStore
+    from test_reference_shim import VARIANTS
+    fx = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'ref_shim_variants.npz'))
+    p = name + '/'
+    cfg = tiny_config(**VARIANTS[name])
+    b = synth_batch(cfg, E=2, num_chunks=4, Lc=32, seed=3)
+    w = mo.init_weights(cfg, seed=8, perturb=True)
+    st = ParamStore(cfg, 'cpu', seed=0)
+    assert st.load_tf_weights(w) == []
+    assert sorted(st.export_tf_weights()) == [str(n) for n in fx[p + 'variable_names']]
+    noise = {k: torch.from_numpy(fx[p + 'noise/' + k]) for k in ('gumbel', 'span_lower', 'span_upper', 'random_ids', 'option')}
+    sidx = torch.from_numpy(b['shuffled_idx_img'])
+    pm = MerlotModel(cfg, True, False, b['image'], b['input_ids'], mask_input=True, shuffled_idx_img=sidx, params=st, noise=noise)
+    assert np.array_equal(pm.lang_mask_info['masked_idx'].numpy(), fx[p + 'masked_idx'])
+    assert np.array_equal(pm.lang_mask_info['masked_ids'].numpy(), fx[p + 'masked_ids'])
+    loss = pm.mask_loss()[0] + pm.contrastive_loss()[0] + pm.temporal_loss(sidx, torch.from_numpy(b['video_src_ids']))[0]
+    assert abs(float(loss) - float(fx[p + 'loss'])) < 3e-2
+    assert rel_l2(torch.from_numpy(head(pm.encoder_hidden_states['lang'].detach().float().numpy().reshape(-1, 768))),
+                  torch.from_numpy(fx[p + 'encoder_lang'])) < 2e-2
+    loss.backward()
+    gt = st.export_tf_grads()
+    for k in fx.files:
+        if k.startswith(p + 'grad/'):
+            n = k[len(p) + 5:]
+            assert rel_l2(torch.from_numpy(head(gt[n].numpy())), torch.from_numpy(fx[k])) < 0.12, n
+
+
+def test_block_mask_is_refused_loudly(emu):
+    from merlot_amd import MerlotModel, ParamStore
+    cfg = tiny_config(disable_pairwise_lang_attn=True)
+    b = synth_batch(cfg)
+    with pytest.raises(NotImplementedError, match='disable_pairwise_lang_attn'):
+        MerlotModel(cfg, True, False, b['image'], b['input_ids'], mask_input=True, params=ParamStore(cfg, 'cpu', seed=0))

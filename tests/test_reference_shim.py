@@ -210,6 +210,37 @@ def test_optimizer_restatement_matches_reference_adam():
     assert oo.learning_rate_scale(500, 1000, 100) == np.float32(1000.0 / 901.0) * np.float32(0.5)
 
 
+VARIANTS = {'unshared': dict(share_params=False, num_lang_transformer_hidden_layers=1),
+            'langonly_groups': dict(langonly_num_chunks_in_group=2),
+            'block_mask': dict(disable_pairwise_lang_attn=True)}
+
+
+@pytest.mark.parametrize('name', sorted(VARIANTS))
+def test_restatement_matches_reference_config_variants(name):
+    """`share_params: False` (separate, shallower `langonly_encoder`, model/modeling.py:357-362),
+    `langonly_num_chunks_in_group` (:345-351), `disable_pairwise_lang_attn` (:160-168) on the training graph."""
+    fx = _load('ref_shim_variants.npz')
+    p = name + '/'
+    cfg = tiny_config(use_bfloat16=False, **VARIANTS[name])
+    b = synth_batch(cfg, E=2, num_chunks=4, Lc=32, seed=3)
+    w = _weights(cfg, 8)
+    assert sorted(w) == [str(n) for n in fx[p + 'variable_names']]
+    assert ('langonly_encoder/layer00/query_layer/kernel' in w) == (name == 'unshared')
+    o = mo.MerlotOracle(cfg, w, b['image'], b['input_ids'], mask_input=True, shuffled_idx_img=b['shuffled_idx_img'],
+                        noise=_noise(fx, p + 'noise/'))
+    loss, info = o.total_loss(b['shuffled_idx_img'], b['video_src_ids'])
+    assert np.array_equal(o.lang_mask_info['masked_idx'].numpy(), fx[p + 'masked_idx'])
+    assert np.array_equal(o.lang_mask_info['masked_ids'].numpy(), fx[p + 'masked_ids'])
+    assert abs(float(loss) - float(fx[p + 'loss'])) < 2e-5
+    assert _relmax(head(o.encoder_hidden_states['lang'].detach().numpy().reshape(-1, 768)), fx[p + 'encoder_lang']) < REL
+    assert _relmax(head(o.lang_trg_h.detach().numpy()), fx[p + 'lang_trg_h']) < REL
+    loss.backward()
+    for k in fx.files:
+        if k.startswith(p + 'grad/'):
+            n = k[len(p) + 5:]
+            assert _relmax(head(w[n].grad.numpy()), fx[k]) < 2e-4, n
+
+
 @pytest.mark.timeout(900)
 @pytest.mark.skipif(not os.path.isdir('/root/reference/model'), reason="reference sources only exist in the build "
                     "container; the committed fixtures carry its outputs everywhere else")
@@ -219,7 +250,7 @@ def test_live_reference_run_reproduces_committed_fixtures(tmp_path):
                        capture_output=True, text=True, timeout=850)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     for name in ('ref_shim_config1.npz', 'ref_shim_optimizer.npz', 'ref_shim_dp2.npz', 'ref_shim_sort_story.npz',
-                 'ref_shim_inference2d.npz', 'ref_shim_resnet_stem.npz'):
+                 'ref_shim_inference2d.npz', 'ref_shim_resnet_stem.npz', 'ref_shim_variants.npz'):
         new, old = np.load(os.path.join(str(tmp_path), name)), _load(name)
         assert sorted(new.files) == sorted(old.files)
         for k in old.files:
