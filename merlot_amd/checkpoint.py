@@ -87,8 +87,10 @@ def _get_varint(buf, pos):
             raise CheckpointError('varint too long')
 
 
-def _proto_fields(buf):
-    """-> [(field number, wire type, value)] of one protobuf message (varint / fixed64 / bytes / fixed32 only)."""
+def _proto_fields(buf, copy=True):
+    """-> [(field number, wire type, value)] of one protobuf message (varint / fixed64 / bytes / fixed32 only).
+    copy=False on a memoryview returns length-delimited payloads as zero-copy slices (the TFRecord path: MB-sized
+    Examples nested four levels deep)."""
     pos, out = 0, []
     while pos < len(buf):
         tag, pos = _get_varint(buf, pos)
@@ -100,7 +102,7 @@ def _proto_fields(buf):
             pos += 8
         elif wt == 2:
             n, pos = _get_varint(buf, pos)
-            v = bytes(buf[pos:pos + n])
+            v = bytes(buf[pos:pos + n]) if copy else buf[pos:pos + n]
             if len(v) != n:
                 raise CheckpointError('truncated proto field')
             pos += n

@@ -174,19 +174,37 @@ __global__ __launch_bounds__(IMG_THREADS) void image_sums_kernel(const uint8_t* 
     }
 }
 
+// pass 1b (contrast frames only): per-frame channel means from the block partials -- one workgroup per frame, a fixed
+// reduction tree (strided per-thread sums, wave butterflies, waves in order): the same bits on every run
+__global__ __launch_bounds__(IMG_THREADS) void image_means_kernel(const Job* __restrict__ jobs, const float* __restrict__ partial,
+                                                                  int nblk, float count, float* __restrict__ means) {
+    if (jobs[blockIdx.x].aug_kind != 2) return;
+    __shared__ float red[IMG_THREADS / 64][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float s = 0.f;
+        for (int b = threadIdx.x; b < nblk; b += IMG_THREADS) s += partial[((int64_t)blockIdx.x * nblk + b) * 3 + c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][c] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float s = 0.f;
+        for (int w = 0; w < IMG_THREADS / 64; ++w) s += red[w][threadIdx.x];
+        means[blockIdx.x * 3 + threadIdx.x] = s / count;
+    }
+}
+
 // pass 2: resize + crop + pad (+ augment) -> bf16 NHWC
 __global__ __launch_bounds__(IMG_THREADS) void image_frames_kernel(const uint8_t* __restrict__ src, const Job* __restrict__ jobs,
-                                                                   int out_h, int out_w, const float* __restrict__ partial,
+                                                                   int out_h, int out_w, const float* __restrict__ means,
                                                                    bf16* __restrict__ dst) {
     const Job j = jobs[blockIdx.y];
-    __shared__ float mean[3];
-    if (j.aug_kind == 2) {                               // fixed-order sum of the block partials: deterministic
-        if (threadIdx.x < 3) {
-            float s = 0.f;
-            for (int b = 0; b < (int)gridDim.x; ++b) s += partial[((int64_t)blockIdx.y * gridDim.x + b) * 3 + threadIdx.x];
-            mean[threadIdx.x] = s / (float)(out_h * out_w);
-        }
-        __syncthreads();
+    float mean[3] = {0.f, 0.f, 0.f};
+    if (j.aug_kind == 2) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) mean[c] = means[blockIdx.y * 3 + c];
     }
     const int pix = blockIdx.x * IMG_THREADS + threadIdx.x;
     if (pix >= out_h * out_w) return;
@@ -209,7 +227,7 @@ __global__ __launch_bounds__(IMG_THREADS) void image_frames_kernel(const uint8_t
 extern "C" int64_t merlot_image_frames_workspace_bytes(int n_img, int out_h, int out_w) {
     if (n_img <= 0 || out_h <= 0 || out_w <= 0) return 0;
     const int64_t blocks = ((int64_t)out_h * out_w + IMG_THREADS - 1) / IMG_THREADS;
-    return (int64_t)n_img * blocks * 3 * sizeof(float);
+    return (int64_t)n_img * (blocks + 1) * 3 * sizeof(float);        // block partials + the per-frame means
 }
 
 extern "C" int merlot_image_frames(const uint8_t* src, int64_t src_bytes, const merlot_image_job_t* jobs_host,
@@ -234,10 +252,15 @@ extern "C" int merlot_image_frames(const uint8_t* src, int64_t src_bytes, const 
         any_contrast |= j.aug_kind == 2;
     }
     const dim3 grid((out_h * out_w + IMG_THREADS - 1) / IMG_THREADS, n_img);
-    if (any_contrast)
+    float* partial = (float*)workspace;
+    float* means = partial + (int64_t)n_img * grid.x * 3;
+    if (any_contrast) {
         hipLaunchKernelGGL(image_sums_kernel, grid, dim3(IMG_THREADS), 0, (hipStream_t)stream, src, (const Job*)jobs_dev,
-                           out_h, out_w, (float*)workspace);
+                           out_h, out_w, partial);
+        hipLaunchKernelGGL(image_means_kernel, dim3(n_img), dim3(IMG_THREADS), 0, (hipStream_t)stream, (const Job*)jobs_dev,
+                           partial, (int)grid.x, (float)(out_h * out_w), means);
+    }
     hipLaunchKernelGGL(image_frames_kernel, grid, dim3(IMG_THREADS), 0, (hipStream_t)stream, src, (const Job*)jobs_dev, out_h,
-                       out_w, (const float*)workspace, (bf16*)dst);
+                       out_w, means, (bf16*)dst);
     return merlot_launch_status("merlot_image_frames");
 }

@@ -14,6 +14,7 @@ and tests can inject the exact draws the reference graph consumed.  There is no 
 """
 import glob
 import io
+import os
 import queue
 import struct
 import threading
@@ -86,34 +87,36 @@ class TFRecordWriter(object):
 
 # ---- tf.train.Example (tensorflow/core/example/{example,feature}.proto) ------------------------------------------------
 def parse_example(buf):
-    """serialized tf.train.Example -> {key: ('bytes'|'float'|'int64', list)}."""
+    """serialized tf.train.Example -> {key: ('bytes'|'float'|'int64', list)}; bytes values are zero-copy memoryviews of
+    `buf` (a frame's JPEG is copied once, by the decoder)."""
     out = {}
-    for f, _, features in _ck._proto_fields(buf):
+    pf = lambda b: _ck._proto_fields(b, copy=False)
+    for f, _, features in pf(memoryview(buf)):
         if f != 1:
             continue
-        for f2, _, entry in _ck._proto_fields(features):            # map<string, Feature> entries
+        for f2, _, entry in pf(features):                           # map<string, Feature> entries
             if f2 != 1:
                 continue
             key, feat = None, b''
-            for f3, _, v in _ck._proto_fields(entry):
+            for f3, _, v in pf(entry):
                 if f3 == 1:
-                    key = v.decode('utf-8')
+                    key = bytes(v).decode('utf-8')
                 elif f3 == 2:
                     feat = v
             kind, vals = None, []
-            for f4, _, lst in _ck._proto_fields(feat):
+            for f4, _, lst in pf(feat):
                 if f4 == 1:
-                    kind, vals = 'bytes', [v for f5, _, v in _ck._proto_fields(lst) if f5 == 1]
+                    kind, vals = 'bytes', [v for f5, _, v in pf(lst) if f5 == 1]
                 elif f4 == 2:
                     kind = 'float'
-                    for f5, wt, v in _ck._proto_fields(lst):
+                    for f5, wt, v in pf(lst):
                         if f5 == 1 and wt == 2:                     # packed
                             vals.extend(struct.unpack(f'<{len(v) // 4}f', v))
                         elif f5 == 1:
                             vals.append(struct.unpack('<f', struct.pack('<I', v))[0])
                 elif f4 == 3:
                     kind = 'int64'
-                    for f5, wt, v in _ck._proto_fields(lst):
+                    for f5, wt, v in pf(lst):
                         if f5 == 1 and wt == 2:
                             pos = 0
                             while pos < len(v):
@@ -168,7 +171,8 @@ def decode_record(record, num_chunks):
             else:
                 if len(got[1]) != 1:
                     raise RecordError(f'c{i:02d}/{k}: expected one value, found {len(got[1])}')
-                cur[k] = got[1][0]
+                v = got[1][0]
+                cur[k] = bytes(v) if (kind == 'bytes' and k != 'image/encoded') else v
         chunks.append(cur)
     return chunks
 
@@ -257,21 +261,69 @@ def parse_example_host(record, config, noise):
     return feats
 
 
-def frames_to_device(frames_u8, jobs, out_hw, device, stream_tensors=None):
-    """all frames of a batch -> bf16 [n, H, W, 3] on `device` with one upload and one `merlot_image_frames` call."""
-    jobs = jobs.copy()
-    off = 0
-    for i, f in enumerate(frames_u8):
-        jobs['src_offset'][i] = off
+def frame_offsets(frames_u8):
+    """16-B aligned byte offsets of the frames in one concatenated source buffer -> (offsets, total bytes)."""
+    offs, off = [], 0
+    for f in frames_u8:
+        offs.append(off)
         off += (f.nbytes + 15) // 16 * 16
-    flat = torch.empty(off, dtype=torch.uint8).pin_memory() if torch.cuda.is_available() else torch.empty(off, dtype=torch.uint8)
+    return np.asarray(offs, np.int64), off
+
+
+class Staging(object):
+    """rotating page-locked host buffers for the decoded frames of a batch: worker threads copy into them in parallel,
+    the consumer uploads with one non-blocking copy and leaves an event behind that guards the buffer's next use."""
+
+    def __init__(self, n):
+        self.bufs, self.events, self.i = [None] * n, [None] * n, 0
+
+    def take(self, nbytes):
+        i = self.i
+        self.i = (i + 1) % len(self.bufs)
+        if self.events[i] is not None:
+            self.events[i].synchronize()
+            self.events[i] = None
+        if self.bufs[i] is None or self.bufs[i].numel() < nbytes:
+            t = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8)
+            self.bufs[i] = t.pin_memory() if torch.cuda.is_available() else t
+        return i, self.bufs[i]
+
+
+def pack_frames(frames_u8, staging=None, pool=None):
+    """-> (flat uint8 host tensor holding every frame, offsets, staging slot or None)"""
+    offs, total = frame_offsets(frames_u8)
+    slot, flat = staging.take(total) if staging is not None else (None, torch.empty(total, dtype=torch.uint8))
     fnp = flat.numpy()
-    for i, f in enumerate(frames_u8):
-        o = int(jobs['src_offset'][i])
-        fnp[o:o + f.nbytes] = f.reshape(-1)
+
+    def put(i):
+        f = frames_u8[i]
+        fnp[offs[i]:offs[i] + f.nbytes] = f.reshape(-1)
+
+    if pool is not None:
+        list(pool.map(put, range(len(frames_u8))))
+    else:
+        for i in range(len(frames_u8)):
+            put(i)
+    return flat[:total], offs, slot
+
+
+def frames_to_device(frames_u8, jobs, out_hw, device, packed=None, staging=None):
+    """all frames of a batch -> bf16 [n, H, W, 3] on `device` with one upload and one `merlot_image_frames` call.
+    jobs[i] describes output frame i and reads source frame i (or, with `packed=(flat, offsets, slot)`, the frame at
+    jobs['src_offset'][i], already set by the caller)."""
+    jobs = jobs.copy()
+    if packed is None:
+        flat, offs, slot = pack_frames(frames_u8)
+        jobs['src_offset'] = offs
+    else:
+        flat, offs, slot = packed
     src = flat.to(device, non_blocking=True)
+    if slot is not None and staging is not None and src.is_cuda:
+        ev = torch.cuda.Event()
+        ev.record()
+        staging.events[slot] = ev
     jobs_host = torch.from_numpy(jobs.view(np.uint8).reshape(-1).copy())
-    return ops.image_frames(src, jobs_host, jobs_host.to(device, non_blocking=True), len(frames_u8), out_hw[0], out_hw[1])
+    return ops.image_frames(src, jobs_host, jobs_host.to(device, non_blocking=True), len(jobs), out_hw[0], out_hw[1])
 
 
 # ---- batch-level processing (model/dataloader.py:202-268) -------------------------------------------------------------
@@ -297,15 +349,18 @@ def shuffle_chunks_index(video_src_ids, u):
     return np.argsort(trg, 1, kind='stable')
 
 
-def collate(examples, config, noise, device, is_training=True):
-    """`dataset.batch(batch_size)` + `_process_example` -> the features dict of model_fn, on `device`."""
+def collate(examples, config, noise, device, is_training=True, packed=None, staging=None):
+    """`dataset.batch(batch_size)` + `_process_example` -> the features dict of model_fn, on `device`.
+    packed = pack_frames(all frames in example order) when the loader thread already staged them."""
     bs = len(examples)
     nc = config['num_chunks']
     H, W = config['image_size']
     host = {k: np.stack([e[k] for e in examples], 0) for k in
             ('youtube_id', 'chunk_num', 'mean_time', 'input_ids', 'is_eoc', 'video_src_ids')}
-    frames = [f for e in examples for f in e['frames_u8']]
     jobs = np.concatenate([e['jobs'] for e in examples])
+    if packed is None:
+        packed = pack_frames([f for e in examples for f in e['frames_u8']])
+    jobs['src_offset'] = packed[1]
     order = np.arange(bs * nc).reshape(bs, nc)
     if is_training and config.get('shuffle_chunks', False):
         idx = shuffle_chunks_index(host['video_src_ids'], noise['u_chunks'])
@@ -313,7 +368,7 @@ def collate(examples, config, noise, device, is_training=True):
             host[k] = np.take_along_axis(host[k], idx.reshape(idx.shape + (1,) * (host[k].ndim - 2)), 1)
         order = np.take_along_axis(order, idx, 1)
     flat_order = order.reshape(-1)
-    images = frames_to_device([frames[i] for i in flat_order], jobs[flat_order], (H, W), device)
+    images = frames_to_device(None, jobs[flat_order], (H, W), device, packed=packed, staging=staging)   # output i <- source flat_order[i]
     feats = {k: torch.from_numpy(np.ascontiguousarray(v)).to(device) for k, v in host.items()}
     feats['images'] = images.reshape(bs, nc, H, W, 3)
     if not is_training:                                     # `_process_example` is only mapped when training (:262-263)
@@ -332,6 +387,68 @@ def collate(examples, config, noise, device, is_training=True):
     return feats
 
 
+def _worker_parse(task):
+    """loader worker PROCESS (never touches the GPU): one record -> host features; the decoded frames travel back in a
+    shared-memory block (name returned), not through the result pipe."""
+    from multiprocessing import resource_tracker, shared_memory
+    record, config, noise = task
+    feats = parse_example_host(record, config, noise)
+    frames = feats.pop('frames_u8')
+    offs, total = frame_offsets(frames)
+    shm = shared_memory.SharedMemory(create=True, size=max(total, 1))
+    try:
+        resource_tracker.unregister(shm._name, 'shared_memory')      # the parent unlinks it after copying out
+    except Exception:
+        pass
+    buf = np.ndarray((total,), np.uint8, buffer=shm.buf)
+    for f, o in zip(frames, offs):
+        buf[o:o + f.nbytes] = f.reshape(-1)
+    feats['shm'] = (shm.name, [f.shape for f in frames], offs)
+    del buf
+    shm.close()
+    return feats
+
+
+def _spawn_pool(n):
+    """loader processes by `spawn` (fork after HIP initialisation is not safe).  spawn re-imports the parent's
+    `__main__` in every child; a training script without an `if __name__ == '__main__':` guard would then run itself
+    again in each worker.  The workers only need this module, so `__main__` is hidden while they start."""
+    import multiprocessing as mp
+    import sys
+    if mp.current_process().name != 'MainProcess':
+        raise RuntimeError('InputPipeline(num_workers > 0) was started from inside a loader worker process')
+    main = sys.modules.get('__main__')
+    saved_file = main.__dict__.pop('__file__', None) if main is not None else None
+    saved_spec = getattr(main, '__spec__', None) if main is not None else None
+    try:
+        if main is not None:
+            main.__spec__ = None
+        pool = mp.get_context('spawn').Pool(n)
+        pool.map(_worker_ready, range(n), chunksize=1)        # all workers are up (and imported) before __main__ returns
+    finally:
+        if main is not None:
+            main.__spec__ = saved_spec
+            if saved_file is not None:
+                main.__file__ = saved_file
+    return pool
+
+
+def _worker_ready(i):
+    import time
+    time.sleep(0.2)                                           # keeps one fast worker from answering every probe
+    return os.getpid()
+
+
+def _attach_frames(feats):
+    """parent side: zero-copy views of a worker's frames + the handle to release afterwards"""
+    from multiprocessing import shared_memory
+    name, shapes, offs = feats.pop('shm')
+    shm = shared_memory.SharedMemory(name=name)
+    base = np.ndarray((shm.size,), np.uint8, buffer=shm.buf)
+    feats['frames_u8'] = [base[o:o + int(np.prod(sh))].reshape(sh) for sh, o in zip(shapes, offs)]
+    return shm
+
+
 class InputPipeline(object):
     """`input_fn_builder(config, is_training)(params)` as a Python iterator of feature dicts.
 
@@ -340,7 +457,10 @@ class InputPipeline(object):
     of `shuffle_buffer_size` (256), are parsed by `num_threads` host threads (JPEG decode releases the GIL) and batched
     with drop_remainder; training repeats forever.  One background thread keeps `prefetch` batches ahead."""
 
-    def __init__(self, config, is_training, batch_size, device, rank=0, world_size=1, seed=0, prefetch=2):
+    def __init__(self, config, is_training, batch_size, device, rank=0, world_size=1, seed=0, prefetch=2, num_workers=0):
+        """num_workers = 0: records are parsed by `num_threads` threads of this process (libjpeg releases the GIL, the
+        protobuf / bookkeeping Python does not: ~125 examples/s per process).  num_workers > 0: that many loader
+        PROCESSES parse and decode, handing frames back through shared memory; this process only stages and uploads."""
         self.merged = dict(config.data)
         self.merged.update(config.model)
         self.is_training, self.batch_size, self.device = is_training, batch_size, device
@@ -354,9 +474,14 @@ class InputPipeline(object):
             files = files[rank::world_size]
         self.files = files
         self.rng = np.random.default_rng([seed, rank])
-        self.num_threads = max(1, min(int(config.data.get('num_threads', 64)), 16))
+        # host threads per process: `data.num_threads` (64 in merlot.yaml) bounded by this rank's share of the cores
+        local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world_size))
+        self.num_threads = max(1, min(int(config.data.get('num_threads', 64)), (os.cpu_count() or 1) // max(1, local_world)))
         self.buffer_size = int(config.data.get('shuffle_buffer_size', 256))
         self.prefetch = prefetch
+        self.staging = Staging(prefetch + 2)
+        self.num_workers = int(num_workers)
+        self._procs = None
 
     def _records(self):
         while True:
@@ -385,14 +510,33 @@ class InputPipeline(object):
     def _host_batches(self):
         from concurrent.futures import ThreadPoolExecutor
         nc = self.merged['num_chunks']
+        if self.num_workers > 0 and self._procs is None:
+            self._procs = _spawn_pool(self.num_workers)
         with ThreadPoolExecutor(self.num_threads) as pool:
             batch = []
             for rec in self._shuffled():
                 batch.append((rec, draw_example_noise(self.rng, nc, self.merged)))
-                if len(batch) == self.batch_size:
+                if len(batch) < self.batch_size:
+                    continue
+                shms = []
+                if self._procs is not None:
+                    examples = self._procs.map(_worker_parse, [(r, self.merged, n) for r, n in batch], chunksize=1)
+                    shms = [_attach_frames(e) for e in examples]
+                else:
                     examples = list(pool.map(lambda a: parse_example_host(a[0], self.merged, a[1]), batch))
-                    yield examples, draw_batch_noise(self.rng, self.batch_size, nc, self.merged)
-                    batch = []
+                packed = pack_frames([f for e in examples for f in e['frames_u8']], self.staging, pool)
+                for e in examples:
+                    e['frames_u8'] = None                    # the staged copy is the only one kept
+                for shm in shms:
+                    shm.close()
+                    shm.unlink()
+                yield examples, draw_batch_noise(self.rng, self.batch_size, nc, self.merged), packed
+                batch = []
+
+    def close(self):
+        if self._procs is not None:
+            self._procs.terminate()
+            self._procs = None
 
     def __iter__(self):
         q = queue.Queue(self.prefetch)
@@ -413,5 +557,5 @@ class InputPipeline(object):
                 return
             if isinstance(item, BaseException):
                 raise item
-            examples, noise = item
-            yield collate(examples, self.merged, noise, self.device, self.is_training)
+            examples, noise, packed = item
+            yield collate(examples, self.merged, noise, self.device, self.is_training, packed=packed, staging=self.staging)

@@ -270,6 +270,12 @@ def test_pipeline_end_to_end_with_emulated_kernels(tmp_path, emu):
     assert all(torch.equal(again[k], b0[k]) for k in b0)                  # same seed, same batch
     other = next(iter(ip.InputPipeline(cfg, True, batch_size=2, device='cpu', seed=4)))
     assert not torch.equal(other['images'], b0['images'])
+    # loader worker processes (frames come back through shared memory) produce the very same batches
+    wp = ip.InputPipeline(cfg, True, batch_size=2, device='cpu', seed=3, num_workers=2)
+    wit = iter(wp)
+    w0, w1 = next(wit), next(wit)
+    wp.close()
+    assert all(torch.equal(w0[k], b0[k]) for k in b0) and all(torch.equal(w1[k], b1[k]) for k in b1)
     # per-rank file sharding (model/dataloader.py:160-166) and the eval path (no repeat, no _process_example)
     p0 = ip.InputPipeline(cfg, True, 2, 'cpu', rank=0, world_size=2)
     p1 = ip.InputPipeline(cfg, True, 2, 'cpu', rank=1, world_size=2)
