@@ -106,12 +106,15 @@ int merlot_ln_bwd(const void* dy, int dy_f32, const void* x, int x_f32, const fl
  * valid: uint8 [B,S] or NULL (=all valid).  mask(b,i,j) = valid[b,i] & valid[b,j]; a masked score is
  * exactly -1e10 (NOT -inf): a padded query row attends uniformly over all S keys (:109-112).
  * ---------------------------------------------------------------------------------------------- */
+/* seg (optional, needs valid): int32 [S] segment id per position, shared by all batch rows -- the
+ * `disable_pairwise_lang_attn` block mask of model/modeling.py:160-168: a pair of valid tokens is additionally masked
+ * (score exactly -1e10) unless seg[q] == seg[k] or one of the two is 0. */
 int merlot_attention_fwd(const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse, const uint8_t* valid,
-                         int B, int S, int heads, float scale, merlot_stream_t stream);
+                         const int32_t* seg, int B, int S, int heads, float scale, merlot_stream_t stream);
 /* dqkv (bf16, same layout as qkv) from dout.  delta: f32 workspace [B*heads*S]. */
 int merlot_attention_bwd(const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout, int64_t lddo,
-                         const float* lse, const uint8_t* valid, void* dqkv, int64_t lddqkv, float* delta, int B,
-                         int S, int heads, float scale, merlot_stream_t stream);
+                         const float* lse, const uint8_t* valid, const int32_t* seg, void* dqkv, int64_t lddqkv,
+                         float* delta, int B, int S, int heads, float scale, merlot_stream_t stream);
 /* Side outputs the reference takes from its stacked [B,layers,S,S] head-mean probabilities, without
  * materialising SxS:  colsum_lo[b,key] += weight * sum_h sum_{q <  qsplit} P[b,h,q,key]
  *                     colsum_hi[b,key] += weight * sum_h sum_{q >= qsplit} P[b,h,q,key]
@@ -119,9 +122,9 @@ int merlot_attention_bwd(const void* qkv, int64_t ld, const void* out, int64_t l
  *   masking, model/modeling.py:428-431 (use qsplit = S, colsum_hi = NULL);
  * valid_q_only=1: only (valid query, valid key) pairs count -- the four viz/lang block sums of the
  *   attention log, model/modeling.py:186-203 (qsplit = P, the host sums key ranges). */
-int merlot_attention_colsum(const void* qkv, int64_t ld, const float* lse, const uint8_t* valid, float* colsum_lo,
-                            float* colsum_hi, int qsplit, int valid_q_only, float weight, int B, int S, int heads,
-                            float scale, merlot_stream_t stream);
+int merlot_attention_colsum(const void* qkv, int64_t ld, const float* lse, const uint8_t* valid, const int32_t* seg,
+                            float* colsum_lo, float* colsum_hi, int qsplit, int valid_q_only, float weight, int B, int S,
+                            int heads, float scale, merlot_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Element-wise / gather / reduction helpers.

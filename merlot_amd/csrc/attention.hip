@@ -35,6 +35,8 @@ struct AttnArgs {
     float* lse;          // [B, heads, S] natural log
     const float* delta;  // [B, heads, S]
     const uint8_t* valid;
+    const int32_t* seg;  // optional [S] segment ids (model/modeling.py:160-168): a valid pair (q, k) is ALSO masked unless
+                         // seg[q] == seg[k] or one of them is 0; same for every batch row; needs `valid`
     bf16* dqkv;
     int64_t lddqkv;
     int B, S, heads;
@@ -127,11 +129,12 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 
 template <bool MASKED>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
-    __shared__ __attribute__((aligned(1024))) char smem[2 * 8192 + 512];
+    __shared__ __attribute__((aligned(1024))) char smem[2 * 8192 + 768];
     char* ldsK = smem;
     char* ldsV = smem + 8192;
     float* biasA = reinterpret_cast<float*>(smem + 16384);
     float* biasB = biasA + 64;
+    int* segK = reinterpret_cast<int*>(biasB + 64);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5;
@@ -146,6 +149,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
 
     const int q = min(qw0 + (lane & 31), S - 1);
     const bool qv = MASKED ? (vrow[q] != 0) : true;
+    const bool segd = MASKED && p.seg != nullptr;
+    const int sq = (segd && qv) ? p.seg[q] : 0;     // 0: every key allowed (viz / padded query rows stay uniform)
     bf16x8 qf[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
@@ -171,6 +176,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
             const bool kval = in && (MASKED ? vrow[min(kidx, S - 1)] != 0 : true);
             biasA[tid] = in ? (kval ? 0.f : MASKED_T) : -INFINITY;
             biasB[tid] = in ? 0.f : -INFINITY;
+            if (segd) segK[tid] = p.seg[min(kidx, S - 1)];
         }
         __syncthreads();
         if (kt + 1 < nkt) {
@@ -200,9 +206,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + kb * 32 + 8 * g);
+                    int sk[4] = {0, 0, 0, 0};
+                    if (segd) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) sk[e] = segK[4 * hi + kb * 32 + 8 * g + e];
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float t = fmaf(st[kb][4 * g + e], sc, b4[e]);
+                        float t = fmaf(st[kb][4 * g + e], sc, b4[e]);
+                        if (segd) t = (sq == 0 || sk[e] == 0 || sk[e] == sq) ? t : MASKED_T;   // exactly -1e10, as a padded key
                         st[kb][4 * g + e] = t;
                         mloc = fmaxf(mloc, t);
                     }
@@ -304,11 +316,12 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs p, float
 // ------------------------------------------------------------------------------------------------
 template <bool MASKED>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
-    __shared__ __attribute__((aligned(1024))) char smem[2 * 8192 + 512];
+    __shared__ __attribute__((aligned(1024))) char smem[2 * 8192 + 768];
     char* ldsK = smem;
     char* ldsV = smem + 8192;
     float* biasA = reinterpret_cast<float*>(smem + 16384);
     float* biasB = biasA + 64;
+    int* segK = reinterpret_cast<int*>(biasB + 64);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5;
@@ -323,6 +336,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
 
     const int q = min(qw0 + (lane & 31), S - 1);
     const bool qv = MASKED ? (vrow[q] != 0) : true;
+    const bool segd = MASKED && p.seg != nullptr;
+    const int sq = (segd && qv) ? p.seg[q] : 0;
     bf16x8 qf[4], dof[4];
     const bf16* dorow = p.dout + ((int64_t)b * S + q) * p.lddo + h * 64;
 #pragma unroll
@@ -353,6 +368,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
             const bool kval = in && (MASKED ? vrow[min(kidx, S - 1)] != 0 : true);
             biasA[tid] = in ? (kval ? 0.f : MASKED_T) : -INFINITY;
             biasB[tid] = in ? 0.f : -INFINITY;
+            if (segd) segK[tid] = p.seg[min(kidx, S - 1)];
         }
         __syncthreads();
         if (kt + 1 < nkt) {
@@ -382,6 +398,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
                     const f32x4 t4 = *reinterpret_cast<const f32x4*>(bias + kb * 32 + 8 * g);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) b4[e] += t4[e];
+                }
+                if (segd) {                               // a pair the segment mask forbids has p == 0 exactly
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int sk = segK[4 * hi + kb * 32 + 8 * g + e];
+                        if (!(sq == 0 || sk == 0 || sk == sq)) b4[e] = -INFINITY;
+                    }
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -424,13 +447,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
 // ------------------------------------------------------------------------------------------------
 template <bool MASKED>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) {
-    __shared__ __attribute__((aligned(1024))) char smem[2 * 8192 + 4 * 256];
+    __shared__ __attribute__((aligned(1024))) char smem[2 * 8192 + 5 * 256];
     char* ldsQ = smem;
     char* ldsO = smem + 8192;
     float* lds_lse = reinterpret_cast<float*>(smem + 16384);
     float* lds_dl = lds_lse + 64;
     float* lds_sc = lds_lse + 128;
     float* lds_mq = lds_lse + 192;
+    int* lds_sq = reinterpret_cast<int*>(lds_lse + 256);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5;
@@ -449,6 +473,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs p)
     const int key = min(kw0 + (lane & 31), S - 1);
     const bool key_in = kw0 + (lane & 31) < S;
     const float kmul = (MASKED && !(vrow[key] != 0)) ? 1.f : 0.f;     // 1 for a masked key
+    const bool segd = MASKED && p.seg != nullptr;
+    const int sk = segd ? p.seg[key] : 0;
     bf16x8 kf[4], vf[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -476,6 +502,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs p)
                 const bool qvl = in && (vrow[min(qi, S - 1)] != 0);
                 lds_sc[tid] = qvl ? sc_const : 0.f;
                 lds_mq[tid] = qvl ? MASKED_T : 0.f;
+                if (segd) lds_sq[tid] = qvl ? p.seg[min(qi, S - 1)] : 0;     // padded rows stay uniform over all keys
             }
         }
         __syncthreads();
@@ -510,6 +537,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs p)
                     const f32x4 m4 = *reinterpret_cast<const f32x4*>(lds_mq + ro);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) b4[e] = fmaf(m4[e], kmul, b4[e]);
+                    if (segd) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int sq = lds_sq[ro + e];
+                            if (!(sq == 0 || sk == 0 || sk == sq)) b4[e] = -INFINITY;
+                        }
+                    }
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -577,6 +611,8 @@ __global__ __launch_bounds__(64) void attn_colsum_kernel(const AttnArgs p) {
     //   m_k = 1 for a valid key, 0 for a padded one (its probability under a valid query is exp2(-1e10...) = 0)
     const float sc = p.scale * LOG2E;
     const float m_k = kv ? 1.f : 0.f;
+    const bool segd = p.seg != nullptr && vrow != nullptr;
+    const int sk = segd ? p.seg[key] : 0;
     float acc_lo = 0.f, acc_hi = 0.f;
     const int nqb = (S + 31) / 32;
     for (int qb = 0; qb < nqb; ++qb) {
@@ -594,6 +630,7 @@ __global__ __launch_bounds__(64) void attn_colsum_kernel(const AttnArgs p) {
         const bool counts = q_in && (p.valid_q_only ? qvl : true);
         const float my_a = qvl ? sc : 0.f;
         const float my_c = counts ? -lse_b[qrow] * LOG2E : -INFINITY;
+        const int my_sq = (segd && qvl) ? p.seg[qrow] : 0;
         const bool all_lo = (qb + 1) * 32 <= p.qsplit, all_hi = qb * 32 >= p.qsplit;
         float part = 0.f, part_lo = 0.f;
 #pragma unroll
@@ -602,7 +639,11 @@ __global__ __launch_bounds__(64) void attn_colsum_kernel(const AttnArgs p) {
             const float a_r = __shfl(my_a, src, 64);
             const float c_r = __shfl(my_c, src, 64);
             const float e = fast_exp2(fmaf(st[r], a_r, c_r));
-            const float pv = e * (a_r != 0.f ? m_k : 1.f);
+            float pv = e * (a_r != 0.f ? m_k : 1.f);
+            if (segd) {
+                const int sq_r = __shfl(my_sq, src, 64);
+                if (!(sq_r == 0 || sk == 0 || sk == sq_r)) pv = 0.f;
+            }
             part += pv;
             if (!all_lo && !all_hi && qb * 32 + src < p.qsplit) part_lo += pv;
         }
@@ -634,12 +675,14 @@ int check_attn(const void* qkv, int64_t ld, int B, int S, int heads) {
 }  // namespace
 
 extern "C" int merlot_attention_fwd(const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse,
-                                    const uint8_t* valid, int B, int S, int heads, float scale, merlot_stream_t stream) {
+                                    const uint8_t* valid, const int32_t* seg, int B, int S, int heads, float scale,
+                                    merlot_stream_t stream) {
     int rc = check_attn(qkv, ld, B, S, heads);
     if (rc) return rc;
     MERLOT_CHECK(out && ldo >= heads * 64 && ldo % 4 == 0, MERLOT_ESHAPE, "attention_fwd: bad out/ldo");
+    MERLOT_CHECK(!seg || valid, MERLOT_ESHAPE, "attention: a segment mask needs the validity mask too");
     AttnArgs a{};
-    a.qkv = (const bf16*)qkv; a.ld = ld; a.out = (bf16*)out; a.ldo = ldo; a.lse = lse; a.valid = valid;
+    a.qkv = (const bf16*)qkv; a.ld = ld; a.out = (bf16*)out; a.ldo = ldo; a.lse = lse; a.valid = valid; a.seg = seg;
     a.B = B; a.S = S; a.heads = heads; a.scale = scale;
     if (valid)
         hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, (hipStream_t)stream, a);
@@ -649,8 +692,9 @@ extern "C" int merlot_attention_fwd(const void* qkv, int64_t ld, void* out, int6
 }
 
 extern "C" int merlot_attention_bwd(const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout,
-                                    int64_t lddo, const float* lse, const uint8_t* valid, void* dqkv, int64_t lddqkv,
-                                    float* delta, int B, int S, int heads, float scale, merlot_stream_t stream) {
+                                    int64_t lddo, const float* lse, const uint8_t* valid, const int32_t* seg, void* dqkv,
+                                    int64_t lddqkv, float* delta, int B, int S, int heads, float scale,
+                                    merlot_stream_t stream) {
     int rc = check_attn(qkv, ld, B, S, heads);
     if (rc) return rc;
     MERLOT_CHECK(out && dout && lse && dqkv && delta, MERLOT_ESHAPE, "attention_bwd: null operand");
@@ -658,7 +702,8 @@ extern "C" int merlot_attention_bwd(const void* qkv, int64_t ld, const void* out
                  "attention_bwd: bad leading dims");
     AttnArgs a{};
     a.qkv = (const bf16*)qkv; a.ld = ld; a.out = (bf16*)out; a.ldo = ldo; a.dout = (const bf16*)dout; a.lddo = lddo;
-    a.lse = (float*)lse; a.delta = delta; a.valid = valid; a.dqkv = (bf16*)dqkv; a.lddqkv = lddqkv;
+    MERLOT_CHECK(!seg || valid, MERLOT_ESHAPE, "attention: a segment mask needs the validity mask too");
+    a.lse = (float*)lse; a.delta = delta; a.valid = valid; a.seg = seg; a.dqkv = (bf16*)dqkv; a.lddqkv = lddqkv;
     a.B = B; a.S = S; a.heads = heads; a.scale = scale;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv((int64_t)B * S, 4)), dim3(256), 0, s, a, delta);
@@ -673,13 +718,15 @@ extern "C" int merlot_attention_bwd(const void* qkv, int64_t ld, const void* out
 }
 
 extern "C" int merlot_attention_colsum(const void* qkv, int64_t ld, const float* lse, const uint8_t* valid,
-                                       float* colsum_lo, float* colsum_hi, int qsplit, int valid_q_only, float weight,
+                                       const int32_t* seg, float* colsum_lo, float* colsum_hi, int qsplit,
+                                       int valid_q_only, float weight,
                                        int B, int S, int heads, float scale, merlot_stream_t stream) {
     int rc = check_attn(qkv, ld, B, S, heads);
     if (rc) return rc;
     MERLOT_CHECK(lse && (colsum_lo || colsum_hi), MERLOT_ESHAPE, "attention_colsum: null operand");
     AttnArgs a{};
-    a.qkv = (const bf16*)qkv; a.ld = ld; a.lse = (float*)lse; a.valid = valid;
+    MERLOT_CHECK(!seg || valid, MERLOT_ESHAPE, "attention: a segment mask needs the validity mask too");
+    a.qkv = (const bf16*)qkv; a.ld = ld; a.lse = (float*)lse; a.valid = valid; a.seg = seg;
     a.colsum_lo = colsum_lo; a.colsum_hi = colsum_hi; a.qsplit = qsplit; a.valid_q_only = valid_q_only;
     a.weight = weight; a.B = B; a.S = S; a.heads = heads; a.scale = scale;
     hipLaunchKernelGGL(attn_colsum_kernel, dim3(cdiv(S, 32), heads, B), dim3(64), 0, (hipStream_t)stream, a);

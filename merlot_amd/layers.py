@@ -49,7 +49,8 @@ class TransformerStackFn(torch.autograd.Function):
     """hidden [B*S, H] bf16 -> LN_final(stack(hidden)) [B*S, H] bf16.
 
     opts: dict(heads, dropout_p, seed, colsum (f32 [B,S] accumulated over layers, all query rows, weight 1/heads),
-               log_lo / log_hi (f32 [B,S], valid pairs only, queries < / >= log_split), num_layers)
+               log_lo / log_hi (f32 [B,S], valid pairs only, queries < / >= log_split), num_layers,
+               seg (int32 [S]: the disable_pairwise_lang_attn block mask, model/modeling.py:160-168))
     """
 
     @staticmethod
@@ -60,6 +61,7 @@ class TransformerStackFn(torch.autograd.Function):
         nl = opts.get('num_layers', len(stack.layers))
         colsum = opts.get('colsum')
         log_lo, log_hi = opts.get('log_lo'), opts.get('log_hi')
+        seg = opts.get('seg')                              # int32 [S] block mask of disable_pairwise_lang_attn, or None
         need_bwd = ctx.needs_input_grad[0]
         saved = []
         h = h.contiguous()
@@ -67,12 +69,13 @@ class TransformerStackFn(torch.autograd.Function):
             w = stack.layers[l]
             x1, _, mean1, rstd1 = ops.ln_fwd(h, w.ln1.gamma, w.ln1.beta)
             qkv = ops.gemm_nt(x1, w.qkv.wb, bias=w.qkv.b)
-            ctx_, lse = ops.attention_fwd(qkv, B, S, heads, valid)
+            ctx_, lse = ops.attention_fwd(qkv, B, S, heads, valid, seg=seg)
             if colsum is not None:
-                ops.attention_colsum(qkv, lse, B, S, heads, colsum, valid=valid, valid_q_only=False, weight=1.0 / heads)
+                ops.attention_colsum(qkv, lse, B, S, heads, colsum, valid=valid, valid_q_only=False, weight=1.0 / heads,
+                                     seg=seg)
             if log_lo is not None:
                 ops.attention_colsum(qkv, lse, B, S, heads, log_lo, log_hi, qsplit=opts['log_split'], valid=valid,
-                                     valid_q_only=True, weight=1.0 / heads)
+                                     valid_q_only=True, weight=1.0 / heads, seg=seg)
             h_mid = ops.gemm_nt(ctx_, w.proj.wb, bias=w.proj.b, epilogue=EPI_RESIDUAL, aux_in=h, dropout_p=p,
                                 dropout_seed=_site_seed(seed, l, 0))
             x2, _, mean2, rstd2 = ops.ln_fwd(h_mid, w.ln2.gamma, w.ln2.beta)
@@ -85,6 +88,7 @@ class TransformerStackFn(torch.autograd.Function):
             h = h_out
         y, _, meanf, rstdf = ops.ln_fwd(h, stack.ln_final.gamma, stack.ln_final.beta)
         ctx.stack, ctx.B, ctx.S, ctx.valid, ctx.heads, ctx.p, ctx.seed, ctx.nl = stack, B, S, valid, heads, p, seed, nl
+        ctx.seg = seg
         ctx.saved = saved
         ctx.final = (h, meanf, rstdf)
         return y
@@ -115,7 +119,7 @@ class TransformerStackFn(torch.autograd.Function):
             # ---- attention branch: h_mid = h + drop(proj(attn(qkv(LN1(h)))))             db1 = d(proj output)
             ops.gemm_tn(db1, ctx_, w.proj.gw)
             dctx = ops.gemm_nt(db1, w.proj.wbT)
-            dqkv = ops.attention_bwd(qkv, ctx_, dctx, lse, B, S, heads, valid)
+            dqkv = ops.attention_bwd(qkv, ctx_, dctx, lse, B, S, heads, valid, seg=ctx.seg)
             ops.colsum_bf16(dqkv, w.qkv.gb)
             ops.gemm_tn(dqkv, x1, w.qkv.gw)
             dx1 = ops.gemm_nt(dqkv, w.qkv.wbT)

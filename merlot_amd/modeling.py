@@ -106,8 +106,6 @@ class MerlotModel(object):
             raise ValueError("the ResNet-hybrid stem reduces by 16 (utils/vision_transformer.py:208)")
         if cfg.get('num_imgs', 1) != 1 or cfg.get('num_texts', 1) != 1:
             raise NotImplementedError("num_imgs / num_texts > 1 (VCR path) is out of scope")
-        if cfg.get('disable_pairwise_lang_attn', False):
-            raise NotImplementedError("disable_pairwise_lang_attn block mask is not supported by the fused attention yet")
         if img_mask is not None:
             raise NotImplementedError("img_mask is only used by the VCR path (out of scope)")
 
@@ -218,6 +216,9 @@ class MerlotModel(object):
         Sj = self.P + self.L
         opts = dict(heads=heads, dropout_p=self.dropout_prob if is_training else 0.0, seed=self.seed * 4 + 2,
                     num_layers=cfg['num_hidden_layers'])
+        if cfg.get('disable_pairwise_lang_attn', False):                          # :160-168, as a segment vector
+            opts['seg'] = torch.cat([torch.zeros(self.P, dtype=torch.int32),
+                                     1 + torch.arange(self.L, dtype=torch.int32) // self.lang_chunk_length]).to(dev)
         if log_attention_probs:
             log_lo = torch.zeros((self.B, Sj), device=dev, dtype=F32)
             log_hi = torch.zeros((self.B, Sj), device=dev, dtype=F32)

@@ -162,27 +162,28 @@ def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, dres=None, dx_dtype=None,
     return dx, (dx_drop if dx_drop is not None else dx)
 
 
-def attention_fwd(qkv, B, S, heads, valid=None, need_lse=True):
-    _chk(qkv, BF16, 'qkv')
+def attention_fwd(qkv, B, S, heads, valid=None, need_lse=True, seg=None):
+    _chk(qkv, BF16, 'qkv'); _chk(seg, torch.int32, 'seg')
     out = torch.empty((B * S, heads * 64), device=qkv.device, dtype=BF16)
     lse = torch.empty((B, heads, S), device=qkv.device, dtype=F32) if need_lse else None
-    call('merlot_attention_fwd', _p(qkv), qkv.stride(0), _p(out), out.stride(0), _p(lse), _p(valid), B, S, heads,
-         0.125, _stream())
+    call('merlot_attention_fwd', _p(qkv), qkv.stride(0), _p(out), out.stride(0), _p(lse), _p(valid), _p(seg), B, S,
+         heads, 0.125, _stream())
     return out, lse
 
 
-def attention_bwd(qkv, out, dout, lse, B, S, heads, valid=None):
-    _chk(dout, BF16, 'dout')
+def attention_bwd(qkv, out, dout, lse, B, S, heads, valid=None, seg=None):
+    _chk(dout, BF16, 'dout'); _chk(seg, torch.int32, 'seg')
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, heads, S), device=qkv.device, dtype=F32)
     call('merlot_attention_bwd', _p(qkv), qkv.stride(0), _p(out), out.stride(0), _p(dout), dout.stride(0), _p(lse),
-         _p(valid), _p(dqkv), dqkv.stride(0), _p(delta), B, S, heads, 0.125, _stream())
+         _p(valid), _p(seg), _p(dqkv), dqkv.stride(0), _p(delta), B, S, heads, 0.125, _stream())
     return dqkv
 
 
 def attention_colsum(qkv, lse, B, S, heads, colsum_lo, colsum_hi=None, *, qsplit=None, valid=None, valid_q_only=False,
-                     weight=1.0):
-    call('merlot_attention_colsum', _p(qkv), qkv.stride(0), _p(lse), _p(valid), _p(colsum_lo), _p(colsum_hi),
+                     weight=1.0, seg=None):
+    _chk(seg, torch.int32, 'seg')
+    call('merlot_attention_colsum', _p(qkv), qkv.stride(0), _p(lse), _p(valid), _p(seg), _p(colsum_lo), _p(colsum_hi),
          S if qsplit is None else qsplit, 1 if valid_q_only else 0, float(weight), B, S, heads, 0.125, _stream())
 
 

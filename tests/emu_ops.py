@@ -111,7 +111,7 @@ def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, dres=None, dx_dtype=None,
     return out, out
 
 
-def _attn_probs(qkv, B, S, heads, valid):
+def _attn_probs(qkv, B, S, heads, valid, seg=None):
     H = heads * 64
     q = qkv[:, :H].float().reshape(B, S, heads, 64).permute(0, 2, 1, 3)
     k = qkv[:, H:2 * H].float().reshape(B, S, heads, 64).permute(0, 2, 1, 3)
@@ -119,24 +119,29 @@ def _attn_probs(qkv, B, S, heads, valid):
     s = (q @ k.transpose(-1, -2)) * 0.125
     if valid is not None:
         vb = valid.bool()
-        m = (vb[:, None, :, None] & vb[:, None, None, :]).float()
+        m = vb[:, None, :, None] & vb[:, None, None, :]
+        if seg is not None:                               # model/modeling.py:160-168
+            sg = seg.long()
+            can = (sg[:, None] == sg[None]) | (sg == 0)[None] | (sg == 0)[:, None]
+            m = m & can[None, None]
+        m = m.float()
         s = s * m - 1e10 * (1 - m)
         s = torch.where(vb[:, None, :, None], s, torch.zeros_like(s))     # padded query rows: score 0 (uniform)
     return q, k, v, s
 
 
-def attention_fwd(qkv, B, S, heads, valid=None, need_lse=True):
-    q, k, v, s = _attn_probs(qkv, B, S, heads, valid)
+def attention_fwd(qkv, B, S, heads, valid=None, need_lse=True, seg=None):
+    q, k, v, s = _attn_probs(qkv, B, S, heads, valid, seg)
     lse = torch.logsumexp(s, -1)
     p = torch.exp(s - lse[..., None])
     o = (p.to(BF16).float() @ v).permute(0, 2, 1, 3).reshape(B * S, heads * 64)
     return o.to(BF16), (lse if need_lse else None)
 
 
-def attention_bwd(qkv, out, dout, lse, B, S, heads, valid=None):
+def attention_bwd(qkv, out, dout, lse, B, S, heads, valid=None, seg=None):
     qkv_f = qkv.float().detach().requires_grad_(True)
     with torch.enable_grad():
-        q, k, v, s = _attn_probs(qkv_f, B, S, heads, valid)
+        q, k, v, s = _attn_probs(qkv_f, B, S, heads, valid, seg)
         p = torch.softmax(s, -1)
         o = (p @ v).permute(0, 2, 1, 3).reshape(B * S, heads * 64)
     (g,) = torch.autograd.grad(o, qkv_f, dout.float())
@@ -144,8 +149,8 @@ def attention_bwd(qkv, out, dout, lse, B, S, heads, valid=None):
 
 
 def attention_colsum(qkv, lse, B, S, heads, colsum_lo, colsum_hi=None, *, qsplit=None, valid=None, valid_q_only=False,
-                     weight=1.0):
-    q, k, v, s = _attn_probs(qkv, B, S, heads, valid)
+                     weight=1.0, seg=None):
+    q, k, v, s = _attn_probs(qkv, B, S, heads, valid, seg)
     p = torch.exp(s - lse[..., None])                      # [B, h, q, key]
     if valid_q_only and valid is not None:
         vb = valid.bool()

@@ -33,7 +33,7 @@ def test_argument_validation_happens_before_any_launch():
     assert rc == -1 and b'null operand' in d.merlot_last_error()
     rc = d.merlot_ln_fwd(1, 0, 1, 1, 1, None, None, None, 4, 700, 1e-5, None)
     assert rc == -1 and b'H=700' in d.merlot_last_error()
-    rc = d.merlot_attention_fwd(None, 2304, None, 768, None, None, 1, 4, 12, 0.125, None)
+    rc = d.merlot_attention_fwd(None, 2304, None, 768, None, None, None, 1, 4, 12, 0.125, None)
     assert rc == -1
 
 

@@ -258,7 +258,7 @@ def test_clip_by_global_norm_matches_reference_rule():
             assert torch.allclose(st.g(n), ref[n] * factor, rtol=1e-5, atol=1e-8), n
 
 
-@pytest.mark.parametrize('name', ['unshared', 'langonly_groups'])
+@pytest.mark.parametrize('name', ['unshared', 'langonly_groups', 'block_mask'])
 def test_config_variants_match_reference_program(emu, name):
     """the host wiring of `share_params: False` (own `langonly_encoder` weights, its own depth) and
     `langonly_num_chunks_in_group` against what the reference program computed (tests/golden/ref_shim_variants.npz)."""
@@ -288,11 +288,3 @@ def test_config_variants_match_reference_program(emu, name):
         if k.startswith(p + 'grad/'):
             n = k[len(p) + 5:]
             assert rel_l2(torch.from_numpy(head(gt[n].numpy())), torch.from_numpy(fx[k])) < 0.12, n
-
-
-def test_block_mask_is_refused_loudly(emu):
-    from merlot_amd import MerlotModel, ParamStore
-    cfg = tiny_config(disable_pairwise_lang_attn=True)
-    b = synth_batch(cfg)
-    with pytest.raises(NotImplementedError, match='disable_pairwise_lang_attn'):
-        MerlotModel(cfg, True, False, b['image'], b['input_ids'], mask_input=True, params=ParamStore(cfg, 'cpu', seed=0))

@@ -262,6 +262,34 @@ def test_attention_colsum(ops, B, S, pad, vq):
     assert rel_l2(lo, lo_r) < 5e-3 and rel_l2(hi, hi_r) < 5e-3
 
 
+@pytest.mark.parametrize("B,S,P,Lc", [(2, 328, 200, 32), (2, 148, 20, 32), (1, 130, 2, 16)])
+def test_attention_segment_block_mask(ops, B, S, P, Lc):
+    """`disable_pairwise_lang_attn` (model/modeling.py:160-168): tokens of different caption chunks do not see each other,
+    everything sees the P vision tokens; chunk boundaries are NOT aligned to the kernels' 32/64-wide tiles."""
+    heads = 12
+    qkv, valid, g = _attn_inputs(B, S, heads, 900 + S, True)
+    seg = torch.cat([torch.zeros(P, dtype=torch.int32), 1 + torch.arange(S - P, dtype=torch.int32) // Lc])
+    vc, sc = valid.cuda(), seg.cuda()
+    o_ref, lse_ref = E.attention_fwd(qkv, B, S, heads, valid, seg=seg)
+    o_plain, _ = E.attention_fwd(qkv, B, S, heads, valid)
+    assert rel_l2(o_plain, o_ref) > 0.1                                   # the mask matters on these inputs
+    o, lse = ops.attention_fwd(qkv.cuda(), B, S, heads, vc, seg=sc)
+    assert rel_l2(o, o_ref) < 8e-3
+    assert float((lse.cpu() - lse_ref).abs().max()) < 2e-2
+    do = rnd((B * S, heads * 64), g) * valid.reshape(B * S, 1).to(BF16)
+    dq_ref = E.attention_bwd(qkv, o_ref, do, lse_ref, B, S, heads, valid, seg=seg).float()
+    dq = ops.attention_bwd(qkv.cuda(), o, do.cuda(), lse, B, S, heads, vc, seg=sc).float().cpu()
+    Hh = heads * 64
+    for name, sl in [('dq', slice(0, Hh)), ('dk', slice(Hh, 2 * Hh)), ('dv', slice(2 * Hh, 3 * Hh))]:
+        assert rel_l2(dq[:, sl], dq_ref[:, sl]) < 1.5e-2, name
+    for vq in (False, True):
+        lo_r, hi_r = torch.zeros(B, S), torch.zeros(B, S)
+        E.attention_colsum(qkv, lse_ref, B, S, heads, lo_r, hi_r, qsplit=P, valid=valid, valid_q_only=vq, weight=1 / heads, seg=seg)
+        lo, hi = torch.zeros(B, S).cuda(), torch.zeros(B, S).cuda()
+        ops.attention_colsum(qkv.cuda(), lse, B, S, heads, lo, hi, qsplit=P, valid=vc, valid_q_only=vq, weight=1 / heads, seg=sc)
+        assert rel_l2(lo, lo_r) < 5e-3 and rel_l2(hi, hi_r) < 5e-3, vq
+
+
 # ---- element-wise / gather / CE ------------------------------------------------------------------------------
 def test_casts_and_colsum(ops):
     g = torch.Generator().manual_seed(2)

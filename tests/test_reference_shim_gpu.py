@@ -154,7 +154,7 @@ def test_hip_adamw_matches_reference_optimizer():
             assert np.allclose(p.cpu().numpy(), fx[f's{i}/new_param/{n}'].reshape(-1), rtol=1e-5, atol=1e-8), n
 
 
-@pytest.mark.parametrize('name', ['unshared', 'langonly_groups'])
+@pytest.mark.parametrize('name', ['unshared', 'langonly_groups', 'block_mask'])
 def test_hip_config_variants_match_reference_program(name):
     """`share_params: False` (separate, shallower `langonly_encoder`) and `langonly_num_chunks_in_group` on the HIP path."""
     from merlot_amd import MerlotModel, ParamStore
@@ -185,4 +185,3 @@ def test_hip_config_variants_match_reference_program(name):
                 assert rel_l2(torch.from_numpy(head(gt[n].float().cpu().numpy())), torch.from_numpy(fx[k])) < 0.12, n
     else:
         pytest.fail('masked_idx differs from the reference run (attention_summs tie?)')
-    assert rel_l2(pm.lang_trg_h, torch.from_numpy(fx[p + 'lang_trg_h'])[:pm.lang_trg_h.shape[0]].cuda()) < 2e-2 or True
