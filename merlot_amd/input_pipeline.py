@@ -482,6 +482,7 @@ class InputPipeline(object):
         self.staging = Staging(prefetch + 2)
         self.num_workers = int(num_workers)
         self._procs = None
+        self._stream = None
 
     def _records(self):
         while True:
@@ -558,4 +559,17 @@ class InputPipeline(object):
             if isinstance(item, BaseException):
                 raise item
             examples, noise, packed = item
-            yield collate(examples, self.merged, noise, self.device, self.is_training, packed=packed, staging=self.staging)
+            if self._stream is None and torch.device(self.device).type == 'cuda':
+                self._stream = torch.cuda.Stream(self.device)
+            if self._stream is None:
+                yield collate(examples, self.merged, noise, self.device, self.is_training, packed=packed, staging=self.staging)
+                continue
+            # upload + frame kernels on a side stream: they overlap the training step still running on the main stream
+            main = torch.cuda.current_stream(self.device)
+            with torch.cuda.stream(self._stream):
+                feats = collate(examples, self.merged, noise, self.device, self.is_training, packed=packed, staging=self.staging)
+            main.wait_stream(self._stream)
+            for v in feats.values():
+                if isinstance(v, torch.Tensor) and v.is_cuda:
+                    v.record_stream(main)
+            yield feats
