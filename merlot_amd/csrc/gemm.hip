@@ -1083,30 +1083,13 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_dyn_kernel(const GemmNTAr
         if (stream_end) return;
         char* la = dsm + (ld_step % S) * C::STAGE_BYTES + wave * C::A_PIECES * 1024;
         char* lb = dsm + (ld_step % S) * C::STAGE_BYTES + C::A_BYTES + wave * C::B_PIECES * 1024;
-        int64_t k0 = ld_kt * BK;
-        // experiments (timing only, results are garbage): dbg 4 = no global->LDS traffic; 1024 = every piece re-reads the
-        // same 16 rows x 64 B (L1-resident source); 2048 = a piece covers 8 rows x 128 B, i.e. whole cache lines, each
-        // fetched once (the request pattern of a BK 64 stage) with unchanged instruction and LDS-write counts.
-        int64_t xa = 0, xb = 0;
-        if (p.dbg & (1024 | 2048)) {
-            if (p.dbg & 1024) {
-                k0 = 0;
-                xa = (int64_t)prow * p.lda + pch * 8 - (a_src[0] - p.A);      // -> p.A + rows 0..15
-                xb = (int64_t)prow * p.ldb + pch * 8 - (b_src[0] - p.B);
-            } else {
-                k0 = (ld_kt >> 1) * 64;
-                xa = (int64_t)((lane >> 3) - prow) * p.lda + ((lane & 7) * 8 - a_chunk[0]);
-                xb = (int64_t)((lane >> 3) - prow) * p.ldb + ((lane & 7) * 8 - b_chunk[0]);
-            }
-        }
-        if (!(p.dbg & 4)) {
+        const int k0 = ld_kt * BK;
 #pragma unroll
-            for (int i = 0; i < C::A_PIECES; ++i)
-                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(((p.dbg & 1024) ? a_src[0] : a_src[i]) + k0 + xa), LDS_PTR(la + i * 1024), 16, 0, 0);
+        for (int i = 0; i < C::A_PIECES; ++i)
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(a_src[i] + k0), LDS_PTR(la + i * 1024), 16, 0, 0);
 #pragma unroll
-            for (int i = 0; i < C::B_PIECES; ++i)
-                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(((p.dbg & 1024) ? b_src[0] : b_src[i]) + k0 + xb), LDS_PTR(lb + i * 1024), 16, 0, 0);
-        }
+        for (int i = 0; i < C::B_PIECES; ++i)
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(b_src[i] + k0), LDS_PTR(lb + i * 1024), 16, 0, 0);
         ++ld_step;
         if (++ld_kt == nk) {                             // the stream moves on to the tile claimed at kt == 0
             ld_kt = 0;
@@ -1510,6 +1493,10 @@ int gemm_nt_dispatch(GemmNTArgs& a, int epilogue, int out_f32, hipStream_t s) {
             return e ? atoi(e) : 21;
         }();
         cfg = (tiles * 100 >= rounds * 256 * 85) ? persist_id : 11;
+        // short K loop behind a three-tile-wide output (attention out-projection and its dgrad, 768 x 768): the epilogue
+        // is a large share of the launch and two co-resident 128x256 workgroups overlap it with each other's main loop
+        // (profiles/r01_i_gemm_ceiling.txt section 3: 4-20 % faster at every token count of the step)
+        if (a.N <= 768 && a.K <= 768) cfg = 11;
         // narrow outputs (the ResNet-stem convolutions with 32..128 filters): a 256-wide tile would compute 2-8x the
         // columns that exist; these launches are HBM-bound and reach ~5 TB/s on 256x64 / 256x128 tiles
         // (scripts/exp_stem_gemm.py)
