@@ -66,6 +66,40 @@ def read_tfrecords(path, verify=True):
             yield body[:n]
 
 
+def scan_tfrecords(path, verify=True):
+    """(path, offset of the record data, length) of every record of a file: headers only, the data is not read"""
+    size = os.path.getsize(path)
+    with open(path, 'rb') as f:
+        pos = 0
+        while pos < size:
+            head = f.read(12)
+            if len(head) != 12:
+                raise RecordError(f'{path}: truncated record header')
+            n, = struct.unpack('<Q', head[:8])
+            if verify and _ck.mask_crc(_ck.crc32c(head[:8])) != struct.unpack('<I', head[8:])[0]:
+                raise RecordError(f'{path}: corrupt record length')
+            if pos + 12 + n + 4 > size:
+                raise RecordError(f'{path}: truncated record')
+            yield path, pos + 12, n
+            pos += 12 + n + 4
+            f.seek(pos)
+
+
+def read_record(ref, verify=True):
+    """the data of one `scan_tfrecords` entry (checksum verified here, by whoever consumes the record)"""
+    if isinstance(ref, (bytes, bytearray, memoryview)):
+        return ref
+    path, off, n = ref
+    with open(path, 'rb') as f:
+        f.seek(off)
+        body = f.read(n + 4)
+    if len(body) != n + 4:
+        raise RecordError(f'{path}: truncated record')
+    if verify and _ck.mask_crc(_ck.crc32c(body[:n])) != struct.unpack('<I', body[n:])[0]:
+        raise RecordError(f'{path}: corrupt record data')
+    return memoryview(body)[:n]
+
+
 class TFRecordWriter(object):
     def __init__(self, path):
         self.f = open(path, 'wb')
@@ -194,20 +228,21 @@ def decode_jpeg(data):
 
 
 def draw_example_noise(rng, num_chunks, config):
-    """the random draws `_dataset_parser` consumes for one example, in graph order per frame (utils/model_utils.py:877,
-    906-907, 834 `apply_with_random_selector`, :832-836 augment index + bernoulli, :778/:788 factors) + do_clean."""
+    """the random draws `_dataset_parser` consumes for one example (utils/model_utils.py:877, 906-907 scale and crop
+    offsets, :834 `apply_with_random_selector`, :832-836 augment index + bernoulli, :778/:788 factors) + do_clean; a few
+    array draws per example rather than ten scalar ones per frame."""
     lo, hi = config.get('random_scale_min', 0.95), config.get('random_scale_max', 1.05)
-    strength = 0.4
-    d = 0.8 * strength
-    frames = []
-    for _ in range(num_chunks):
-        n = {'scale': np.float32(rng.uniform(lo, hi)), 'u_y': np.float32(rng.uniform()), 'u_x': np.float32(rng.uniform()),
-             'method': int(rng.integers(0, 4)), 'do_augment': False, 'kind': 0, 'factor': np.ones(3, np.float32)}
-        if config.get('augment_prob', 0.0) > 0.0:
-            n['kind'] = int(rng.integers(0, 2))                       # categorical over ['brightness', 'contrast']
-            n['do_augment'] = bool(rng.uniform() < config['augment_prob'])
-            n['factor'] = rng.uniform(1.0 - d, 1.0 + d, 3).astype(np.float32)
-        frames.append(n)
+    d = 0.8 * 0.4                                        # max_{brightness,contrast}_delta at strength 0.4
+    nc = num_chunks
+    scale = rng.uniform(lo, hi, nc).astype(np.float32)
+    u = rng.uniform(size=(nc, 2)).astype(np.float32)
+    method = rng.integers(0, 4, nc)
+    augment = config.get('augment_prob', 0.0) > 0.0
+    kind = rng.integers(0, 2, nc) if augment else np.zeros(nc, np.int64)        # categorical over the two transforms
+    do_aug = (rng.uniform(size=nc) < config['augment_prob']) if augment else np.zeros(nc, bool)
+    factor = rng.uniform(1.0 - d, 1.0 + d, (nc, 3)).astype(np.float32) if augment else np.ones((nc, 3), np.float32)
+    frames = [{'scale': scale[i], 'u_y': u[i, 0], 'u_x': u[i, 1], 'method': int(method[i]), 'do_augment': bool(do_aug[i]),
+               'kind': int(kind[i]), 'factor': factor[i]} for i in range(nc)]
     return {'frames': frames, 'do_clean': bool(rng.uniform() < config.get('clean_asr_prob', 0.5))}
 
 
@@ -230,7 +265,7 @@ def parse_example_host(record, config, noise):
     -> dict(youtube_id, chunk_num, mean_time, input_ids, is_eoc, video_src_ids, frames_u8 [list of HWC uint8], jobs)."""
     num_chunks = config['num_chunks']
     desired = tuple(config['image_size'])
-    chunks = decode_record(record, num_chunks)
+    chunks = decode_record(read_record(record), num_chunks)
     feats = {
         'youtube_id': np.stack([encode_string(c['youtube_id'], 64) for c in chunks], 0),
         'chunk_num': np.array([c['chunk_num'] for c in chunks], np.int32),
@@ -490,8 +525,7 @@ class InputPipeline(object):
             if self.is_training:
                 self.rng.shuffle(files)
             for f in files:
-                for r in read_tfrecords(f):
-                    yield r
+                yield from scan_tfrecords(f)              # (path, offset, length): whoever parses the record reads it
             if not self.is_training:
                 return
 
