@@ -35,6 +35,22 @@ def test_argument_validation_happens_before_any_launch():
     assert rc == -1 and b'H=700' in d.merlot_last_error()
     rc = d.merlot_attention_fwd(None, 2304, None, 768, None, None, None, 1, 4, 12, 0.125, None)
     assert rc == -1
+    # the frame-kernel job table is checked on its HOST copy before anything is launched
+    import numpy as np
+    from merlot_amd.input_pipeline import JOB_DTYPE
+    jobs = np.zeros(2, JOB_DTYPE)
+    jobs[0] = (0, 8, 8, 16, 16, 0, 0, 0, 0, (1, 1, 1), 0)
+    jobs[1] = (192, 8, 8, 16, 16, 5, 0, 0, 0, (1, 1, 1), 0)            # resize method 5 does not exist
+    fake = 4096                                                      # never dereferenced: validation fails first
+    rc = d.merlot_image_frames(fake, 384, jobs.ctypes.data, fake, 2, fake, 16, 16, fake, 1 << 20, None)
+    assert rc == -1 and b'frame 1: resize method 5' in d.merlot_last_error()
+    jobs[1]['method'] = 0
+    rc = d.merlot_image_frames(fake, 300, jobs.ctypes.data, fake, 2, fake, 16, 16, fake, 1 << 20, None)
+    assert rc == -1 and b'frame 1 lies outside the source buffer' in d.merlot_last_error()
+    rc = d.merlot_image_frames(fake, 384, jobs.ctypes.data, fake, 2, fake, 16, 16, fake, 16, None)
+    assert rc == -1 and b'workspace too small' in d.merlot_last_error()
+    rc = d.merlot_im2col_patches(fake, fake, 1, 64, 64, 8, -0.5, None)
+    assert rc == -1 and b'patch_size 16' in d.merlot_last_error()
 
 
 def test_product_has_no_cpu_fallback():
