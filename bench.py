@@ -221,11 +221,13 @@ def main():
         if timer is not None:
             summ = timer.summary()
             f, t, n = summ.get('gemm_nt', (0.0, 1.0, 0))
+            traffic = measured_traffic()                     # PMC bytes of the representative launch, or None
             res['roofline'] = {'bound': 'mfma',
                                'kernel': 'merlot_gemm_bf16_nt = gemm_nt_persist_dyn_kernel<EPI,OUT> + gemm_nt_ring_kernel<Cfg<2,4,2,2,32,3>,EPI,OUT> '
                                          '(bf16 MFMA 32x32x16, all epilogues; the dominant kernel family of the step)',
                                'achieved': f / t / 1e12, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': f / t / 1e12 / PEAK_BF16_TFLOPS, 'traffic': measured_traffic(), 'launches': n,
+                               'frac': f / t / 1e12 / PEAK_BF16_TFLOPS, 'traffic': (traffic or {}).get('bytes_per_launch'),
+                               'traffic_detail': traffic, 'launches': n,
                                'avg_launch_us': 1e6 * t / max(n, 1), 'gflop_per_launch': f / max(n, 1) / 1e9,
                                'share_of_step_time': t / timed_steps / (elapsed / args.steps),
                                'timed_steps': timed_steps}
