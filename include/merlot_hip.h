@@ -285,6 +285,13 @@ int merlot_image_frames(const uint8_t* src, int64_t src_bytes, const merlot_imag
  * (data/process.py:236-256).  Returns the unmasked checksum in the low 32 bits; force_sw != 0 selects the table path. */
 int64_t merlot_crc32c(uint64_t crc, const void* data, int64_t n, int force_sw);
 
+/* One pass over a serialized tf.train.Example (the records of data/process.py:236-256; `_decode_record`,
+ * model/dataloader.py:33-54).  rows[i] = {key offset, key length, kind (1 bytes, 2 float, 3 int64, 0 empty), a, b, count}:
+ * bytes: a / b = offset / length of the first value; float / int64: a = first index into fvals / ivals.  Returns the
+ * number of features, -1 for malformed input, -2 if an output array is too small. */
+int64_t merlot_example_index(const void* buf, int64_t n, int64_t* rows, int64_t max_rows, int64_t* ivals, int64_t max_ivals,
+                             float* fvals, int64_t max_fvals);
+
 #ifdef __cplusplus
 }
 #endif

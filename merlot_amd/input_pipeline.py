@@ -163,6 +163,45 @@ def parse_example(buf):
     return out
 
 
+_KIND = {1: 'bytes', 2: 'float', 3: 'int64', 0: None}
+
+
+def parse_example_native(buf):
+    """`parse_example` through the native one-pass indexer (merlot_example_index in libmerlot_hip.so): same result,
+    no per-field Python -- what `decode_record` uses."""
+    mv = memoryview(buf)
+    n = len(mv)
+    arr = np.frombuffer(mv, np.uint8)
+    cap_r, cap_i, cap_f = 256, 4096, 256
+    while True:
+        rows = np.empty((cap_r, 6), np.int64)
+        ivals = np.empty(cap_i, np.int64)
+        fvals = np.empty(cap_f, np.float32)
+        cnt = int(LIB.query('merlot_example_index', arr.ctypes.data if n else None, n, rows.ctypes.data, cap_r,
+                            ivals.ctypes.data, cap_i, fvals.ctypes.data, cap_f))
+        if cnt == -2:
+            cap_r, cap_i, cap_f = cap_r * 4, cap_i * 4, cap_f * 4
+            continue
+        if cnt < 0:
+            raise RecordError('malformed tf.train.Example')
+        break
+    out = {}
+    for ko, kl, kind, a, b, c in rows[:cnt].tolist():
+        key = bytes(mv[ko:ko + kl]).decode('utf-8')
+        if kind == 1:
+            if c > 1:                                       # several bytes values in one feature: rare, general parser
+                return parse_example(buf)
+            vals = [mv[a:a + b]] if c == 1 else []
+        elif kind == 2:
+            vals = fvals[a:a + c].tolist()
+        elif kind == 3:
+            vals = ivals[a:a + c].tolist()
+        else:
+            vals = []
+        out[key] = (_KIND[kind], vals)
+    return out
+
+
 def _ld(field, payload):
     out = bytearray([(field << 3) | 2])
     _ck._put_varint(out, len(payload))
@@ -192,7 +231,7 @@ def encode_example(features):
 def decode_record(record, num_chunks):
     """model/dataloader.py:33-54: -> list of per-chunk dicts (FixedLen features as scalars with the reference's
     defaults, VarLen as int lists)."""
-    ex = parse_example(record)
+    ex = parse_example_native(record)
     chunks = []
     for i in range(num_chunks):
         cur = {}
@@ -224,7 +263,9 @@ def decode_jpeg(data):
     """tf.image.decode_jpeg(x, channels=3) -> uint8 [h, w, 3] (host libjpeg through PIL)."""
     from PIL import Image
     img = Image.open(io.BytesIO(data))
-    return np.asarray(img.convert('RGB'), dtype=np.uint8)
+    if img.mode != 'RGB':                                  # grayscale / CMYK sources; RGB frames are not copied again
+        img = img.convert('RGB')
+    return np.asarray(img, dtype=np.uint8)
 
 
 def draw_example_noise(rng, num_chunks, config):

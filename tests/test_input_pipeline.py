@@ -150,9 +150,20 @@ def test_example_wire_format_against_protobuf_runtime():
     mine = ip.encode_example({k: (np.float32(v[0]) if kind == 'float' else v) for k, (kind, v) in feats.items()
                               if k != 'c01/tokenized_cleaned_asr'})
     assert ip.parse_example(mine) == {k: v for k, v in got.items() if k != 'c01/tokenized_cleaned_asr'}
+    # the native indexer agrees with the Python parser, value for value
+    for w in (wire, mine, ip.encode_example({'a': [b'x', b'yy'], 'b': [1.5, 2.5], 'c': []})):
+        nat, py = ip.parse_example_native(w), ip.parse_example(w)
+        assert set(nat) == set(py)
+        for k in py:
+            assert nat[k][0] == py[k][0] or not py[k][1], k
+            assert [bytes(v) if isinstance(v, memoryview) else v for v in nat[k][1]] == \
+                   [bytes(v) if isinstance(v, memoryview) else v for v in py[k][1]], k
+    for bad in (wire[:-3], b'\x0a\xff\xff\xff\xff\x0f', bytes([0x0a, 0x02, 0x0a, 0x05])):
+        with pytest.raises((ip.RecordError, Exception)):
+            ip.parse_example_native(bad)
     # unpacked repeated scalars (older writers) parse too
     unpacked = ip._ld(1, ip._ld(1, ip._ld(1, b'k') + ip._ld(2, ip._ld(3, bytes([0x08, 0x07, 0x08, 0x09])))))
-    assert ip.parse_example(unpacked) == {'k': ('int64', [7, 9])}
+    assert ip.parse_example(unpacked) == {'k': ('int64', [7, 9])} == ip.parse_example_native(unpacked)
 
 
 def test_tfrecord_framing(tmp_path):
