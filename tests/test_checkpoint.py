@@ -206,3 +206,27 @@ def test_trainer_config_hook_names(tmp_path):
     from merlot_amd import train
     src = inspect.getsource(train.Trainer.__init__)
     assert "config.model.get('init_checkpoint'" in src
+
+
+def test_table_round_trip_and_corruption_properties():
+    """property test of the SSTable layer: any sorted key/value set survives write -> read at any block size; any single
+    corrupted byte is either detected (CheckpointError) or leaves the content intact (it hit padding)."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=120, deadline=None)
+    @given(st.dictionaries(st.binary(min_size=1, max_size=24), st.binary(max_size=60), max_size=40),
+           st.integers(16, 400), st.integers(0, 10 ** 6), st.integers(0, 255))
+    def run(kv, block_size, where, xor):
+        items = [(b'', b'header')] + sorted(kv.items())
+        img = ck._write_table(items, block_size)
+        assert ck._read_table(img) == items
+        if xor:
+            bad = bytearray(img)
+            bad[where % len(bad)] ^= xor
+            try:
+                got = ck._read_table(bytes(bad))
+            except ck.CheckpointError:
+                return
+            assert got == items
+
+    run()

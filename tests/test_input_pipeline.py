@@ -301,3 +301,40 @@ def test_pipeline_end_to_end_with_emulated_kernels(tmp_path, emu):
     want = index_oracle.shuffled_idx(nz['num_shuffle'], nz['u_sel'], nz['u_perm'], 16) if hasattr(index_oracle, 'shuffled_idx') \
         else io_.shuffled_idx_img(nz['num_shuffle'], nz['u_sel'], nz['u_perm'], 4)
     assert np.array_equal(io_.shuffled_idx_img(nz['num_shuffle'], nz['u_sel'], nz['u_perm'], 4), np.asarray(want).reshape(-1))
+
+
+def test_example_parsers_agree_on_random_messages_and_survive_garbage():
+    """property test: for random feature maps the native indexer, the Python parser and the encoder agree; on truncated or
+    random bytes the native indexer either agrees with the Python parser or reports malformed input -- it never reads
+    outside the buffer (the records come from disk)."""
+    from hypothesis import given, settings, strategies as st
+    keys = st.text(alphabet='abc/0123456789_', min_size=1, max_size=12)
+    feature = st.one_of(st.lists(st.binary(max_size=40), min_size=1, max_size=1),
+                        st.lists(st.integers(-2 ** 63, 2 ** 63 - 1), max_size=30),
+                        st.lists(st.floats(width=32, allow_nan=False), min_size=1, max_size=10).map(lambda v: [np.float32(x) for x in v]))
+
+    def norm(d):
+        return {k: (kind, [bytes(v) if isinstance(v, memoryview) else v for v in vals]) for k, (kind, vals) in d.items()}
+
+    @settings(max_examples=150, deadline=None)
+    @given(st.dictionaries(keys, feature, max_size=8), st.integers(0, 64), st.binary(max_size=64))
+    def run(feats, cut, junk):
+        wire = ip.encode_example(feats)
+        nat, py = norm(ip.parse_example_native(wire)), norm(ip.parse_example(wire))
+        assert set(nat) == set(py) == set(feats)
+        for k, v in feats.items():
+            want = [float(x) for x in v] if v and isinstance(v[0], np.floating) else list(v)
+            assert nat[k][1] == py[k][1] == want, k
+        for bad in (wire[:max(0, len(wire) - 1 - cut)], junk, wire + junk):
+            try:
+                ref = norm(ip.parse_example(bad))
+            except Exception:
+                ref = None
+            try:
+                got = norm(ip.parse_example_native(bad))
+            except ip.RecordError:
+                got = None
+            if ref is not None and got is not None:
+                assert {k: v[1] for k, v in got.items()} == {k: v[1] for k, v in ref.items()}
+
+    run()
