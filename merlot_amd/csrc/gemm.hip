@@ -45,6 +45,7 @@ struct GemmNTArgs {
     uint64_t drop_seed;
     int accumulate;
     int ntm, ntn;
+    int cg;               // persistent kernel: tiles are enumerated in groups of `cg` tile columns (0: plain row-major)
     int dbg;              // experiments only: 1 = skip epilogue, 2 = skip main loop
 };
 
@@ -1024,6 +1025,25 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const GemmNTArgs p
 // resident there at all -- then simply takes fewer tiles instead of stretching the whole launch by a full tile round.
 // Counters live in a small pool of self-resetting slots (the last workgroup to leave zeroes its slot).
 // ------------------------------------------------------------------------------------------------
+// Tile enumeration of the dynamic persistent kernel.  Row-major order makes a 32-tile XCD band 2-3 tile rows x ALL tile
+// columns: with 12 columns the weight panel (12 x 393 KB at K = 768) exceeds the XCD's 4 MB L2 and is re-fetched through
+// the fabric in every round of tiles.  Grouped order walks the grid column group by column group (cg columns wide, all
+// rows inside a group, row-major within it): a band is ~32/cg rows x cg columns, successive bands of an XCD stay in the
+// same group, and its weight slice (cg x 393 KB) stays L2-resident; activations are read once per group instead of once.
+__device__ __forceinline__ void tile_coords(const GemmNTArgs& p, int tile, int& tm, int& tn) {
+    if (p.cg <= 0 || p.ntn <= p.cg) {
+        tm = tile / p.ntn;
+        tn = tile - tm * p.ntn;
+        return;
+    }
+    const int per_group = p.ntm * p.cg;
+    const int g = tile / per_group;
+    const int r = tile - g * per_group;
+    const int w = min(p.cg, p.ntn - g * p.cg);
+    tm = r / w;
+    tn = g * p.cg + (r - tm * w);
+}
+
 constexpr int PERSIST_SLOTS = 1024;
 // experiments (dbg & 512): per-workgroup timeline, [wg][tile-slot][0..2] = s_memtime at tile start / loop end / epilogue end
 constexpr int TRACE_TILES = 32;
@@ -1068,7 +1088,8 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_dyn_kernel(const GemmNTAr
     const bf16* a_src[C::A_PIECES];
     const bf16* b_src[C::B_PIECES];
     auto set_tile = [&](int tile) {
-        const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
+        int tm, tn;
+        tile_coords(p, tile, tm, tn);
 #pragma unroll
         for (int i = 0; i < C::A_PIECES; ++i)
             a_src[i] = p.A + (int64_t)min(tm * C::BM + a_rowoff[i], p.M - 1) * p.lda + a_chunk[i];
@@ -1168,7 +1189,8 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_dyn_kernel(const GemmNTAr
             g_persist_trace[(blockIdx.x * TRACE_TILES + trace_i) * 4 + 1] = __builtin_amdgcn_s_memtime();
         int claimed = ntiles;
         if (tid == 0 && claims_open) claimed = claim();  // for the tile after next; the return is awaited below
-        const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
+        int tm, tn;
+        tile_coords(p, tile, tm, tn);
         const int m_base = tm * C::BM + wm * C::FM * 32, n_base = tn * C::BN + wn * C::FN * 32;
         if (!(p.dbg & 1)) {
             const bool interior = fast_ok && (tm + 1) * C::BM <= p.M && (tn + 1) * C::BN <= p.N;
@@ -1438,6 +1460,12 @@ int launch_persist_dyn_one(GemmNTArgs& a, hipStream_t s) {
     }
     a.ntm = cdiv(a.M, RingP::BM);
     a.ntn = cdiv(a.N, RingP::BN);
+    static const int tile_cg = [] {
+        const char* e = getenv("MERLOT_NT_TILE_CG");       // tile-column group width of the enumeration, 0 = row-major
+        return e ? atoi(e) : 0;
+    }();
+    a.cg = tile_cg;
+    if (const char* e = getenv("MERLOT_NT_TILE_CG_DYN")) a.cg = atoi(e);   // re-read every call (experiments only)
     int grid = a.ntm * a.ntn;
     if (grid > 256) grid = 256;
     static std::atomic<unsigned int> seq{0};             // counter slots are handed out round-robin; a slot is free
