@@ -101,6 +101,26 @@ def test_hip_sort_story_matches_reference_model_fn():
                 assert ix.best_permutation(probs[s])[0] == ix.best_permutation(fx[f'{name}_probs'][s])[0]
 
 
+def test_hip_sort_story_product_model_fn():
+    """the same through the product's own zero-shot model_fn and permutation search (merlot_amd/sort_story.py)."""
+    from merlot_amd import ParamStore, sort_story as ss
+    fx = _load('ref_shim_sort_story.npz')
+    cfg = tiny_config(num_chunks_in_group=5)
+    bs, n = 2, 5
+    w = mo.init_weights(cfg, seed=int(fx['weights_seed']), perturb=True)
+    b = synth_batch(cfg, E=bs, num_chunks=n, Lc=32, seed=int(fx['batch_seed']))
+    st = ParamStore(cfg, 'cuda', seed=0)
+    st.load_tf_weights(w)
+    H, W = cfg['image_size']
+    feats = {'images': b['image'].reshape(bs, n, H, W, 3).cuda(), 'sentences': b['input_ids'].cuda()}
+    out = ss.model_fn_builder(cfg)(feats, None, 'infer', {'store': st, 'batch_size': bs, 'u_shuffle': fx['u_shuffle']})
+    for name in ('lang_viz', 'viz_viz'):
+        probs = out[f'{name}_probs'].cpu().numpy()
+        assert float(np.abs(probs - fx[f'{name}_probs']).max()) < 2e-2, name
+        for s in range(bs):
+            assert ss.best_permutation(probs[s])[0] == ss.best_permutation(fx[f'{name}_probs'][s])[0]
+
+
 def test_hip_inference_2d_ids_matches_reference_program():
     """2-D input_ids, is_training=False, no masking, shuffled_idx_img=None, ragged captions (one without padding, one that
     is START + padding) -- the way the downstream callers construct MerlotModel."""
