@@ -92,3 +92,74 @@ class Trainer(object):
         self.opt.step()
         self.step_idx += 1
         return out
+
+
+def train(config, device, dist_ctx=None, max_steps=None, num_workers=None, log_every=100, seed=0):
+    """`estimator.train(input_fn_builder(config, is_training=True), max_steps=optimizer.num_train_steps)` of
+    model/train.py:17-26 with the Estimator's housekeeping: resume from the latest checkpoint of `device.output_dir` if
+    there is one, a checkpoint every `device.iterations_per_loop` steps (utils/neat_config.py:140) and at the end, written
+    by rank 0 in the reference's own bundle format.  `train_batch_size` is the GLOBAL batch (examples), split evenly over
+    the ranks like the TPU replicas.  -> the Trainer."""
+    import os
+
+    from .input_pipeline import InputPipeline
+    rank = dist_ctx.rank if dist_ctx is not None else 0
+    world = dist_ctx.world_size if dist_ctx is not None else 1
+    global_bs = int(config.device['train_batch_size'])
+    if global_bs % world != 0:
+        raise ValueError(f"train_batch_size {global_bs} is not divisible by {world} replicas")
+    trainer = Trainer(config, device, dist_ctx, seed=seed)
+    out_dir = config.device['output_dir']
+    if ckpt_io.latest_checkpoint(out_dir) is not None:
+        trainer.restore(out_dir)
+    max_steps = int(max_steps if max_steps is not None else config.optimizer['num_train_steps'])
+    every = int(config.device.get('iterations_per_loop', 1000))
+    if num_workers is None:
+        num_workers = int(config.data.get('num_workers', 0))
+    pipe = InputPipeline(config, True, global_bs // world, device, rank=rank, world_size=world,
+                         seed=seed + trainer.step_idx, num_workers=num_workers)
+    try:
+        for features in pipe:
+            if trainer.step_idx >= max_steps:
+                break
+            out = trainer.step(features)
+            if rank == 0 and log_every and trainer.step_idx % log_every == 0:
+                print(f"step {trainer.step_idx}: loss {float(out['loss'].detach()):.4f}", flush=True)
+            if rank == 0 and (trainer.step_idx % every == 0 or trainer.step_idx == max_steps):
+                os.makedirs(out_dir, exist_ok=True)
+                trainer.save(out_dir)
+    finally:
+        pipe.close()
+    return trainer
+
+
+def main(argv=None):
+    """`python -m merlot_amd.train configs/merlot.yaml` (one process per GPU under torch.distributed.run)."""
+    import argparse
+    import os
+
+    import torch.distributed as dist
+
+    from .config import NeatConfig
+    from .parallel import DistContext
+    ap = argparse.ArgumentParser(description='MERLOT pretraining on MI355X')
+    ap.add_argument('config_file')
+    ap.add_argument('--max-steps', type=int, default=None)
+    ap.add_argument('--num-workers', type=int, default=None, help='loader processes per rank (default data.num_workers or 0)')
+    args = ap.parse_args(argv)
+    config = NeatConfig.from_yaml(args.config_file)
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    ctx = None
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+        ctx = DistContext()
+    train(config, device, ctx, max_steps=args.max_steps, num_workers=args.num_workers)
+    if ctx is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

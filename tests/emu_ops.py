@@ -443,11 +443,31 @@ def image_frames(src, jobs_host, jobs_dev, n_img, out_h, out_w):
     return out
 
 
+def adamw_step(param, grad, m, v, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0, wd_flags=None):
+    """csrc/elementwise.hip merlot_adamw_step: `lr` already carries the schedule and the bias correction; bf16 states use
+    the reference's sign-bit encoding of v (utils/optimization.py:267-288, restated in oracle/optimizer_oracle.py)."""
+    from oracle import optimizer_oracle as oo
+    bf = m.dtype == BF16
+    g = grad.float() * grad_scale
+    mf = m.float()
+    vf = torch.from_numpy(oo.decode_v(v.float().numpy())) if bf else v.float()
+    g2 = g * g + 1e-30
+    nm = beta1 * mf + (1.0 - beta1) * g
+    nv = beta2 * vf + (1.0 - beta2) * g2
+    upd = nm / (nv.sqrt() + eps)
+    wd = torch.full_like(param, float(weight_decay))
+    if wd_flags is not None:
+        wd = wd * wd_flags.float().repeat_interleave(64)[:param.numel()]
+    param.sub_(lr * (upd + wd * param))
+    m.copy_(nm)
+    v.copy_(torch.from_numpy(oo.encode_v(nv.numpy())) if bf else nv)
+
+
 _NAMES = ['gemm_nt', 'gemm_tn', 'patch_embed_fwd', 'patch_embed_wgrad', 'ln_fwd', 'ln_bwd', 'attention_fwd',
           'attention_bwd', 'attention_colsum', 'cast_bf16', 'cast_transpose_bf16', 'colsum_bf16', 'gather_add4',
           'scatter_add_rows', 'dropout_apply', 'cls_avgpool_fwd', 'cls_avgpool_bwd', 'softmax_ce', 'l2norm_fwd',
           'l2norm_bwd', 'gelu_fwd', 'gelu_bwd', 'mask_inputs', 'temporal_labels', 'shuffled_idx', 'im2col3x3', 'col2im3x3',
-          'groupnorm_fwd', 'groupnorm_bwd', 'avgpool2_fwd', 'avgpool2_bwd', 'cast_transpose_batched', 'image_frames']
+          'groupnorm_fwd', 'groupnorm_bwd', 'avgpool2_fwd', 'avgpool2_bwd', 'cast_transpose_batched', 'image_frames', 'adamw_step']
 
 
 def install(monkeypatch):

@@ -194,7 +194,7 @@ def _jpeg(arr):
     return b.getvalue()
 
 
-def _write_records(path, n_examples, num_chunks, seed):
+def _write_records(path, n_examples, num_chunks, seed, vocab=50000):
     """records as data/process.py:236-256 writes them"""
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), 'golden'))
     r = np.random.RandomState(seed)
@@ -207,8 +207,8 @@ def _write_records(path, n_examples, num_chunks, seed):
                 yy, xx = np.mgrid[0:h, 0:wd]
                 img = np.stack([(yy * 3 + e * 20) % 256, (xx * 2 + i * 30) % 256, (yy + xx) % 256], -1).astype(np.uint8)
                 enc = _jpeg(img)
-                clean = [int(t) for t in r.randint(100, 50000, r.randint(0, 45))]
-                raw = [int(t) for t in r.randint(100, 50000, r.randint(1, 20))]
+                clean = [int(t) for t in r.randint(100, vocab, r.randint(0, 45))]
+                raw = [int(t) for t in r.randint(100, vocab, r.randint(1, 20))]
                 c = {'image/encoded': enc, 'image/height': h, 'image/width': wd, 'image/key/sha256': b'00', 'image/format': b'jpeg',
                      'youtube_id': f'vid{e}_{i // 3}'.encode(), 'tokenized_cleaned_asr': clean, 'tokenized_raw_asr': raw,
                      'is_eoc': int(i % 3 == 2), 'mean_time': np.float32(1.5 * i), 'chunk_num': i}
@@ -338,3 +338,29 @@ def test_example_parsers_agree_on_random_messages_and_survive_garbage():
                 assert {k: v[1] for k, v in got.items()} == {k: v[1] for k, v in ref.items()}
 
     run()
+
+
+def test_train_loop_resumes_like_the_estimator(tmp_path, emu):
+    """merlot_amd.train.train = model/train.py's estimator.train: records -> steps, a checkpoint every
+    iterations_per_loop steps in the reference's bundle format, resume from output_dir on the next call."""
+    from merlot_amd import checkpoint as ck, train as T
+    from merlot_amd.config import NeatConfig
+    from common import tiny_config
+    for i in range(2):
+        _write_records(str(tmp_path / f'train{i:03d}.tfrecord'), 3, 4, seed=40 + i, vocab=2000)
+    out = str(tmp_path / 'out')
+    config = NeatConfig.from_dict({
+        'data': {'train_file': str(tmp_path / 'train*.tfrecord'), 'num_chunks': 4, 'chunk_text_len': 32, 'shuffle_buffer_size': 4,
+                 'num_threads': 2},
+        'model': dict(tiny_config(), vocab_size=2048),            # small word table: four checkpoints are written
+        'optimizer': {'type': 'adam_optimizer', 'learning_rate': 1e-4, 'num_train_steps': 100, 'num_warmup_steps': 10,
+                      'weight_decay_rate': 0.1, 'beta_2': 0.98, 'use_bfloat16_adam': True},
+        'device': {'output_dir': out, 'train_batch_size': 2, 'iterations_per_loop': 2}})
+    t1 = T.train(config, 'cpu', max_steps=3, log_every=0)
+    assert t1.step_idx == 3 and t1.opt.step_count == 3
+    assert ck.latest_checkpoint(out).endswith('model.ckpt-3')
+    assert os.path.exists(os.path.join(out, 'model.ckpt-2.index'))             # the periodic one
+    t2 = T.train(config, 'cpu', max_steps=4, log_every=0)                        # resumes at 3, runs ONE more step
+    assert t2.step_idx == 4 and ck.latest_checkpoint(out).endswith('model.ckpt-4')
+    assert int(ck.load_variable(out, 'global_step')) == 4
+    assert not torch.equal(t1.store.master, t2.store.master)
