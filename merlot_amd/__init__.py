@@ -6,3 +6,4 @@ Compute: hand-written gfx950 HIP kernels in libmerlot_hip.so behind the C-ABI of
 from .config import NeatConfig  # noqa: F401
 from .params import ParamStore  # noqa: F401
 from .modeling import MerlotModel, model_fn_builder  # noqa: F401
+from . import checkpoint, input_pipeline, optimization, sort_story, train  # noqa: F401,E402
