@@ -121,3 +121,48 @@ def test_dp2_matches_single_process_oracle(tmp_path):
             n = k[5:]
             r_ = rel_l2(torch.from_numpy(head(res[0]['grad'][n].float().numpy())), torch.from_numpy(fx[k]))
             assert r_ < 0.15, (n, r_)
+
+
+def _train_worker(rank, world, port, tmp):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import emu_ops
+
+    class MP(object):
+        def setattr(self, o, n, v):
+            setattr(o, n, v)
+    emu_ops.install(MP())
+    from common import tiny_config
+    from merlot_amd import train as T
+    from merlot_amd.config import NeatConfig
+    from merlot_amd.parallel import DistContext
+    config = NeatConfig.from_dict({
+        'data': {'train_file': os.path.join(tmp, 'train*.tfrecord'), 'num_chunks': 4, 'chunk_text_len': 32, 'shuffle_buffer_size': 2,
+                 'num_threads': 2},
+        'model': dict(tiny_config(), vocab_size=2048),
+        'optimizer': {'type': 'adam_optimizer', 'learning_rate': 1e-4, 'num_train_steps': 100, 'num_warmup_steps': 10,
+                      'weight_decay_rate': 0.1, 'beta_2': 0.98, 'use_bfloat16_adam': True},
+        'device': {'output_dir': os.path.join(tmp, 'out'), 'train_batch_size': 4, 'iterations_per_loop': 2}})
+    t = T.train(config, 'cpu', DistContext(), max_steps=2, log_every=0)
+    torch.save({'master': t.store.master.clone(), 'step': t.step_idx}, os.path.join(tmp, f'rank{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_train_loop_two_replicas(tmp_path):
+    """merlot_amd.train.train on 2 gloo ranks: the files are sharded by rank, the global batch of 4 examples is split 2 + 2,
+    both replicas hold the same weights after two steps (summed gradients, same update), rank 0 writes the checkpoint."""
+    from test_input_pipeline import _write_records
+    from merlot_amd import checkpoint as ck
+    for i in range(4):
+        _write_records(str(tmp_path / f'train{i:03d}.tfrecord'), 3, 4, seed=60 + i, vocab=2000)
+    port = 29600 + (os.getpid() % 300)
+    mp.spawn(_train_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(str(tmp_path / 'rank0.pt')), torch.load(str(tmp_path / 'rank1.pt'))
+    assert r0['step'] == r1['step'] == 2
+    assert torch.equal(r0['master'], r1['master'])
+    prefix = ck.latest_checkpoint(str(tmp_path / 'out'))
+    assert prefix.endswith('model.ckpt-2') and int(ck.load_variable(prefix, 'global_step')) == 2
