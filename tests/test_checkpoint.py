@@ -213,7 +213,7 @@ def test_table_round_trip_and_corruption_properties():
     corrupted byte is either detected (CheckpointError) or leaves the content intact (it hit padding)."""
     from hypothesis import given, settings, strategies as st
 
-    @settings(max_examples=120, deadline=None)
+    @settings(max_examples=120, deadline=None, derandomize=True, database=None)
     @given(st.dictionaries(st.binary(min_size=1, max_size=24), st.binary(max_size=60), max_size=40),
            st.integers(16, 400), st.integers(0, 10 ** 6), st.integers(0, 255))
     def run(kv, block_size, where, xor):
