@@ -17,6 +17,13 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(HERE))
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
 def _fixture_noise(rank):
     fx = np.load(os.path.join(HERE, 'golden', 'ref_shim_dp2.npz'))
     return {k: fx[f'r{rank}/noise/{k}'] for k in ('gumbel', 'span_lower', 'span_upper', 'random_ids', 'option')}
@@ -66,7 +73,7 @@ def _worker(rank, world, port, out_dir):
 @pytest.mark.timeout(600)
 def test_dp2_matches_single_process_oracle(tmp_path):
     world = 2
-    port = 29500 + os.getpid() % 2000
+    port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     res = [torch.load(os.path.join(str(tmp_path), f'rank{r}.pt')) for r in range(world)]
     # every replica ends with the same (summed) gradient arena
@@ -159,7 +166,7 @@ def test_train_loop_two_replicas(tmp_path):
     from merlot_amd import checkpoint as ck
     for i in range(4):
         _write_records(str(tmp_path / f'train{i:03d}.tfrecord'), 3, 4, seed=60 + i, vocab=2000)
-    port = 29600 + (os.getpid() % 300)
+    port = _free_port()
     mp.spawn(_train_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     r0, r1 = torch.load(str(tmp_path / 'rank0.pt')), torch.load(str(tmp_path / 'rank1.pt'))
     assert r0['step'] == r1['step'] == 2
