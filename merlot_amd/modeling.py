@@ -106,8 +106,6 @@ class MerlotModel(object):
             raise ValueError("the ResNet-hybrid stem reduces by 16 (utils/vision_transformer.py:208)")
         if cfg.get('num_imgs', 1) != 1 or cfg.get('num_texts', 1) != 1:
             raise NotImplementedError("num_imgs / num_texts > 1 (VCR path) is out of scope")
-        if img_mask is not None:
-            raise NotImplementedError("img_mask is only used by the VCR path (out of scope)")
 
         input_ids = torch.as_tensor(input_ids).to(dev)
         if input_ids.dim() == 2:                                                  # modeling.py:72-77
@@ -196,8 +194,11 @@ class MerlotModel(object):
                                     (st.p('vision_backbone/final_pe/pos_embs'), st.g('vision_backbone/final_pe/pos_embs'), idx_fpos, vl)],
                                    N * vl, H, self._anchor)                        # :125 + :299-337
         image_feats = L.layer_norm(image_feats, st.ln('vision_backbone/LayerNorm_final_ln'), out_bf16=True)   # :126-128
-        self.encoder_pieces = [{'name': 'viz', 'x': image_feats.view(self.B, self.P, H),
-                                'is_valid': torch.ones((self.B, self.P), device=dev, dtype=torch.bool)}]
+        if img_mask is None:                                                      # :105-108
+            viz_valid = torch.ones((self.B, self.P), device=dev, dtype=torch.bool)
+        else:                                                                     # :108, :122 with num_imgs = 1: one flag
+            viz_valid = torch.as_tensor(img_mask).to(dev).bool().reshape(self.B, 1).expand(self.B, self.P)   # per group
+        self.encoder_pieces = [{'name': 'viz', 'x': image_feats.view(self.B, self.P, H), 'is_valid': viz_valid}]
 
         # ---------------- language half (:135-149)
         if mask_input:

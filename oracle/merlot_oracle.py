@@ -315,7 +315,7 @@ class MerlotOracle(object):
     """
 
     def __init__(self, config, weights, image, input_ids, mask_input=False, shuffled_idx_img=None,
-                 log_attention_probs=True, noise=None, attention_summs=None):
+                 log_attention_probs=True, noise=None, attention_summs=None, img_mask=None):
         """attention_summs (optional, [B, L] fp32): use THESE per-key attention sums for the top-k step of mask_inputs
         instead of the oracle's own -- lets a test hold the integer masking logic to bit-exactness when the other
         implementation's sums differ in the last bf16 digits (a near-tie then legitimately flips the top-k set)."""
@@ -348,7 +348,10 @@ class MerlotOracle(object):
         image_feats = image_feats + self.vision_pos_emb(shuffled_idx_img)         # :125
         image_feats = layer_norm(image_feats, self.w, 'vision_backbone/LayerNorm_final_ln')   # :126
         self.image_feats = image_feats
-        img_valid = torch.ones(self.B, self.P, dtype=torch.bool)
+        if img_mask is None:                                                      # :105-108, :122 (num_imgs = 1)
+            img_valid = torch.ones(self.B, self.P, dtype=torch.bool)
+        else:
+            img_valid = torch.as_tensor(img_mask).bool().reshape(self.B, 1).expand(self.B, self.P)
 
         # ---- language half (:135-149)
         if mask_input:

@@ -62,14 +62,15 @@ def draws_to_noise(draws, B, L, nm):
 
 
 def run_reference(cfg, weights, batch, seed, is_training=True, mask_input=True, with_optimizer=None,
-                  global_step=0):
+                  global_step=0, img_mask=None):
     tf_shim.STATE.reset(seed=seed, injected={k: npy(v) for k, v in weights.items()})
     image = tf_shim._w(batch['image'].float().clone())
     ids = tf_shim._w(batch['input_ids'].to(torch.int32).clone())
     sidx = tf_shim._w(torch.from_numpy(np.asarray(batch['shuffled_idx_img']).reshape(-1)).to(torch.int32))
     vsrc = tf_shim._w(torch.from_numpy(np.asarray(batch['video_src_ids'])).to(torch.int32))
     model = ref_modeling.MerlotModel(config=cfg, is_training=is_training, use_tpu=False, image=image,
-                                     input_ids=ids, mask_input=mask_input, shuffled_idx_img=sidx)
+                                     input_ids=ids, mask_input=mask_input, shuffled_idx_img=sidx,
+                                     img_mask=None if img_mask is None else tf_shim._w(torch.as_tensor(img_mask)))
     out = {'model': model}
     if mask_input:
         # model_fn, model/modeling.py:700-713
@@ -447,7 +448,8 @@ def make_resnet_stem():
 
 VARIANTS = {'unshared': dict(share_params=False, num_lang_transformer_hidden_layers=1),
             'langonly_groups': dict(langonly_num_chunks_in_group=2),
-            'block_mask': dict(disable_pairwise_lang_attn=True)}
+            'block_mask': dict(disable_pairwise_lang_attn=True),
+            'img_mask': dict(_img_mask=[True, False])}          # constructor argument, not a config key (:65, :105-122)
 VARIANT_GRADS = ('encoder/layer00/query_layer/kernel', 'encoder/layer01/output/kernel', 'word_embeddings/word_embeddings',
                  'langonly_embeddings/position_embeddings', 'langonly_encoder/layer00/intermediate/kernel',
                  'langonly_encoder/LayerNorm_ln_final/gamma')
@@ -459,11 +461,13 @@ def make_variants():
     (:345-351) and `disable_pairwise_lang_attn` (:160-168)."""
     fx = {}
     for name, over in VARIANTS.items():
+        over = dict(over)
+        img_mask = over.pop('_img_mask', None)
         cfg = tiny_config(use_bfloat16=False, **over)
         batch = synth_batch(cfg, E=2, num_chunks=4, Lc=32, seed=3)
         weights = mo.init_weights(cfg, seed=8, perturb=True)
         tf_shim.STATE.reset(seed=11, injected={k: npy(v) for k, v in weights.items()})
-        ref = run_reference(cfg, weights, batch, seed=11)
+        ref = run_reference(cfg, weights, batch, seed=11, img_mask=img_mask)
         m = ref['model']
         st = tf_shim.STATE
         names = sorted(n for n in st.vars if 'adam_' not in n and n != 'global_step')
@@ -475,7 +479,7 @@ def make_variants():
         for t in weights.values():
             t.requires_grad_(True)
         o = mo.MerlotOracle(cfg, weights, batch['image'], batch['input_ids'], mask_input=True,
-                            shuffled_idx_img=batch['shuffled_idx_img'], noise=noise)
+                            shuffled_idx_img=batch['shuffled_idx_img'], noise=noise, img_mask=img_mask)
         o_loss, _ = o.total_loss(batch['shuffled_idx_img'], batch['video_src_ids'])
         o_loss.backward()
         e_loss = abs(float(o_loss) - float(npy(ref['loss'])))

@@ -258,7 +258,7 @@ def test_clip_by_global_norm_matches_reference_rule():
             assert torch.allclose(st.g(n), ref[n] * factor, rtol=1e-5, atol=1e-8), n
 
 
-@pytest.mark.parametrize('name', ['unshared', 'langonly_groups', 'block_mask'])
+@pytest.mark.parametrize('name', ['unshared', 'langonly_groups', 'block_mask', 'img_mask'])
 def test_config_variants_match_reference_program(emu, name):
     """the host wiring of `share_params: False` (own `langonly_encoder` weights, its own depth) and
     `langonly_num_chunks_in_group` against what the reference program computed (tests/golden/ref_shim_variants.npz)."""
@@ -267,7 +267,9 @@ def test_config_variants_match_reference_program(emu, name):
     from test_reference_shim import VARIANTS
     fx = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'ref_shim_variants.npz'))
     p = name + '/'
-    cfg = tiny_config(**VARIANTS[name])
+    over = dict(VARIANTS[name])
+    img_mask = over.pop('_img_mask', None)
+    cfg = tiny_config(**over)
     b = synth_batch(cfg, E=2, num_chunks=4, Lc=32, seed=3)
     w = mo.init_weights(cfg, seed=8, perturb=True)
     st = ParamStore(cfg, 'cpu', seed=0)
@@ -275,7 +277,8 @@ def test_config_variants_match_reference_program(emu, name):
     assert sorted(st.export_tf_weights()) == [str(n) for n in fx[p + 'variable_names']]
     noise = {k: torch.from_numpy(fx[p + 'noise/' + k]) for k in ('gumbel', 'span_lower', 'span_upper', 'random_ids', 'option')}
     sidx = torch.from_numpy(b['shuffled_idx_img'])
-    pm = MerlotModel(cfg, True, False, b['image'], b['input_ids'], mask_input=True, shuffled_idx_img=sidx, params=st, noise=noise)
+    pm = MerlotModel(cfg, True, False, b['image'], b['input_ids'], mask_input=True, shuffled_idx_img=sidx, params=st, noise=noise,
+                     img_mask=None if img_mask is None else torch.tensor(img_mask))
     assert np.array_equal(pm.lang_mask_info['masked_idx'].numpy(), fx[p + 'masked_idx'])
     assert np.array_equal(pm.lang_mask_info['masked_ids'].numpy(), fx[p + 'masked_ids'])
     loss = pm.mask_loss()[0] + pm.contrastive_loss()[0] + pm.temporal_loss(sidx, torch.from_numpy(b['video_src_ids']))[0]

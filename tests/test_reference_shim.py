@@ -212,7 +212,8 @@ def test_optimizer_restatement_matches_reference_adam():
 
 VARIANTS = {'unshared': dict(share_params=False, num_lang_transformer_hidden_layers=1),
             'langonly_groups': dict(langonly_num_chunks_in_group=2),
-            'block_mask': dict(disable_pairwise_lang_attn=True)}
+            'block_mask': dict(disable_pairwise_lang_attn=True),
+            'img_mask': dict(_img_mask=[True, False])}          # constructor argument (model/modeling.py:65, 105-122)
 
 
 @pytest.mark.parametrize('name', sorted(VARIANTS))
@@ -221,13 +222,15 @@ def test_restatement_matches_reference_config_variants(name):
     `langonly_num_chunks_in_group` (:345-351), `disable_pairwise_lang_attn` (:160-168) on the training graph."""
     fx = _load('ref_shim_variants.npz')
     p = name + '/'
-    cfg = tiny_config(use_bfloat16=False, **VARIANTS[name])
+    over = dict(VARIANTS[name])
+    img_mask = over.pop('_img_mask', None)
+    cfg = tiny_config(use_bfloat16=False, **over)
     b = synth_batch(cfg, E=2, num_chunks=4, Lc=32, seed=3)
     w = _weights(cfg, 8)
     assert sorted(w) == [str(n) for n in fx[p + 'variable_names']]
     assert ('langonly_encoder/layer00/query_layer/kernel' in w) == (name == 'unshared')
     o = mo.MerlotOracle(cfg, w, b['image'], b['input_ids'], mask_input=True, shuffled_idx_img=b['shuffled_idx_img'],
-                        noise=_noise(fx, p + 'noise/'))
+                        noise=_noise(fx, p + 'noise/'), img_mask=img_mask)
     loss, info = o.total_loss(b['shuffled_idx_img'], b['video_src_ids'])
     assert np.array_equal(o.lang_mask_info['masked_idx'].numpy(), fx[p + 'masked_idx'])
     assert np.array_equal(o.lang_mask_info['masked_ids'].numpy(), fx[p + 'masked_ids'])

@@ -181,7 +181,9 @@ def test_hip_config_variants_match_reference_program(name):
     from test_reference_shim import VARIANTS
     fx = _load('ref_shim_variants.npz')
     p = name + '/'
-    cfg = tiny_config(**VARIANTS[name])
+    over = dict(VARIANTS[name])
+    over.pop('_img_mask', None)
+    cfg = tiny_config(**over)
     b = synth_batch(cfg, E=2, num_chunks=4, Lc=32, seed=3)
     w = mo.init_weights(cfg, seed=8, perturb=True)
     st = ParamStore(cfg, 'cuda', seed=0)
