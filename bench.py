@@ -71,7 +71,29 @@ def cpu_baseline_worker(threads):
         if time.time() - t_start > 20.0 and times:
             break
     med = float(np.median(times))
+    # BASELINE config #1 exactly as stated (64^2 frames, 2+2+2 layers, batch 2 x 4 segments): the reference's own
+    # CPU-runnable case, timed the same way
+    from common import tiny_config
+    cfg1 = tiny_config(use_bfloat16=False)
+    w1 = mo.init_weights(cfg1, 0, perturb=False)
+    for t in w1.values():
+        t.requires_grad_(True)
+    b1 = synth_batch(cfg1, E=2, num_chunks=4, seed=3)
+    t1 = []
+    for it in range(4):
+        for t in w1.values():
+            t.grad = None
+        t0 = time.time()
+        m1 = mo.MerlotOracle(cfg1, w1, b1['image'], b1['input_ids'], mask_input=True, shuffled_idx_img=b1['shuffled_idx_img'],
+                             noise=b1['noise'])
+        l1, _ = m1.total_loss(b1['shuffled_idx_img'], b1['video_src_ids'])
+        l1.backward()
+        if it > 0:
+            t1.append(time.time() - t0)
+    med1 = float(np.median(t1))
     print(json.dumps({'value': 4.0 / med, 'unit': 'segments/s', 'cores': threads, 'kind': 'port',
+                      'config1': {'value': 8.0 / med1, 'unit': 'segments/s', 'sample': f'BASELINE config #1 (64^2, 2+2+2 layers, '
+                                  f'batch 2 x 4 segments), oracle fwd+bwd, median of {len(t1)} steps ({med1:.2f} s/step)'},
                       'sample': f'oracle (torch-CPU fp32, unfused, op-for-op restatement of the TF graph) fwd+bwd, 1 example x 4 '
                                 f'segments @224^2, 12+12+12 layers, median of {len(times)} steps after 1 warm-up '
                                 f'({med:.2f} s/step), {threads} threads'}), flush=True)
