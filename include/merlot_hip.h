@@ -59,6 +59,15 @@ int merlot_gemm_bf16_nt(const void* A, int64_t lda, const void* Bt, int64_t ldb,
                         const float* bias, const void* aux_in, int64_t ld_aux_in, void* aux_out,
                         int64_t ld_aux_out, float dropout_p, uint64_t dropout_seed, merlot_stream_t stream);
 
+/* Which kernel merlot_gemm_bf16_nt runs for a problem size (the choice depends on M, N, K only); -1 for sizes the
+ * entry point rejects.  Tests use it to assert that a shape exercises the kernel they mean to check. */
+#define MERLOT_NT_KERNEL_RING_128x256 11    /* gemm_nt_ring_kernel<Cfg<2,4,2,2,32,3>>: 2 workgroups / CU            */
+#define MERLOT_NT_KERNEL_RING_256x64 14     /* gemm_nt_ring_kernel<Cfg<4,1,2,2,32,3>>: narrow outputs               */
+#define MERLOT_NT_KERNEL_RING_256x128 15    /* gemm_nt_ring_kernel<Cfg<4,1,2,4,32,3>>                               */
+#define MERLOT_NT_KERNEL_PERSIST_STATIC 20  /* gemm_nt_persist_kernel: persistent 256x256, static tile striding      */
+#define MERLOT_NT_KERNEL_PERSIST_DYN 21     /* gemm_nt_persist_dyn_kernel: persistent 256x256, dynamic tile claims   */
+int merlot_gemm_bf16_nt_plan(int64_t M, int64_t N, int64_t K);
+
 /* Weight gradient: C[M,N] (f32) (+)= alpha * sum_r A[r,M] * B[r,N].  A, B bf16 row-major with the
  * reduction index r as the SLOW dim (activations / output grads as stored).  M, N even.
  * The reduction is split over the grid; partial tiles go through the caller-owned `workspace` (f32, at least
@@ -240,22 +249,6 @@ int merlot_groupnorm_bwd(const void* dy, const void* y, const void* x, const flo
 /* tf.nn.avg_pool2d(ksize 2, strides 2) on even H, W; the backward takes dy [N, H/2, W/2, C] and writes dx [N, H, W, C]. */
 int merlot_avgpool2_fwd(const void* x, void* y, int N, int H, int W, int C, merlot_stream_t stream);
 int merlot_avgpool2_bwd(const void* dy, void* dx, int N, int H, int W, int C, merlot_stream_t stream);
-
-/* ------------------------------------------------------------------------------------------------
- * Hardware-layout probes (diagnostics; used by tests to pin the MFMA / LDS-transpose lane maps the
- * kernels above assume).  out_* are small device buffers, see csrc/probe.hip.
- * ---------------------------------------------------------------------------------------------- */
-int merlot_probe_mfma32(const void* a, const void* b, float* d, merlot_stream_t stream);
-int merlot_probe_tr16(const void* tile, void* out, merlot_stream_t stream);
-/* experiment helper: `blocks` one-wave workgroups that each hold lds_bytes of LDS and spin for ~cycles shader clocks
- * (a stand-in for a communication kernel sharing the GPU with the GEMMs); sink = any 4-byte device buffer. */
-/* experiment helper: copy the persistent GEMM's per-workgroup timeline (recorded when MERLOT_DBG has bit 512) */
-int merlot_probe_persist_trace(void* dst, int64_t bytes, merlot_stream_t stream);
-int merlot_probe_cu_hog(int blocks, int lds_bytes, int64_t cycles, void* sink, merlot_stream_t stream);
-/* experiment helper: matrix-pipe rate of `blocks` 8-wave workgroups issuing the 256x256 GEMM's K-step instruction mix
- * (16 MFMA 32x32x16 per wave and iteration; mode bit 1: + its 12 ds_read_b128, bit 2: + s_barrier, bit 4: MFMA operands
- * come from those reads).  out: int64 [blocks][4] = {shader-clock delta, 100 MHz wall-clock delta, 0, 0}. */
-int merlot_probe_mfma_rate(int blocks, int iters, int mode, void* out, void* sink, merlot_stream_t stream);
 
 /* ---- input pipeline: frame preprocessing ---------------------------------------------------------
  * One job per frame: decoded JPEG (HWC uint8, device) -> convert_image_dtype * resize_images(method, align_corners=True)

@@ -1,26 +1,45 @@
 #!/bin/bash
-# Build libmerlot_hip.so for gfx950 (cross-compiles without a GPU).  Usage: build.sh [-j]
+# Build the HIP libraries for gfx950 (cross-compiles without a GPU).
+#   build.sh        libmerlot_hip.so   (product: no experiment switches, no probes)
+#                   libmerlot_probe.so (hardware probes used by tests/ and scripts/; never loaded by the product)
+#   build.sh exp    additionally libmerlot_hip_exp.so = the product sources with -DMERLOT_EXPERIMENTS (scripts/ only)
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-OUT=../libmerlot_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable"
-mkdir -p build
-pids=()
-for f in gemm attention layernorm elementwise index probe conv image; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ ../../include/merlot_hip.h -nt build/$f.o ]; then
-    ( $HIPCC $FLAGS -c $f.hip -o build/$f.o ) &
-    pids+=($!)
-  fi
-done
-if [ ! -f build/capi.o ] || [ capi.cpp -nt build/capi.o ] || [ ../../include/merlot_hip.h -nt build/capi.o ]; then
-  ( g++ -O2 -fPIC -std=c++17 -c capi.cpp -o build/capi.o ) &
-  pids+=($!)
+SRCS="gemm attention layernorm elementwise index conv image"
+HDRS="common.h gemm_ring.h ../../include/merlot_hip.h"
+
+newer() {  # newer <target> <deps...>: true when target is missing or older than a dependency
+  local t=$1; shift
+  [ ! -f "$t" ] && return 0
+  for d in "$@"; do [ "$d" -nt "$t" ] && return 0; done
+  return 1
+}
+
+build_lib() {  # build_lib <objdir> <out> <extra flags>
+  local dir=$1 out=$2 extra=$3
+  mkdir -p $dir
+  local pids=()
+  for f in $SRCS; do
+    if newer $dir/$f.o $f.hip $HDRS; then ( $HIPCC $FLAGS $extra -c $f.hip -o $dir/$f.o ) & pids+=($!); fi
+  done
+  for f in capi hostio; do
+    if newer $dir/$f.o $f.cpp ../../include/merlot_hip.h; then ( g++ -O2 -fPIC -std=c++17 $extra -c $f.cpp -o $dir/$f.o ) & pids+=($!); fi
+  done
+  for p in "${pids[@]}"; do wait $p; done
+  local objs=""
+  for f in $SRCS capi hostio; do objs="$objs $dir/$f.o"; done
+  $HIPCC --offload-arch=gfx950 -shared -fPIC -o $out $objs
+  echo "built $(realpath $out)"
+}
+
+build_lib build ../libmerlot_hip.so ""
+if newer ../libmerlot_probe.so probe.hip capi.cpp common.h ../../include/merlot_probe.h; then
+  $HIPCC $FLAGS -c probe.hip -o build/probe.o
+  $HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libmerlot_probe.so build/probe.o build/capi.o
+  echo "built $(realpath ../libmerlot_probe.so)"
 fi
-if [ ! -f build/hostio.o ] || [ hostio.cpp -nt build/hostio.o ] || [ ../../include/merlot_hip.h -nt build/hostio.o ]; then
-  ( g++ -O2 -fPIC -std=c++17 -c hostio.cpp -o build/hostio.o ) &
-  pids+=($!)
+if [ "$1" = "exp" ]; then
+  build_lib build_exp ../libmerlot_hip_exp.so "-DMERLOT_EXPERIMENTS"
 fi
-for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT build/gemm.o build/attention.o build/layernorm.o build/elementwise.o build/index.o build/probe.o build/conv.o build/image.o build/capi.o build/hostio.o
-echo "built $(realpath $OUT)"

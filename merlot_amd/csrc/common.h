@@ -16,6 +16,14 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
+// Experiment switches (scripts/ only).  The product library is compiled WITHOUT MERLOT_EXPERIMENTS: no getenv, no
+// debug bits in any kernel, no probe exports -- `build.sh exp` builds libmerlot_hip_exp.so with them.
+#ifdef MERLOT_EXPERIMENTS
+#define DBG_BIT(p, bit) ((((p).dbg) & (bit)) != 0)
+#else
+#define DBG_BIT(p, bit) (false)
+#endif
+
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 

@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTNArgs p) {
 template <int EPI, bool OUT_F32>
 __device__ __forceinline__ void epilogue_row8(const GemmNTArgs& p, int m, int n, float (&v)[8]) {
     // v = alpha * acc for columns n..n+7 of row m; n + 7 < N guaranteed, 16-B alignment guaranteed by the caller
-    if (p.dbg & 8) {                                     // experiments: epilogue arithmetic + staging, no memory ops
+    if DBG_BIT(p, 8) {                                     // experiments: epilogue arithmetic + staging, no memory ops
         if (v[0] == 12345.678f) *reinterpret_cast<float*>(p.C) = v[1];
         return;
     }
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(C::NT) void gemm_nt_ring_kernel(const GemmNTArgs p)
         b_src[i] = p.B + (int64_t)min(n0 + row, p.N - 1) * p.ldb + chunk * 8;
     }
     auto stage = [&](int kt) {
-        if (p.dbg & 4) return;                       // experiments: no global->LDS traffic at all
+        if DBG_BIT(p, 4) return;                       // experiments: no global->LDS traffic at all
         char* la = dsm + (kt % S) * C::STAGE_BYTES + wave * C::A_PIECES * 1024;
         char* lb = dsm + (kt % S) * C::STAGE_BYTES + C::A_BYTES + wave * C::B_PIECES * 1024;
         const int k0 = kt * BK;
@@ -692,7 +692,7 @@ __global__ __launch_bounds__(C::NT) void gemm_nt_ring_kernel(const GemmNTArgs p)
                     acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[kk][fj], af[kk][fi], acc[fi][fj], 0, 0, 0);
     };
 
-    const int nk = (p.dbg & 2) ? 0 : p.K / BK;
+    const int nk = DBG_BIT(p, 2) ? 0 : p.K / BK;
     // prologue: S-1 stages in flight
 #pragma unroll
     for (int t = 0; t < S - 1; ++t)
@@ -712,7 +712,7 @@ __global__ __launch_bounds__(C::NT) void gemm_nt_ring_kernel(const GemmNTArgs p)
     }
 
     // ---- epilogue (row-contiguous, staged through this wave's slice of the now idle ring)
-    if ((p.dbg & 1) && acc[0][0][0] != 12345.678f) return;
+    if (DBG_BIT(p, 1) && acc[0][0][0] != 12345.678f) return;
     __builtin_amdgcn_s_barrier();                    // every wave is done reading the last ring stage
     staged_epilogue<C, EPI, OUT_F32>(p, acc, dsm + wave * C::EPI_BYTES, m0 + wm * C::FM * 32, n0 + wn * C::FN * 32, lane);
 }
@@ -836,7 +836,7 @@ __device__ __forceinline__ void fast_tile_epilogue(const GemmNTArgs& p, f32x16 (
                 v[e] = x0[e] + bias_r[fp][0][e];
                 v[4 + e] = x1[e] + bias_r[fp][1][e];
             }
-            const bool no_store = p.dbg & 8, no_math = p.dbg & 128;       // experiments only
+            const bool no_store = DBG_BIT(p, 8), no_math = DBG_BIT(p, 128);       // experiments only
             if (EPI == MERLOT_EPI_GELU) {
                 if (p.aux_out && !no_store) {
                     bf16x8 u8;
@@ -1004,7 +1004,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const GemmNTArgs p
                         acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[fj], af[fi], acc[fi][fj], 0, 0, 0);
             }
         }
-        if ((p.dbg & 1) && acc[0][0][0] != 12345.678f) continue;
+        if (DBG_BIT(p, 1) && acc[0][0][0] != 12345.678f) continue;
         const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
         const int m_base = tm * C::BM + wm * C::FM * 32, n_base = tn * C::BN + wn * C::FN * 32;
 #pragma unroll
@@ -1047,7 +1047,12 @@ __device__ __forceinline__ void tile_coords(const GemmNTArgs& p, int tile, int& 
 constexpr int PERSIST_SLOTS = 1024;
 // experiments (dbg & 512): per-workgroup timeline, [wg][tile-slot][0..2] = s_memtime at tile start / loop end / epilogue end
 constexpr int TRACE_TILES = 32;
+#ifdef MERLOT_EXPERIMENTS
 __device__ long long g_persist_trace[256 * TRACE_TILES * 4];
+#define PERSIST_TRACE(i, j, v) g_persist_trace[((i) * TRACE_TILES + trace_i) * 4 + (j)] = (v)
+#else
+#define PERSIST_TRACE(i, j, v) ((void)0)
+#endif
 __device__ unsigned int g_persist_ctr[PERSIST_SLOTS * 16];   // [slot][0..7] claims per XCD, [slot][8] departures
 
 template <int EPI, bool OUT_F32>
@@ -1067,7 +1072,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_dyn_kernel(const GemmNTAr
     const int band0 = slot - ((int)blockIdx.x >> 3);                  // first tile of the band in round 0
     unsigned int* ctr = g_persist_ctr + ctr_slot * 16;
     volatile int* bcast = reinterpret_cast<volatile int*>(dsm + C::RING_BYTES);   // wave 0's idle epilogue slab
-    const bool fast_ok = !(p.dbg & 32) && !(p.N & 1) && ((p.ldc & 7) == 0) && ((p.ld_aux_in & 7) == 0) && ((p.ld_aux_out & 7) == 0) &&
+    const bool fast_ok = !DBG_BIT(p, 32) && !(p.N & 1) && ((p.ldc & 7) == 0) && ((p.ld_aux_in & 7) == 0) && ((p.ld_aux_out & 7) == 0) &&
                          ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) && ((reinterpret_cast<uintptr_t>(p.aux_in) & 15) == 0) &&
                          ((reinterpret_cast<uintptr_t>(p.aux_out) & 15) == 0) && ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0) &&
                          !(OUT_F32 && p.accumulate) && !(EPI == MERLOT_EPI_GELU && !p.aux_out && false);
@@ -1151,9 +1156,9 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_dyn_kernel(const GemmNTAr
     int g = 0;
     int trace_i = 0;
     for (int tile = slot; tile < ntiles; tile = next_tile) {
-        if ((p.dbg & 512) && tid == 0 && trace_i < TRACE_TILES) {
-            g_persist_trace[(blockIdx.x * TRACE_TILES + trace_i) * 4 + 0] = __builtin_amdgcn_s_memtime();
-            g_persist_trace[(blockIdx.x * TRACE_TILES + trace_i) * 4 + 3] = tile;
+        if (DBG_BIT(p, 512) && tid == 0 && trace_i < TRACE_TILES) {
+            PERSIST_TRACE(blockIdx.x, 0, __builtin_amdgcn_s_memtime());
+            PERSIST_TRACE(blockIdx.x, 3, tile);
         }
         f32x16 acc[C::FM][C::FN];
 #pragma unroll
@@ -1185,14 +1190,14 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_dyn_kernel(const GemmNTAr
                         acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[fj], af[fi], acc[fi][fj], 0, 0, 0);
             }
         }
-        if ((p.dbg & 512) && tid == 0 && trace_i < TRACE_TILES)
-            g_persist_trace[(blockIdx.x * TRACE_TILES + trace_i) * 4 + 1] = __builtin_amdgcn_s_memtime();
+        if (DBG_BIT(p, 512) && tid == 0 && trace_i < TRACE_TILES)
+            PERSIST_TRACE(blockIdx.x, 1, __builtin_amdgcn_s_memtime());
         int claimed = ntiles;
         if (tid == 0 && claims_open) claimed = claim();  // for the tile after next; the return is awaited below
         int tm, tn;
         tile_coords(p, tile, tm, tn);
         const int m_base = tm * C::BM + wm * C::FM * 32, n_base = tn * C::BN + wn * C::FN * 32;
-        if (!(p.dbg & 1)) {
+        if (!DBG_BIT(p, 1)) {
             const bool interior = fast_ok && (tm + 1) * C::BM <= p.M && (tn + 1) * C::BN <= p.N;
             if (interior) {
                 fast_tile_epilogue<EPI, OUT_F32>(p, acc, slab, m_base, n_base, lane);
@@ -1208,8 +1213,8 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_dyn_kernel(const GemmNTAr
             claims_open = claimed < ntiles;
             *bcast = claimed;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // published before the next s_barrier
-            if ((p.dbg & 512) && trace_i < TRACE_TILES)
-                g_persist_trace[(blockIdx.x * TRACE_TILES + trace_i) * 4 + 2] = __builtin_amdgcn_s_memtime();
+            if (DBG_BIT(p, 512) && trace_i < TRACE_TILES)
+                PERSIST_TRACE(blockIdx.x, 2, __builtin_amdgcn_s_memtime());
         }
         ++trace_i;
     }
@@ -1260,7 +1265,7 @@ __global__ __launch_bounds__(C::NT) void gemm_tn_ring_kernel(const GemmTNArgs p,
     const int tile_n = tile - tile_m * p.ntn;
     const int m0 = tile_m * C::BM, n0 = tile_n * C::BN;
     const int ks = split * p.rchunk;                     // rchunk in K-steps
-    const int ke = (p.dbg & 2) ? ks : min(ksteps, ks + p.rchunk);
+    const int ke = DBG_BIT(p, 2) ? ks : min(ksteps, ks + p.rchunk);
     const int nk = ke - ks;
 
     const bf16* a_src[C::A_PIECES];
@@ -1280,7 +1285,7 @@ __global__ __launch_bounds__(C::NT) void gemm_tn_ring_kernel(const GemmTNArgs p,
         b_src[i] = p.B + (int64_t)(ks * BK + rb * 16 + (lane >> 2)) * p.ldb + col;
     }
     auto stage = [&](int t) {
-        if (p.dbg & 4) return;
+        if DBG_BIT(p, 4) return;
         char* la = dsm + (t % S) * C::STAGE_BYTES + wave * C::A_PIECES * 1024;
         char* lb = dsm + (t % S) * C::STAGE_BYTES + C::A_BYTES + wave * C::B_PIECES * 1024;
         const int64_t r0 = (int64_t)t * BK;
@@ -1345,7 +1350,7 @@ __global__ __launch_bounds__(C::NT) void gemm_tn_ring_kernel(const GemmTNArgs p,
         compute(t);
     }
 
-    if ((p.dbg & 1) && acc[0][0][0] != 12345.678f) return;
+    if (DBG_BIT(p, 1) && acc[0][0][0] != 12345.678f) return;
     __builtin_amdgcn_s_barrier();
     GemmNTArgs e{};                                      // reuse the row-contiguous NT epilogue (EPI_NONE, fp32 out)
     e.M = p.M; e.N = p.N; e.alpha = p.alpha;
@@ -1460,12 +1465,10 @@ int launch_persist_dyn_one(GemmNTArgs& a, hipStream_t s) {
     }
     a.ntm = cdiv(a.M, RingP::BM);
     a.ntn = cdiv(a.N, RingP::BN);
-    static const int tile_cg = [] {
-        const char* e = getenv("MERLOT_NT_TILE_CG");       // tile-column group width of the enumeration, 0 = row-major
-        return e ? atoi(e) : 0;
-    }();
-    a.cg = tile_cg;
-    if (const char* e = getenv("MERLOT_NT_TILE_CG_DYN")) a.cg = atoi(e);   // re-read every call (experiments only)
+    a.cg = 0;                                            // row-major tile enumeration (profiles/r01_i_gemm_ceiling.txt section 5)
+#ifdef MERLOT_EXPERIMENTS
+    if (const char* e = getenv("MERLOT_NT_TILE_CG_DYN")) a.cg = atoi(e);
+#endif
     int grid = a.ntm * a.ntn;
     if (grid > 256) grid = 256;
     static std::atomic<unsigned int> seq{0};             // counter slots are handed out round-robin; a slot is free
@@ -1497,49 +1500,47 @@ using RingK = ring::Cfg<2, 4, 2, 2, 32, 3>;   // 128x256, BK 32, 3 stages, 72 KB
 using RingN64 = ring::Cfg<4, 1, 2, 2, 32, 3>;   // 256x64,  4 waves, 60 KB: narrow outputs (ResNet-stem 1x1 / 3x3 with 32..64 filters)
 using RingN128 = ring::Cfg<4, 1, 2, 4, 32, 3>;  // 256x128, 4 waves, 72 KB
 
-int nt_config_override() {
-    static int v = -2;
-    if (v == -2) {
-        const char* e = getenv("MERLOT_NT_CFG");
-        v = e ? atoi(e) : -1;
-    }
-    return v;
+// Which kernel a shape runs on (also exported as merlot_gemm_bf16_nt_plan so tests can assert it).  From the sweeps in
+// profiles/r01_gemm_tile_sweep.txt: the persistent 256x256 kernel wins whenever its rounds of 256 workgroups are well
+// filled (>= 85 % of the slots of its last round included); otherwise 128x256 tiles with two co-resident workgroups
+// per CU absorb the ragged tail better.
+int nt_plan(int64_t M, int64_t N, int64_t K) {
+    const int64_t tiles = (int64_t)cdiv(M, 256) * cdiv(N, 256);
+    const int64_t rounds = (tiles + 255) / 256;
+    int cfg = (tiles * 100 >= rounds * 256 * 85) ? MERLOT_NT_KERNEL_PERSIST_DYN : MERLOT_NT_KERNEL_RING_128x256;
+    if (cfg == MERLOT_NT_KERNEL_PERSIST_DYN && K / RingP::BK < 4) cfg = MERLOT_NT_KERNEL_PERSIST_STATIC;
+    // short K loop behind a three-tile-wide output (attention out-projection and its dgrad, 768 x 768): the epilogue
+    // is a large share of the launch and two co-resident 128x256 workgroups overlap it with each other's main loop
+    // (profiles/r01_i_gemm_ceiling.txt section 3: 4-20 % faster at every token count of the step)
+    if (N <= 768 && K <= 768) cfg = MERLOT_NT_KERNEL_RING_128x256;
+    // narrow outputs (the ResNet-stem convolutions with 32..128 filters): a 256-wide tile would compute 2-8x the
+    // columns that exist; these launches are HBM-bound and reach ~5 TB/s on 256x64 / 256x128 tiles
+    if (N <= 64 || (N <= 128 && K <= 512)) cfg = MERLOT_NT_KERNEL_RING_256x64;
+    else if (N <= 128) cfg = MERLOT_NT_KERNEL_RING_256x128;
+    return cfg;
 }
 
 int gemm_nt_dispatch(GemmNTArgs& a, int epilogue, int out_f32, hipStream_t s) {
+    int cfg = nt_plan(a.M, a.N, a.K);
+#ifdef MERLOT_EXPERIMENTS
     if (const char* e = getenv("MERLOT_DBG")) a.dbg = atoi(e);
-    int cfg = nt_config_override();
-    if (const char* e = getenv("MERLOT_NT_CFG_DYN")) cfg = atoi(e);     // re-read every call (experiments only)
-    if (cfg < 0) {
-        // Tile choice, from the sweeps in profiles/r01_gemm_tile_sweep.txt: the persistent 256x256 kernel (id 20) wins
-        // whenever its rounds of 256 workgroups are well filled (>= 85 % of the slots of its last round included);
-        // otherwise 128x256 tiles with two co-resident workgroups per CU (id 11) absorb the ragged tail better.
-        const int64_t tiles = (int64_t)cdiv(a.M, 256) * cdiv(a.N, 256);
-        const int64_t rounds = (tiles + 255) / 256;
-        static const int persist_id = [] {
-            const char* e = getenv("MERLOT_NT_PERSIST_ID");            // 20 static striding / 21 dynamic claims
-            return e ? atoi(e) : 21;
-        }();
-        cfg = (tiles * 100 >= rounds * 256 * 85) ? persist_id : 11;
-        // short K loop behind a three-tile-wide output (attention out-projection and its dgrad, 768 x 768): the epilogue
-        // is a large share of the launch and two co-resident 128x256 workgroups overlap it with each other's main loop
-        // (profiles/r01_i_gemm_ceiling.txt section 3: 4-20 % faster at every token count of the step)
-        if (a.N <= 768 && a.K <= 768) cfg = 11;
-        // narrow outputs (the ResNet-stem convolutions with 32..128 filters): a 256-wide tile would compute 2-8x the
-        // columns that exist; these launches are HBM-bound and reach ~5 TB/s on 256x64 / 256x128 tiles
-        // (scripts/exp_stem_gemm.py)
-        if (a.N <= 64 || (a.N <= 128 && a.K <= 512)) cfg = 14;
-        else if (a.N <= 128) cfg = 15;
-    }
+    if (const char* e = getenv("MERLOT_NT_CFG_DYN")) cfg = atoi(e);
+#endif
     switch (cfg) {
+        case MERLOT_NT_KERNEL_RING_128x256: return launch_ring<RingK>(a, epilogue, out_f32, s);
+        case MERLOT_NT_KERNEL_RING_256x64: return launch_ring<RingN64>(a, epilogue, out_f32, s);
+        case MERLOT_NT_KERNEL_RING_256x128: return launch_ring<RingN128>(a, epilogue, out_f32, s);
+        case MERLOT_NT_KERNEL_PERSIST_STATIC: return launch_persist(a, epilogue, out_f32, 0, s);
+        case MERLOT_NT_KERNEL_PERSIST_DYN: return launch_persist(a, epilogue, out_f32, 1, s);
+#ifdef MERLOT_EXPERIMENTS
         case 3: return launch_ring<RingC>(a, epilogue, out_f32, s);
-        case 11: return launch_ring<RingK>(a, epilogue, out_f32, s);
-        case 14: return launch_ring<RingN64>(a, epilogue, out_f32, s);
-        case 15: return launch_ring<RingN128>(a, epilogue, out_f32, s);
-        case 20: return launch_persist(a, epilogue, out_f32, 0, s);
-        case 21: return launch_persist(a, epilogue, out_f32, a.K / RingP::BK >= 4 ? 1 : 0, s);
+#endif
         default: break;
     }
+#ifndef MERLOT_EXPERIMENTS
+    merlot_set_error("merlot_gemm_bf16_nt: no kernel for plan %d", cfg);
+    return MERLOT_ESHAPE;
+#else
     a.ntm = cdiv(a.M, BM);
     a.ntn = cdiv(a.N, BN);
     switch (epilogue) {
@@ -1550,6 +1551,7 @@ int gemm_nt_dispatch(GemmNTArgs& a, int epilogue, int out_f32, hipStream_t s) {
     }
     merlot_set_error("merlot_gemm_bf16_nt: unknown epilogue %d", epilogue);
     return MERLOT_ESHAPE;
+#endif
 }
 
 int tn_launch(GemmTNArgs& a, int accumulate, hipStream_t s) {
@@ -1578,7 +1580,9 @@ using TnRingC = ring::Cfg<4, 2, 2, 4, 32, 4>;   // 256x256, BK 32, 4 stages, 8 w
 using TnRingK = ring::Cfg<2, 4, 2, 2, 32, 3>;   // 128x256, BK 32, 3 stages, 8 waves, 2 workgroups / CU
 
 int tn_config() {
-    if (const char* e = getenv("MERLOT_TN_CFG")) return atoi(e);      // experiments only
+#ifdef MERLOT_EXPERIMENTS
+    if (const char* e = getenv("MERLOT_TN_CFG")) return atoi(e);
+#endif
     return 1;                                            // 128x256, 2 WG/CU: +5-7 % over 256x256 on the wgrad shapes
 }
 
@@ -1598,10 +1602,12 @@ TnPlan tn_plan(int64_t M, int64_t N, int64_t R) {
     int splits = slots / tiles;                          // one round of resident workgroups
     if (splits < 1) splits = 1;
     if (splits > ksteps / 8) splits = ksteps / 8 > 0 ? ksteps / 8 : 1;
-    if (const char* env = getenv("MERLOT_TN_SPLITS")) {   // tuning / experiments only
+#ifdef MERLOT_EXPERIMENTS
+    if (const char* env = getenv("MERLOT_TN_SPLITS")) {
         const int v = atoi(env);
         if (v > 0) splits = v > ksteps ? ksteps : v;
     }
+#endif
     pl.chunk = (ksteps + splits - 1) / splits;
     pl.splits = (ksteps + pl.chunk - 1) / pl.chunk;
     return pl;
@@ -1625,7 +1631,9 @@ int tn_ring_launch(GemmTNArgs& a, int accumulate, float* ws, int64_t ws_bytes, h
     const TnPlan pl = tn_plan(a.M, a.N, a.R);
     a.ntm = pl.ntm; a.ntn = pl.ntn; a.splits = pl.splits; a.rchunk = pl.chunk;
     a.use_atomics = accumulate;                          // meaning here: accumulate into C when splits == 1
+#ifdef MERLOT_EXPERIMENTS
     if (const char* e = getenv("MERLOT_DBG")) a.dbg = atoi(e);
+#endif
     if (pl.splits > 1) {
         const int64_t need = (int64_t)pl.splits * a.M * a.N * 4;
         MERLOT_CHECK(ws != nullptr && ws_bytes >= need, MERLOT_ESHAPE,
@@ -1697,6 +1705,11 @@ extern "C" int merlot_gemm_bf16_nt(const void* A, int64_t lda, const void* Bt, i
     return gemm_nt_dispatch(a, epilogue, out_f32, (hipStream_t)stream);
 }
 
+extern "C" int merlot_gemm_bf16_nt_plan(int64_t M, int64_t N, int64_t K) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % BK != 0) return -1;
+    return nt_plan(M, N, K);
+}
+
 extern "C" int64_t merlot_gemm_bf16_tn_workspace_bytes(int64_t M, int64_t N, int64_t R) {
     if (M <= 0 || N <= 0 || R < 8 * TnRingC::BK) return 0;
     const TnPlan pl = tn_plan(M, N, R / TnRingC::BK * TnRingC::BK);
@@ -1742,6 +1755,7 @@ extern "C" int merlot_patch_embed_wgrad(const void* patches, int64_t rows, int K
     return merlot_gemm_bf16_tn(dY, hidden, patches, K, dWt, K, hidden, K, rows, 1.f, accumulate, workspace, workspace_bytes, stream);
 }
 
+#ifdef MERLOT_EXPERIMENTS
 extern "C" int merlot_probe_persist_trace(void* dst, int64_t bytes, merlot_stream_t stream) {
     MERLOT_CHECK(dst && bytes > 0 && bytes <= (int64_t)sizeof(long long) * 256 * TRACE_TILES * 4, MERLOT_ESHAPE,
                  "merlot_probe_persist_trace: bad size");
@@ -1750,3 +1764,4 @@ extern "C" int merlot_probe_persist_trace(void* dst, int64_t bytes, merlot_strea
     MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipMemcpyFromSymbolAsync: %s", hipGetErrorString(e));
     return MERLOT_OK;
 }
+#endif

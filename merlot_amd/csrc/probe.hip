@@ -2,6 +2,7 @@
 // tests can pin the lane maps the production kernels assume (MFMA operand/accumulator layout; LDS
 // transpose-read gather pattern).
 #include "common.h"
+#include "../../include/merlot_probe.h"
 
 namespace {
 __global__ void probe_mfma32_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, float* __restrict__ d) {

@@ -45,18 +45,23 @@ def parse_header(path=HEADER):
 
 
 class _Lib(object):
-    def __init__(self):
+    """One shared library + the header that declares it.  The product uses exactly one instance, `LIB`
+    (libmerlot_hip.so / include/merlot_hip.h); tests and scripts make another for libmerlot_probe.so."""
+
+    def __init__(self, header=HEADER, path=None):
         self._dll = None
-        self.protos = parse_header()
+        self.path = path
+        self.protos = parse_header(header)
 
     def load(self):
         if self._dll is not None:
             return self._dll
-        if not os.path.exists(LIB_PATH):
+        path = self.path or LIB_PATH
+        if not os.path.exists(path):
             raise MerlotHipError(
-                f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+                f"{path} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
                 f"g.build()'` (or merlot_amd/csrc/build.sh). There is no CPU fallback for the product path.")
-        dll = ctypes.CDLL(LIB_PATH)
+        dll = ctypes.CDLL(path)
         for name, (ret, args) in self.protos.items():
             fn = getattr(dll, name)
             fn.restype = {'int': ctypes.c_int, 'int64_t': ctypes.c_int64}.get(ret, ctypes.c_char_p)

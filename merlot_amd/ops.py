@@ -405,18 +405,6 @@ def avgpool2_bwd(dy):
     return dx
 
 
-def probe_mfma32(a, b):
-    d = torch.empty((64, 16), device=a.device, dtype=F32)
-    call('merlot_probe_mfma32', _p(a), _p(b), _p(d), _stream())
-    return d
-
-
-def probe_tr16(tile):
-    out = torch.empty_like(tile)
-    call('merlot_probe_tr16', _p(tile), _p(out), _stream())
-    return out
-
-
 # ---- input pipeline: frame preprocessing --------------------------------------------------------------
 def image_frames(src, jobs_host, jobs_dev, n_img, out_h, out_w):
     """decoded frames (uint8, device, concatenated) + job table -> bf16 [n_img, out_h, out_w, 3] (csrc/image.hip)."""

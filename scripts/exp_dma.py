@@ -3,6 +3,7 @@ normal | no loads (4) | L1-resident source (1024) | whole-cache-line pieces, eac
 The three experiment switches lived in `stage_next` of gemm_nt_persist_dyn_kernel for the measurement of
 profiles/r01_i_gemm_ceiling.txt section 2 and were REMOVED afterwards (their address arithmetic cost the production
 loop 3-6 %); re-apply them from the commit "GEMM: half-step skewed main loop..." to re-run this script."""
+import _exp_lib  # noqa: F401  (experiments build of the library + probes)
 import os
 import sys
 import torch

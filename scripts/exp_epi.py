@@ -1,5 +1,6 @@
 """Cost of each NT epilogue relative to the bare main loop (MERLOT_DBG=1 skips the epilogue).
 gpurun: python scripts/exp_epi.py"""
+import _exp_lib  # noqa: F401  (experiments build of the library + probes)
 import os
 import sys
 import torch

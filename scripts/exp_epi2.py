@@ -1,4 +1,5 @@
 """NT GEMM configs (21 persistent-dynamic 256x256, 11 = 128x256 2 WG/CU, 3 = 256x256 1 WG/CU) per epilogue type."""
+import _exp_lib  # noqa: F401  (experiments build of the library + probes)
 import os
 import sys
 import torch

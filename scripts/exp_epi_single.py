@@ -1,4 +1,5 @@
 """Epilogue time of ONE tile per CU with the rest of the chip idle (12 or 256 workgroups, one tile each)."""
+import _exp_lib  # noqa: F401  (experiments build of the library + probes)
 import os
 import sys
 import torch

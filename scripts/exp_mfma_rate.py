@@ -1,5 +1,6 @@
 """Matrix-pipe ceiling under the 256x256 GEMM's K-step instruction mix (merlot_probe_mfma_rate): what pure MFMA issue
 reaches on this box, and what the fragment reads / the per-K-step barrier cost on top -- no global memory traffic."""
+import _exp_lib  # noqa: F401  (experiments build of the library + probes)
 import os
 import sys
 import torch
@@ -14,11 +15,11 @@ for blocks in (256, 512):
                        (2, '+ s_barrier / K-step'), (7, '+ reads feeding the MFMAs + s_barrier')]:
         out = torch.zeros((blocks, 4), dtype=torch.int64, device=dev)
         for _ in range(2):
-            LIB.call('merlot_probe_mfma_rate', blocks, iters, mode, out.data_ptr(), sink.data_ptr(), None)
+            _exp_lib.PROBE.call('merlot_probe_mfma_rate', blocks, iters, mode, out.data_ptr(), sink.data_ptr(), None)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        LIB.call('merlot_probe_mfma_rate', blocks, iters, mode, out.data_ptr(), sink.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        _exp_lib.PROBE.call('merlot_probe_mfma_rate', blocks, iters, mode, out.data_ptr(), sink.data_ptr(), torch.cuda.current_stream().cuda_stream)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1)

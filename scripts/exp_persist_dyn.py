@@ -1,5 +1,6 @@
 """Static vs dynamic tile claims of the persistent NT GEMM, alone and beside a kernel that keeps N CUs' LDS busy
 (stand-in for an RCCL all-reduce overlapping the backward).  gpurun: python scripts/exp_persist_dyn.py"""
+import _exp_lib  # noqa: F401  (experiments build of the library + probes)
 import os
 import sys
 import ctypes
@@ -26,7 +27,7 @@ def run(a, b, bias, cfg, hog_blocks, iters=20):
     if hog_blocks:
         # ~ (iters * 0.6 ms) of hogging at ~2 GHz
         with torch.cuda.stream(side):
-            LIB.call('merlot_probe_cu_hog', hog_blocks, 96 * 1024, ctypes.c_int64(int(iters * 3e6)),
+            _exp_lib.PROBE.call('merlot_probe_cu_hog', hog_blocks, 96 * 1024, ctypes.c_int64(int(iters * 3e6)),
                      sink.data_ptr(), side.cuda_stream)
         torch.cuda._sleep(200000)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -2,6 +2,7 @@
 step's big shapes, mirrored order after a warm-up; results must agree bit for bit (same MFMA order per accumulator).
 Used for the id 21 vs id 22 (half-step skewed loop, since removed) and 256x256 vs 128x256 comparisons of
 profiles/r01_i_gemm_ceiling.txt."""
+import _exp_lib  # noqa: F401  (experiments build of the library + probes)
 import os
 import sys
 import torch

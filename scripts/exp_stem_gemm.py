@@ -1,4 +1,5 @@
 """NT GEMM shapes of the ResNet-hybrid stem at 512 frames: which tile config serves narrow outputs."""
+import _exp_lib  # noqa: F401  (experiments build of the library + probes)
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from merlot_amd import ops

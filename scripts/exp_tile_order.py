@@ -1,5 +1,6 @@
 """A/B of the persistent NT kernel's tile enumeration: row-major (MERLOT_NT_TILE_CG_DYN=0) vs column groups of 6 tile
 columns (=6), mirrored order after a warm-up, results must be bit-identical (same tiles, different order)."""
+import _exp_lib  # noqa: F401  (experiments build of the library + probes)
 import os
 import sys
 import torch

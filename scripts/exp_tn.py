@@ -1,3 +1,4 @@
+import _exp_lib  # noqa: F401  (experiments build of the library + probes)
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

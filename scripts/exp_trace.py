@@ -1,4 +1,5 @@
 """Per-workgroup timeline of the persistent NT GEMM (MERLOT_DBG bit 512): when do the epilogues happen?"""
+import _exp_lib  # noqa: F401  (experiments build of the library + probes)
 import os
 import sys
 import numpy as np

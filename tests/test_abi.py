@@ -11,7 +11,7 @@ def test_header_declares_the_survey_export_list():
             'merlot_ln_fwd', 'merlot_ln_bwd', 'merlot_attention_fwd', 'merlot_attention_bwd', 'merlot_attention_colsum',
             'merlot_gather_add4', 'merlot_scatter_add_rows', 'merlot_softmax_ce', 'merlot_cls_avgpool_fwd',
             'merlot_cls_avgpool_bwd', 'merlot_adamw_step', 'merlot_mask_inputs', 'merlot_temporal_labels',
-            'merlot_shuffled_idx', 'merlot_last_error']
+            'merlot_shuffled_idx', 'merlot_last_error', 'merlot_gemm_bf16_nt_plan']
     for n in need:
         assert n in protos, n
 
@@ -22,8 +22,38 @@ def test_library_exports_every_declared_symbol():
     for name in lib.parse_header():
         assert hasattr(dll, name), f"{name} declared in include/merlot_hip.h but not exported"
     d = lib.LIB.load()
-    assert d.merlot_abi_version() == 1
+    assert d.merlot_abi_version() == 2
     assert d.merlot_last_error() is not None
+
+
+def test_product_library_carries_no_experiment_hooks():
+    """the benchmarked library must not be steerable from the environment and must not export
+    diagnostics.  The experiment switches live behind -DMERLOT_EXPERIMENTS (libmerlot_hip_exp.so, scripts/ only) and
+    the probes in libmerlot_probe.so."""
+    dll = ctypes.CDLL(lib.LIB_PATH)
+    for name in ('merlot_probe_mfma32', 'merlot_probe_tr16', 'merlot_probe_cu_hog', 'merlot_probe_mfma_rate',
+                 'merlot_probe_persist_trace'):
+        assert not hasattr(dll, name), f"{name} exported from the product library"
+    blob = open(lib.LIB_PATH, 'rb').read()
+    for knob in (b'MERLOT_DBG', b'MERLOT_NT_CFG', b'MERLOT_NT_TILE_CG', b'MERLOT_NT_PERSIST_ID', b'MERLOT_TN_CFG',
+                 b'MERLOT_TN_SPLITS'):
+        assert knob not in blob, f"environment knob {knob.decode()} compiled into the product library"
+    probe_path = os.path.join(os.path.dirname(lib.LIB_PATH), 'libmerlot_probe.so')
+    assert os.path.exists(probe_path)
+    pdll = ctypes.CDLL(probe_path)
+    hdr = os.path.join(os.path.dirname(os.path.dirname(lib.LIB_PATH)), 'include', 'merlot_probe.h')
+    for name in lib.parse_header(hdr):
+        assert hasattr(pdll, name), f"{name} declared in include/merlot_probe.h but not exported"
+
+
+def test_nt_plan_is_a_pure_function_of_the_shape():
+    d = lib.LIB.load()
+    assert d.merlot_gemm_bf16_nt_plan(101376, 2304, 768) == 21        # ViT QKV at the bench batch: persistent, dynamic
+    assert d.merlot_gemm_bf16_nt_plan(101376, 768, 3072) == 21        # fc2
+    assert d.merlot_gemm_bf16_nt_plan(101376, 768, 768) == 11         # out-projection: 128x256 ring, 2 WG / CU
+    assert d.merlot_gemm_bf16_nt_plan(4000, 768, 768) == 11
+    assert d.merlot_gemm_bf16_nt_plan(50176, 64, 576) == 14
+    assert d.merlot_gemm_bf16_nt_plan(128, 128, 100) == -1            # K % 64 != 0 is rejected by the entry point
 
 
 def test_argument_validation_happens_before_any_launch():

@@ -87,3 +87,21 @@ def test_temporal_labels_and_shuffled_idx():
         labels, w = ops.temporal_labels(t(vs), t(ref), B, n)
         assert np.array_equal(labels.cpu().numpy(), ix.allpairs_temporal_labels(vs, n))
         assert np.array_equal(w.cpu().numpy(), ix.temporal_label_weights(ref, n))
+
+
+def test_shuffled_idx_kernel_matches_the_reference_run():
+    """`merlot_shuffled_idx` against what model/dataloader.py:224-257 itself produced under the TF shim
+    (tests/golden/ref_shim_shuffle.npz, tests/golden/make_shuffle_golden.py) -- not only against the restatement."""
+    from merlot_amd import ops
+    fx = np.load(os.path.join(G, 'ref_shim_shuffle.npz'))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    checked = 0
+    for i in range(int(fx['shuffle/count'])):
+        pre = f'shuffle/{i}/'
+        if pre + 'num_shuffle' not in fx.files:
+            continue                                   # image_shuffle_prob < 1e-6: host-side arange, no kernel (:233-235)
+        n, B = int(fx[pre + 'n']), int(fx[pre + 'B'])
+        got = ops.shuffled_idx(t(fx[pre + 'num_shuffle']), t(fx[pre + 'u_select']), t(fx[pre + 'u_perm']), B, n, 16)
+        assert np.array_equal(got.cpu().numpy(), fx[pre + 'out']), i
+        checked += 1
+    assert checked >= 6

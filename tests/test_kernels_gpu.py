@@ -40,7 +40,8 @@ def test_probe_mfma32_layout(ops):
     lanes = torch.arange(64)
     a = torch.stack([A[lanes & 31, 8 * (lanes >> 5) + j] for j in range(8)], 1).to(BF16)     # A[l&31][8(l>>5)+j]
     b = torch.stack([Bm[8 * (lanes >> 5) + j, lanes & 31] for j in range(8)], 1).to(BF16)    # B[8(l>>5)+j][l&31]
-    d = ops.probe_mfma32(a.cuda().contiguous(), b.cuda().contiguous()).cpu()
+    import probe_lib
+    d = probe_lib.probe_mfma32(a.cuda().contiguous(), b.cuda().contiguous()).cpu()
     ref = A @ Bm
     got = torch.zeros(32, 32)
     for l in range(64):
@@ -51,7 +52,8 @@ def test_probe_mfma32_layout(ops):
 
 def test_probe_tr16_layout(ops):
     tile = torch.arange(256).to(BF16)          # 0..255 exactly representable
-    out = ops.probe_tr16(tile.cuda()).cpu().float().reshape(64, 4)
+    import probe_lib
+    out = probe_lib.probe_tr16(tile.cuda()).cpu().float().reshape(64, 4)
     exp = torch.zeros(64, 4)
     for l in range(64):
         gi, i = l >> 4, l & 15
