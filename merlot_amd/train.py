@@ -75,15 +75,23 @@ class Trainer(object):
                                                    self.opt)
         return self.step_idx
 
+    def step_seed(self):
+        """seed of this step's dropout masks and MLM masking noise on THIS replica.  TPU replicas draw independent
+        randomness (every replica runs its own `tf.random` ops), so the rank is folded in: distinct for every
+        (step, rank) pair.  Parameter initialisation (`ParamStore(seed=...)`) stays rank-independent."""
+        world = self.dist.world_size if self.dist is not None else 1
+        rank = self.dist.rank if self.dist is not None else 0
+        return (self.step_idx + 1) * world + rank
+
     def forward_only(self, features):
         """one forward pass (ViT, text-only, masking, joint, the three losses) with the training graph's ops but no
         tape: the `fwd-only` figure SURVEY.md 8(d) asks for next to the training step."""
         with torch.no_grad():
-            return self.model_fn(features, None, 'train', {'store': self.store, 'dist': self.dist, 'seed': self.step_idx + 1})
+            return self.model_fn(features, None, 'train', {'store': self.store, 'dist': self.dist, 'seed': self.step_seed()})
 
     def step(self, features):
         self.store.zero_grad()
-        out = self.model_fn(features, None, 'train', {'store': self.store, 'dist': self.dist, 'seed': self.step_idx + 1})
+        out = self.model_fn(features, None, 'train', {'store': self.store, 'dist': self.dist, 'seed': self.step_seed()})
         out['loss'].backward()
         if self.opt.clip_norm > 0.0:                         # clip the local gradients, then sum across replicas
             out['grad_norm'] = self.opt.clip_local_gradients()

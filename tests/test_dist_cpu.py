@@ -153,7 +153,15 @@ def _train_worker(rank, world, port, tmp):
                       'weight_decay_rate': 0.1, 'beta_2': 0.98, 'use_bfloat16_adam': True},
         'device': {'output_dir': os.path.join(tmp, 'out'), 'train_batch_size': 4, 'iterations_per_loop': 2}})
     t = T.train(config, 'cpu', DistContext(), max_steps=2, log_every=0)
-    torch.save({'master': t.store.master.clone(), 'step': t.step_idx}, os.path.join(tmp, f'rank{rank}.pt'))
+    seeds = []
+    for k in range(3):                                        # the seeds the next three steps would use on this rank
+        seeds.append(t.step_seed())
+        t.step_idx += 1
+    t.step_idx -= 3
+    from merlot_amd.modeling import draw_mask_noise
+    gum = draw_mask_noise(2, 128, config.model, 2048, torch.Generator().manual_seed(seeds[0] * 7919 + 17))['gumbel']
+    torch.save({'master': t.store.master.clone(), 'step': t.step_idx, 'seeds': seeds, 'gumbel': gum},
+               os.path.join(tmp, f'rank{rank}.pt'))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -171,5 +179,7 @@ def test_train_loop_two_replicas(tmp_path):
     r0, r1 = torch.load(str(tmp_path / 'rank0.pt')), torch.load(str(tmp_path / 'rank1.pt'))
     assert r0['step'] == r1['step'] == 2
     assert torch.equal(r0['master'], r1['master'])
+    # replicas must not share dropout masks / masking noise -- the per-step seed carries the rank
+    assert len(set(r0['seeds'] + r1['seeds'])) == 6 and not torch.equal(r0['gumbel'], r1['gumbel'])
     prefix = ck.latest_checkpoint(str(tmp_path / 'out'))
     assert prefix.endswith('model.ckpt-2') and int(ck.load_variable(prefix, 'global_step')) == 2

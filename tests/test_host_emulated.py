@@ -250,12 +250,58 @@ def test_clip_by_global_norm_matches_reference_rule():
         ref = {n: st.g(n).clone() for n in st.names()}
         norm_ref = float(np.sqrt(sum(float((v.double() ** 2).sum()) for v in ref.values())))
         opt = AdamOptimizer.__new__(AdamOptimizer)
-        opt.store, opt.clip_norm = st, clip
+        opt.store, opt.clip_norm, opt.frozen = st, clip, []
         norm = float(opt.clip_local_gradients())
         assert abs(norm - norm_ref) < 1e-4 * norm_ref
         factor = clip / max(norm_ref, clip)
         for n in st.names():
             assert torch.allclose(st.g(n), ref[n] * factor, rtol=1e-5, atol=1e-8), n
+
+
+def test_optimizer_hyperparameter_semantics_follow_the_reference(emu):
+    """ADVICE r1 (medium): utils/optimization.py defaults and overrides.  (1) clip_norm defaults to 1.0 (:57);
+    (2) `freeze_scope` is the deprecated spelling of a learning_rate-0 override (:124-127): those variables are dropped
+    before tf.gradients (:145-152) -- no update, no Adam slots touched, not part of the clipped global norm;
+    (3) per-parameter beta_1 / beta_2 / epsilon overrides reach the update (:340-345), incl. the bias correction."""
+    from merlot_amd import ParamStore
+    from merlot_amd.optimization import AdamOptimizer, build_optimizer_from_config, learning_rate_scale
+    cfg = tiny_config()
+    st = ParamStore(cfg, 'cpu', seed=0)
+    opt = build_optimizer_from_config(st, {'type': 'adam_optimizer', 'learning_rate': 1e-3, 'num_train_steps': 100,
+                                           'num_warmup_steps': 10})
+    assert opt.clip_norm == 1.0 and opt.eps == 1e-6 and opt.b2 == 0.98 and opt.b1 == 0.9
+    with pytest.raises(ValueError, match="isn't a changable optimization parameter"):
+        AdamOptimizer(st, 1e-3, 100, 10, param_overrides=[[['nothing_matches_this'], {'momentum': 0.5}]])
+
+    over = [[['LayerNorm', 'bias'], {'weight_decay_rate': 0}], [['^lm_head/'], {'beta_2': 0.5, 'epsilon': 1e-3, 'beta_1': 0.8}]]
+    opt = AdamOptimizer(st, 1e-3, 100, 10, weight_decay_rate=0.1, param_overrides=over, freeze_scope='contrastive',
+                        clip_norm=2.0)
+    assert not opt.single_launch
+    g = torch.Generator().manual_seed(1)
+    st.grad.copy_(torch.randn(st.grad.shape, generator=g) * 1e-3)
+    for name, (off, n, _) in st.offsets.items():                     # arena padding carries no gradient
+        st.grad[off + n:off + (n + 63) // 64 * 64] = 0
+    before = st.master.clone()
+    frozen_names = [n for n in st.names() if n.startswith('contrastive')]
+    live = torch.cat([st.g(n).reshape(-1) for n in st.names() if not n.startswith('contrastive')])
+    norm = float(opt.clip_local_gradients())
+    assert abs(norm - float(live.double().norm())) < 1e-6 * norm          # frozen gradients are not in the norm
+    opt.step_count = 3                                                    # warm-up: scale = 3 / 10
+    grads = {n: st.g(n).clone() for n in st.names()}
+    opt.step()
+    scale = learning_rate_scale(3, 100, 10)
+    assert scale == 0.3
+    for n in frozen_names:
+        assert torch.equal(st.p(n), st.view(before, n)) and float(st.view(opt.m, n).abs().sum()) == 0.0
+    for n, (b1, b2, eps, wd) in {'lm_head/projection/kernel': (0.8, 0.5, 1e-3, 0.1), 'lm_head/projection/bias': (0.8, 0.5, 1e-3, 0.0),
+                                 'encoder/layer00/output/kernel': (0.9, 0.98, 1e-6, 0.1),
+                                 'encoder/layer00/LayerNorm_mlp_ln0/gamma': (0.9, 0.98, 1e-6, 0.0)}.items():
+        p0, gr = st.view(before, n).double(), grads[n].double()
+        t = 4.0
+        lr = 1e-3 * scale * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+        nm, nv = (1 - b1) * gr, (1 - b2) * (gr * gr + 1e-30)
+        want = p0 - lr * (nm / (nv.sqrt() + eps) + wd * p0)
+        assert torch.allclose(st.p(n).double(), want, rtol=2e-5, atol=1e-9), n
 
 
 @pytest.mark.parametrize('name', ['unshared', 'langonly_groups', 'block_mask', 'img_mask'])
