@@ -66,6 +66,7 @@ int merlot_gemm_bf16_nt(const void* A, int64_t lda, const void* Bt, int64_t ldb,
 #define MERLOT_NT_KERNEL_RING_256x128 15    /* gemm_nt_ring_kernel<Cfg<4,1,2,4,32,3>>                               */
 #define MERLOT_NT_KERNEL_PERSIST_STATIC 20  /* gemm_nt_persist_kernel: persistent 256x256, static tile striding      */
 #define MERLOT_NT_KERNEL_PERSIST_DYN 21     /* gemm_nt_persist_dyn_kernel: persistent 256x256, dynamic tile claims   */
+#define MERLOT_NT_KERNEL_P8 22              /* gemm_nt_p8_kernel: persistent 256x256, BK 64, two wave groups in ping-pong */
 int merlot_gemm_bf16_nt_plan(int64_t M, int64_t N, int64_t K);
 
 /* Weight gradient: C[M,N] (f32) (+)= alpha * sum_r A[r,M] * B[r,N].  A, B bf16 row-major with the

@@ -17,6 +17,7 @@
 // `s_waitcnt vmcnt(N)` + raw `s_barrier`, XCD-aware block -> tile maps, row-contiguous epilogues staged through LDS.
 #include <atomic>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "gemm_ring.h"
@@ -779,16 +780,18 @@ __device__ __forceinline__ void slab_epilogue(const GemmNTArgs& p, const f32x16&
 // cost as much as the whole K=768 main loop was LATENCY: `bias` was re-loaded after every store (may alias C) and
 // each residual / pre-activation row segment was loaded right where it was consumed, 16 dependent round trips per
 // wave per tile.  Here bias is read once per tile and the auxiliary operand runs PF passes (1 KiB each) ahead.
-template <int EPI, bool OUT_F32>
-__device__ __forceinline__ void fast_tile_epilogue(const GemmNTArgs& p, f32x16 (&acc)[2][4], char* slab, int m_base,
+template <int EPI, bool OUT_F32, int FM = 2, int FN = 4, int PF = 8>
+__device__ __forceinline__ void fast_tile_epilogue(const GemmNTArgs& p, f32x16 (&acc)[FM][FN], char* slab, int m_base,
                                                    int n_base, int lane) {
+    static_assert(FM * FN == 8, "a wave owns 8 accumulators = 4 slabs of 32 x 64");
+    constexpr int NFP = FN / 2;                          // 64-column slabs per 32-row block
     constexpr bool HAS_AUX = (EPI == MERLOT_EPI_RESIDUAL) || (EPI == MERLOT_EPI_DGELU);
-    constexpr int PF = 8;                                // aux prefetch distance in passes (4 VGPRs each)
+    // PF = aux prefetch distance in passes (4 VGPRs each)
     const int hi = lane >> 5, row = lane & 31;
     const int rr = lane >> 3, c0 = (lane & 7) * 8, ch = 2 * (lane & 7);
-    f32x4 bias_r[2][2];
+    f32x4 bias_r[NFP][2];
 #pragma unroll
-    for (int fp = 0; fp < 2; ++fp) {
+    for (int fp = 0; fp < NFP; ++fp) {
         if (p.bias) {
             bias_r[fp][0] = *reinterpret_cast<const f32x4*>(p.bias + n_base + fp * 64 + c0);
             bias_r[fp][1] = *reinterpret_cast<const f32x4*>(p.bias + n_base + fp * 64 + c0 + 4);
@@ -797,10 +800,10 @@ __device__ __forceinline__ void fast_tile_epilogue(const GemmNTArgs& p, f32x16 (
             for (int e = 0; e < 4; ++e) bias_r[fp][0][e] = bias_r[fp][1][e] = 0.f;
         }
     }
-    // pass q = slab * 4 + ps, slab = fi * 2 + fp: rows m_base + fi*32 + ps*8 + rr, columns n_base + fp*64 + c0 .. +7
+    // pass q = slab * 4 + ps, slab = fi * NFP + fp: rows m_base + fi*32 + ps*8 + rr, columns n_base + fp*64 + c0 .. +7
     auto aux_addr = [&](int q) {
         const int sl = q >> 2, ps = q & 3;
-        return p.aux_in + (int64_t)(m_base + (sl >> 1) * 32 + ps * 8 + rr) * p.ld_aux_in + (n_base + (sl & 1) * 64 + c0);
+        return p.aux_in + (int64_t)(m_base + (sl / NFP) * 32 + ps * 8 + rr) * p.ld_aux_in + (n_base + (sl % NFP) * 64 + c0);
     };
     bf16x8 aux[PF];
     if (HAS_AUX) {
@@ -810,7 +813,7 @@ __device__ __forceinline__ void fast_tile_epilogue(const GemmNTArgs& p, f32x16 (
     }
 #pragma unroll
     for (int sl = 0; sl < 4; ++sl) {
-        const int fi = sl >> 1, fp = sl & 1;
+        const int fi = sl / NFP, fp = sl % NFP;
 #pragma unroll
         for (int fj = 0; fj < 2; ++fj)
 #pragma unroll
@@ -1054,6 +1057,7 @@ __device__ long long g_persist_trace[256 * TRACE_TILES * 4];
 #define PERSIST_TRACE(i, j, v) ((void)0)
 #endif
 __device__ unsigned int g_persist_ctr[PERSIST_SLOTS * 16];   // [slot][0..7] claims per XCD, [slot][8] departures
+std::atomic<unsigned int> g_persist_seq{0};                  // host side: next counter slot (shared by both persistent kernels)
 
 template <int EPI, bool OUT_F32>
 __global__ __launch_bounds__(512) void gemm_nt_persist_dyn_kernel(const GemmNTArgs p, const int ctr_slot) {
@@ -1471,8 +1475,8 @@ int launch_persist_dyn_one(GemmNTArgs& a, hipStream_t s) {
 #endif
     int grid = a.ntm * a.ntn;
     if (grid > 256) grid = 256;
-    static std::atomic<unsigned int> seq{0};             // counter slots are handed out round-robin; a slot is free
-    const int slot = (int)(seq.fetch_add(1) % PERSIST_SLOTS);   // again long before 1024 later launches are issued
+    const int slot = (int)(g_persist_seq.fetch_add(1) % PERSIST_SLOTS);   // counter slots are handed out round-robin; a slot is
+                                                                          // free again long before 1024 later launches are issued
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), PERSIST_LDS, s, a, slot);
     return merlot_launch_status("merlot_gemm_bf16_nt(persistent, dynamic)");
 }
@@ -1500,6 +1504,8 @@ using RingK = ring::Cfg<2, 4, 2, 2, 32, 3>;   // 128x256, BK 32, 3 stages, 72 KB
 using RingN64 = ring::Cfg<4, 1, 2, 2, 32, 3>;   // 256x64,  4 waves, 60 KB: narrow outputs (ResNet-stem 1x1 / 3x3 with 32..64 filters)
 using RingN128 = ring::Cfg<4, 1, 2, 4, 32, 3>;  // 256x128, 4 waves, 72 KB
 
+#include "gemm_p8.inc"
+
 // Which kernel a shape runs on (also exported as merlot_gemm_bf16_nt_plan so tests can assert it).  From the sweeps in
 // profiles/r01_gemm_tile_sweep.txt: the persistent 256x256 kernel wins whenever its rounds of 256 workgroups are well
 // filled (>= 85 % of the slots of its last round included); otherwise 128x256 tiles with two co-resident workgroups
@@ -1507,8 +1513,10 @@ using RingN128 = ring::Cfg<4, 1, 2, 4, 32, 3>;  // 256x128, 4 waves, 72 KB
 int nt_plan(int64_t M, int64_t N, int64_t K) {
     const int64_t tiles = (int64_t)cdiv(M, 256) * cdiv(N, 256);
     const int64_t rounds = (tiles + 255) / 256;
-    int cfg = (tiles * 100 >= rounds * 256 * 85) ? MERLOT_NT_KERNEL_PERSIST_DYN : MERLOT_NT_KERNEL_RING_128x256;
-    if (cfg == MERLOT_NT_KERNEL_PERSIST_DYN && K / RingP::BK < 4) cfg = MERLOT_NT_KERNEL_PERSIST_STATIC;
+    // well-filled rounds of 256 workgroups: the ping-pong persistent kernel (K-tiles of 64, at least 2 per tile; round 2:
+    // +5..13 % over the lock-step persistent kernel on every shape of the step, profiles/r02_p8_ab.txt)
+    int cfg = (tiles * 100 >= rounds * 256 * 85) ? MERLOT_NT_KERNEL_P8 : MERLOT_NT_KERNEL_RING_128x256;
+    if (cfg == MERLOT_NT_KERNEL_P8 && K < 128) cfg = MERLOT_NT_KERNEL_PERSIST_STATIC;
     // short K loop behind a three-tile-wide output (attention out-projection and its dgrad, 768 x 768): the epilogue
     // is a large share of the launch and two co-resident 128x256 workgroups overlap it with each other's main loop
     // (profiles/r01_i_gemm_ceiling.txt section 3: 4-20 % faster at every token count of the step)
@@ -1526,12 +1534,14 @@ int gemm_nt_dispatch(GemmNTArgs& a, int epilogue, int out_f32, hipStream_t s) {
     if (const char* e = getenv("MERLOT_DBG")) a.dbg = atoi(e);
     if (const char* e = getenv("MERLOT_NT_CFG_DYN")) cfg = atoi(e);
 #endif
+    if (cfg == MERLOT_NT_KERNEL_P8 && !p8_ok(a)) cfg = MERLOT_NT_KERNEL_PERSIST_DYN;   // operands beyond 2 GiB: 64-bit addressing
     switch (cfg) {
         case MERLOT_NT_KERNEL_RING_128x256: return launch_ring<RingK>(a, epilogue, out_f32, s);
         case MERLOT_NT_KERNEL_RING_256x64: return launch_ring<RingN64>(a, epilogue, out_f32, s);
         case MERLOT_NT_KERNEL_RING_256x128: return launch_ring<RingN128>(a, epilogue, out_f32, s);
         case MERLOT_NT_KERNEL_PERSIST_STATIC: return launch_persist(a, epilogue, out_f32, 0, s);
         case MERLOT_NT_KERNEL_PERSIST_DYN: return launch_persist(a, epilogue, out_f32, 1, s);
+        case MERLOT_NT_KERNEL_P8: return launch_p8(a, epilogue, out_f32, s);
 #ifdef MERLOT_EXPERIMENTS
         case 3: return launch_ring<RingC>(a, epilogue, out_f32, s);
 #endif
