@@ -119,8 +119,11 @@ int merlot_ln_bwd(const void* dy, int dy_f32, const void* x, int x_f32, const fl
 /* seg (optional, needs valid): int32 [S] segment id per position, shared by all batch rows -- the
  * `disable_pairwise_lang_attn` block mask of model/modeling.py:160-168: a pair of valid tokens is additionally masked
  * (score exactly -1e10) unless seg[q] == seg[k] or one of the two is 0. */
+/* colsum_lo / colsum_hi (optional, f32 [B,S], ACCUMULATED): the side outputs of merlot_attention_colsum below, produced by
+ * the same launch (S <= 512: from the K tile still resident in LDS; longer sequences: a second pass); needs lse. */
 int merlot_attention_fwd(const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse, const uint8_t* valid,
-                         const int32_t* seg, int B, int S, int heads, float scale, merlot_stream_t stream);
+                         const int32_t* seg, int B, int S, int heads, float scale, float* colsum_lo, float* colsum_hi,
+                         int qsplit, int valid_q_only, float weight, merlot_stream_t stream);
 /* dqkv (bf16, same layout as qkv) from dout.  delta: f32 workspace [B*heads*S]. */
 int merlot_attention_bwd(const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout, int64_t lddo,
                          const float* lse, const uint8_t* valid, const int32_t* seg, void* dqkv, int64_t lddqkv,

@@ -662,6 +662,8 @@ __global__ __launch_bounds__(64) void attn_colsum_kernel(const AttnArgs p) {
     }
 }
 
+#include "attention_res.inc"
+
 int check_attn(const void* qkv, int64_t ld, int B, int S, int heads) {
     MERLOT_CHECK(qkv != nullptr, MERLOT_ESHAPE, "attention: null qkv");
     MERLOT_CHECK(B > 0 && S > 0 && heads > 0, MERLOT_ESHAPE, "attention: bad dims B=%d S=%d heads=%d", B, S, heads);
@@ -676,18 +678,28 @@ int check_attn(const void* qkv, int64_t ld, int B, int S, int heads) {
 
 extern "C" int merlot_attention_fwd(const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse,
                                     const uint8_t* valid, const int32_t* seg, int B, int S, int heads, float scale,
+                                    float* colsum_lo, float* colsum_hi, int qsplit, int valid_q_only, float weight,
                                     merlot_stream_t stream) {
     int rc = check_attn(qkv, ld, B, S, heads);
     if (rc) return rc;
     MERLOT_CHECK(out && ldo >= heads * 64 && ldo % 4 == 0, MERLOT_ESHAPE, "attention_fwd: bad out/ldo");
     MERLOT_CHECK(!seg || valid, MERLOT_ESHAPE, "attention: a segment mask needs the validity mask too");
+    const bool want_cs = colsum_lo != nullptr || colsum_hi != nullptr;
+    MERLOT_CHECK(!want_cs || lse, MERLOT_ESHAPE, "attention_fwd: the column sums need the lse output");
     AttnArgs a{};
     a.qkv = (const bf16*)qkv; a.ld = ld; a.out = (bf16*)out; a.ldo = ldo; a.lse = lse; a.valid = valid; a.seg = seg;
     a.B = B; a.S = S; a.heads = heads; a.scale = scale;
+    a.colsum_lo = colsum_lo; a.colsum_hi = colsum_hi; a.qsplit = qsplit; a.valid_q_only = valid_q_only; a.weight = weight;
+    if (S <= RES_MAX_S) {                                // K and V of one (batch, head) resident in LDS, no per-tile barriers;
+        rc = res_fwd(a, (hipStream_t)stream);            // the column sums come from the same launch
+        return rc ? rc : merlot_launch_status("merlot_attention_fwd");
+    }
     if (valid)
         hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, (hipStream_t)stream, a);
+    if (want_cs)                                         // long sequences: the separate column-sum pass
+        hipLaunchKernelGGL(attn_colsum_kernel, dim3(cdiv(S, 32), heads, B), dim3(64), 0, (hipStream_t)stream, a);
     return merlot_launch_status("merlot_attention_fwd");
 }
 
@@ -706,6 +718,18 @@ extern "C" int merlot_attention_bwd(const void* qkv, int64_t ld, const void* out
     a.lse = (float*)lse; a.delta = delta; a.valid = valid; a.seg = seg; a.dqkv = (bf16*)dqkv; a.lddqkv = lddqkv;
     a.B = B; a.S = S; a.heads = heads; a.scale = scale;
     hipStream_t s = (hipStream_t)stream;
+    if (S <= RES_MAX_S) {                                // resident kernels; delta is produced by the dQ kernel
+        rc = res_bwd_dq(a, delta, s);
+        if (rc) return rc;
+        if (S <= RES_MAX_S_DKDV) {
+            rc = res_bwd_dkdv(a, s);
+            return rc ? rc : merlot_launch_status("merlot_attention_bwd");
+        }
+        // 256 < S <= 512: the dK/dV kernel needs more than the 128 VGPRs a 16-wave workgroup leaves: tiled kernel
+        if (valid) hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);
+        return merlot_launch_status("merlot_attention_bwd");
+    }
     hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv((int64_t)B * S, 4)), dim3(256), 0, s, a, delta);
     if (valid) {
         hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);

@@ -69,13 +69,21 @@ class TransformerStackFn(torch.autograd.Function):
             w = stack.layers[l]
             x1, _, mean1, rstd1 = ops.ln_fwd(h, w.ln1.gamma, w.ln1.beta)
             qkv = ops.gemm_nt(x1, w.qkv.wb, bias=w.qkv.b)
-            ctx_, lse = ops.attention_fwd(qkv, B, S, heads, valid, seg=seg)
-            if colsum is not None:
-                ops.attention_colsum(qkv, lse, B, S, heads, colsum, valid=valid, valid_q_only=False, weight=1.0 / heads,
-                                     seg=seg)
-            if log_lo is not None:
-                ops.attention_colsum(qkv, lse, B, S, heads, log_lo, log_hi, qsplit=opts['log_split'], valid=valid,
-                                     valid_q_only=True, weight=1.0 / heads, seg=seg)
+            # the attention-probability side outputs (a7) come out of the forward launch: K is still resident in LDS
+            if colsum is not None and log_lo is None:
+                ctx_, lse = ops.attention_fwd(qkv, B, S, heads, valid, seg=seg, colsum_lo=colsum, valid_q_only=False,
+                                              weight=1.0 / heads)
+            elif log_lo is not None and colsum is None:
+                ctx_, lse = ops.attention_fwd(qkv, B, S, heads, valid, seg=seg, colsum_lo=log_lo, colsum_hi=log_hi,
+                                              qsplit=opts['log_split'], valid_q_only=True, weight=1.0 / heads)
+            else:
+                ctx_, lse = ops.attention_fwd(qkv, B, S, heads, valid, seg=seg)
+                if colsum is not None:
+                    ops.attention_colsum(qkv, lse, B, S, heads, colsum, valid=valid, valid_q_only=False, weight=1.0 / heads,
+                                         seg=seg)
+                if log_lo is not None:
+                    ops.attention_colsum(qkv, lse, B, S, heads, log_lo, log_hi, qsplit=opts['log_split'], valid=valid,
+                                         valid_q_only=True, weight=1.0 / heads, seg=seg)
             h_mid = ops.gemm_nt(ctx_, w.proj.wb, bias=w.proj.b, epilogue=EPI_RESIDUAL, aux_in=h, dropout_p=p,
                                 dropout_seed=_site_seed(seed, l, 0))
             x2, _, mean2, rstd2 = ops.ln_fwd(h_mid, w.ln2.gamma, w.ln2.beta)

@@ -162,12 +162,15 @@ def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, dres=None, dx_dtype=None,
     return dx, (dx_drop if dx_drop is not None else dx)
 
 
-def attention_fwd(qkv, B, S, heads, valid=None, need_lse=True, seg=None):
-    _chk(qkv, BF16, 'qkv'); _chk(seg, torch.int32, 'seg')
+def attention_fwd(qkv, B, S, heads, valid=None, need_lse=True, seg=None, colsum_lo=None, colsum_hi=None, qsplit=None,
+                  valid_q_only=False, weight=1.0):
+    """colsum_lo / colsum_hi (f32 [B,S], accumulated in place): the attention_colsum side outputs from the same launch."""
+    _chk(qkv, BF16, 'qkv'); _chk(seg, torch.int32, 'seg'); _chk(colsum_lo, F32, 'colsum_lo'); _chk(colsum_hi, F32, 'colsum_hi')
     out = torch.empty((B * S, heads * 64), device=qkv.device, dtype=BF16)
     lse = torch.empty((B, heads, S), device=qkv.device, dtype=F32) if need_lse else None
     call('merlot_attention_fwd', _p(qkv), qkv.stride(0), _p(out), out.stride(0), _p(lse), _p(valid), _p(seg), B, S,
-         heads, 0.125, _stream())
+         heads, 0.125, _p(colsum_lo), _p(colsum_hi), S if qsplit is None else qsplit, 1 if valid_q_only else 0, float(weight),
+         _stream())
     return out, lse
 
 

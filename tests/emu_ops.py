@@ -130,11 +130,15 @@ def _attn_probs(qkv, B, S, heads, valid, seg=None):
     return q, k, v, s
 
 
-def attention_fwd(qkv, B, S, heads, valid=None, need_lse=True, seg=None):
+def attention_fwd(qkv, B, S, heads, valid=None, need_lse=True, seg=None, colsum_lo=None, colsum_hi=None, qsplit=None,
+                  valid_q_only=False, weight=1.0):
     q, k, v, s = _attn_probs(qkv, B, S, heads, valid, seg)
     lse = torch.logsumexp(s, -1)
     p = torch.exp(s - lse[..., None])
     o = (p.to(BF16).float() @ v).permute(0, 2, 1, 3).reshape(B * S, heads * 64)
+    if colsum_lo is not None or colsum_hi is not None:      # the fused side outputs = the stand-alone column-sum op
+        attention_colsum(qkv, lse, B, S, heads, colsum_lo, colsum_hi, qsplit=qsplit, valid=valid, valid_q_only=valid_q_only,
+                         weight=weight, seg=seg)
     return o.to(BF16), (lse if need_lse else None)
 
 

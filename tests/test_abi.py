@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for name in lib.parse_header():
         assert hasattr(dll, name), f"{name} declared in include/merlot_hip.h but not exported"
     d = lib.LIB.load()
-    assert d.merlot_abi_version() == 2
+    assert d.merlot_abi_version() == 3
     assert d.merlot_last_error() is not None
 
 
@@ -63,7 +63,7 @@ def test_argument_validation_happens_before_any_launch():
     assert rc == -1 and b'null operand' in d.merlot_last_error()
     rc = d.merlot_ln_fwd(1, 0, 1, 1, 1, None, None, None, 4, 700, 1e-5, None)
     assert rc == -1 and b'H=700' in d.merlot_last_error()
-    rc = d.merlot_attention_fwd(None, 2304, None, 768, None, None, None, 1, 4, 12, 0.125, None)
+    rc = d.merlot_attention_fwd(None, 2304, None, 768, None, None, None, 1, 4, 12, 0.125, None, None, 4, 0, 1.0, None)
     assert rc == -1
     # the frame-kernel job table is checked on its HOST copy before anything is launched
     import numpy as np

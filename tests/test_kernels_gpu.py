@@ -238,6 +238,12 @@ def test_attention_fwd_bwd(ops, B, S, heads, pad):
         assert rel_l2(dq[:, sl], dq_ref[:, sl]) < 1.5e-2, name
 
 
+@pytest.mark.parametrize("B,S,heads,pad", [(1, 578, 12, False), (1, 700, 4, True)])
+def test_attention_fwd_bwd_long_sequences_tiled_kernels(ops, B, S, heads, pad):
+    """S > 512 (config #5: Sv = 578) keeps the tiled kernels: same checks as above."""
+    test_attention_fwd_bwd(ops, B, S, heads, pad)
+
+
 def test_attention_padded_query_rows_uniform(ops):
     """utils/transformer.py:109-112: a fully masked query row attends uniformly over ALL keys (-1e10, not -inf)."""
     B, S, heads = 1, 70, 12
@@ -262,6 +268,33 @@ def test_attention_colsum(ops, B, S, pad, vq):
     ops.attention_colsum(qkv.cuda(), lse, B, S, heads, lo, hi, qsplit=split, valid=None if valid is None else valid.cuda(),
                          valid_q_only=vq, weight=1 / heads)
     assert rel_l2(lo, lo_r) < 5e-3 and rel_l2(hi, hi_r) < 5e-3
+
+
+@pytest.mark.parametrize("B,S,pad,vq", [(3, 198, False, False), (2, 128, True, False), (2, 148, True, True), (2, 328, True, True),
+                                        (1, 512, True, False), (3, 50, False, False), (1, 600, True, True), (2, 18, False, False)])
+def test_attention_fwd_fused_colsum(ops, B, S, pad, vq):
+    """the column sums / block sums produced by the FORWARD launch (S <= 512: tail of attn_fwd_res_kernel on the K tile
+    still resident in LDS; S = 600: tiled forward + the separate pass) equal the stand-alone op's, accumulate in place,
+    and leave the attention output and lse untouched."""
+    heads = 12
+    qkv, valid, g = _attn_inputs(B, S, heads, 70 + S, pad)
+    vc = None if valid is None else valid.cuda()
+    o_ref, lse_ref = E.attention_fwd(qkv, B, S, heads, valid)
+    lo_r, hi_r = torch.full((B, S), 0.5), torch.full((B, S), -0.25)
+    split = S // 3
+    E.attention_colsum(qkv, lse_ref, B, S, heads, lo_r, hi_r, qsplit=split, valid=valid, valid_q_only=vq, weight=1 / heads)
+    lo, hi = torch.full((B, S), 0.5).cuda(), torch.full((B, S), -0.25).cuda()
+    o, lse = ops.attention_fwd(qkv.cuda(), B, S, heads, vc, colsum_lo=lo, colsum_hi=hi, qsplit=split, valid_q_only=vq, weight=1 / heads)
+    assert rel_l2(lo, lo_r) < 5e-3 and rel_l2(hi, hi_r) < 5e-3
+    o2, lse2 = ops.attention_fwd(qkv.cuda(), B, S, heads, vc)
+    assert torch.equal(o, o2) and torch.equal(lse, lse2)
+    assert rel_l2(o, o_ref) < 8e-3
+    # only the low half requested (the text-only pass: every query row counts, qsplit = S)
+    lo1, lo1_r = torch.zeros(B, S).cuda(), torch.zeros(B, S)
+    E.attention_colsum(qkv, lse_ref, B, S, heads, lo1_r, None, valid=valid, valid_q_only=False, weight=1 / heads)
+    ops.attention_fwd(qkv.cuda(), B, S, heads, vc, colsum_lo=lo1, valid_q_only=False, weight=1 / heads)
+    assert rel_l2(lo1, lo1_r) < 5e-3
+    assert abs(float(lo1.sum()) - B * S) < 1e-2 * B * S                    # probabilities: every query row sums to 1
 
 
 @pytest.mark.parametrize("B,S,P,Lc", [(2, 328, 200, 32), (2, 148, 20, 32), (1, 130, 2, 16)])
@@ -289,6 +322,9 @@ def test_attention_segment_block_mask(ops, B, S, P, Lc):
         E.attention_colsum(qkv, lse_ref, B, S, heads, lo_r, hi_r, qsplit=P, valid=valid, valid_q_only=vq, weight=1 / heads, seg=seg)
         lo, hi = torch.zeros(B, S).cuda(), torch.zeros(B, S).cuda()
         ops.attention_colsum(qkv.cuda(), lse, B, S, heads, lo, hi, qsplit=P, valid=vc, valid_q_only=vq, weight=1 / heads, seg=sc)
+        assert rel_l2(lo, lo_r) < 5e-3 and rel_l2(hi, hi_r) < 5e-3, vq
+        lo, hi = torch.zeros(B, S).cuda(), torch.zeros(B, S).cuda()      # ... and fused into the forward launch
+        ops.attention_fwd(qkv.cuda(), B, S, heads, vc, seg=sc, colsum_lo=lo, colsum_hi=hi, qsplit=P, valid_q_only=vq, weight=1 / heads)
         assert rel_l2(lo, lo_r) < 5e-3 and rel_l2(hi, hi_r) < 5e-3, vq
 
 
