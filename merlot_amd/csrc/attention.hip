@@ -690,8 +690,8 @@ extern "C" int merlot_attention_fwd(const void* qkv, int64_t ld, void* out, int6
     a.qkv = (const bf16*)qkv; a.ld = ld; a.out = (bf16*)out; a.ldo = ldo; a.lse = lse; a.valid = valid; a.seg = seg;
     a.B = B; a.S = S; a.heads = heads; a.scale = scale;
     a.colsum_lo = colsum_lo; a.colsum_hi = colsum_hi; a.qsplit = qsplit; a.valid_q_only = valid_q_only; a.weight = weight;
-    if (S <= RES_MAX_S) {                                // K and V of one (batch, head) resident in LDS, no per-tile barriers;
-        rc = res_fwd(a, (hipStream_t)stream);            // the column sums come from the same launch
+    if (want_cs && S <= RES_MAX_S) {                     // K and V of one (batch, head) resident in LDS: the column sums
+        rc = res_fwd(a, (hipStream_t)stream);            // come from the same launch
         return rc ? rc : merlot_launch_status("merlot_attention_fwd");
     }
     if (valid)
@@ -718,18 +718,6 @@ extern "C" int merlot_attention_bwd(const void* qkv, int64_t ld, const void* out
     a.lse = (float*)lse; a.delta = delta; a.valid = valid; a.seg = seg; a.dqkv = (bf16*)dqkv; a.lddqkv = lddqkv;
     a.B = B; a.S = S; a.heads = heads; a.scale = scale;
     hipStream_t s = (hipStream_t)stream;
-    if (S <= RES_MAX_S) {                                // resident kernels; delta is produced by the dQ kernel
-        rc = res_bwd_dq(a, delta, s);
-        if (rc) return rc;
-        if (S <= RES_MAX_S_DKDV) {
-            rc = res_bwd_dkdv(a, s);
-            return rc ? rc : merlot_launch_status("merlot_attention_bwd");
-        }
-        // 256 < S <= 512: the dK/dV kernel needs more than the 128 VGPRs a 16-wave workgroup leaves: tiled kernel
-        if (valid) hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);
-        return merlot_launch_status("merlot_attention_bwd");
-    }
     hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv((int64_t)B * S, 4)), dim3(256), 0, s, a, delta);
     if (valid) {
         hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);

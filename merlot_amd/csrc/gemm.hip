@@ -1517,10 +1517,9 @@ int nt_plan(int64_t M, int64_t N, int64_t K) {
     // +5..13 % over the lock-step persistent kernel on every shape of the step, profiles/r02_p8_ab.txt)
     int cfg = (tiles * 100 >= rounds * 256 * 85) ? MERLOT_NT_KERNEL_P8 : MERLOT_NT_KERNEL_RING_128x256;
     if (cfg == MERLOT_NT_KERNEL_P8 && K < 128) cfg = MERLOT_NT_KERNEL_PERSIST_STATIC;
-    // short K loop behind a three-tile-wide output (attention out-projection and its dgrad, 768 x 768): the epilogue
-    // is a large share of the launch and two co-resident 128x256 workgroups overlap it with each other's main loop
-    // (profiles/r01_i_gemm_ceiling.txt section 3: 4-20 % faster at every token count of the step)
-    if (N <= 768 && K <= 768) cfg = MERLOT_NT_KERNEL_RING_128x256;
+    // (round 1 sent every [T, 768] x [768, 768] launch to the 128x256 ring kernel; the ping-pong kernel wins those too once
+    // its rounds are filled: 166 vs 200 us at T = 101376, 70 vs 78 at 41984, neutral at 16384 = 75 % of one round,
+    // which the fill rule above already routes to the ring kernel -- profiles/r02_a_p8_vs_ring_768.txt)
     // narrow outputs (the ResNet-stem convolutions with 32..128 filters): a 256-wide tile would compute 2-8x the
     // columns that exist; these launches are HBM-bound and reach ~5 TB/s on 256x64 / 256x128 tiles
     if (N <= 64 || (N <= 128 && K <= 512)) cfg = MERLOT_NT_KERNEL_RING_256x64;
@@ -1666,8 +1665,72 @@ bool tn_ring_ok(const GemmTNArgs& a) {
            (a.N % 8 == 0) && (a.ldc % 4 == 0) && (((uintptr_t)a.A | (uintptr_t)a.B | (uintptr_t)a.C) & 15) == 0;
 }
 
+// ---- TN ping-pong kernel (gemm_tn_p8_kernel): 256x256 tiles x reduction chunks = one round of workgroups
+struct TnP8Plan {
+    int ntm, ntn, splits, chunk;                         // chunk in K-tiles of 64 reduction rows
+};
+bool tn_p8_shape(int64_t M, int64_t N, int64_t R) {      // pure function of the shape (the workspace query uses it too)
+    const int64_t tiles = (int64_t)cdiv(M, 256) * cdiv(N, 256);
+    return R >= 4096 && tiles <= 256 && M >= 128 && N >= 128;
+}
+TnP8Plan tn_p8_plan(int64_t M, int64_t N, int64_t R) {
+    TnP8Plan pl;
+    pl.ntm = cdiv(M, 256);
+    pl.ntn = cdiv(N, 256);
+    const int tiles = pl.ntm * pl.ntn;
+    const int nkt = (int)(R / 64);
+    int splits = 256 / tiles;
+    if (splits > nkt / 16) splits = nkt / 16;            // >= 16 K-tiles per chunk: prologue + epilogue stay small
+    if (splits < 1) splits = 1;
+    pl.chunk = (nkt + splits - 1) / splits;
+    pl.splits = (nkt + pl.chunk - 1) / pl.chunk;
+    return pl;
+}
+int tn_p8_launch(GemmTNArgs& a, int accumulate, float* ws, int64_t ws_bytes, hipStream_t s) {
+    const TnP8Plan pl = tn_p8_plan(a.M, a.N, a.R);
+    a.ntm = pl.ntm; a.ntn = pl.ntn; a.splits = pl.splits; a.rchunk = pl.chunk;
+    a.use_atomics = accumulate;                          // meaning here: accumulate into C when splits == 1
+    if (pl.splits > 1) {
+        const int64_t need = (int64_t)pl.splits * a.M * a.N * 4;
+        MERLOT_CHECK(ws != nullptr && ws_bytes >= need, MERLOT_ESHAPE,
+                     "merlot_gemm_bf16_tn: workspace too small (%lld < %lld bytes)", (long long)ws_bytes, (long long)need);
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_p8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+        MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_p8_kernel, dim3(pl.ntm * pl.ntn * pl.splits), dim3(512), P8_LDS, s, a, ws);
+    if (pl.splits > 1) {
+        int64_t total = (int64_t)a.M * (a.N / 4);
+        int grid = (int)((total + 255) / 256);
+        if (grid > 2048) grid = 2048;
+        hipLaunchKernelGGL(tn_reduce_kernel, dim3(grid), dim3(256), 0, s, ws, pl.splits, a.C, a.ldc, a.M, a.N, accumulate);
+    }
+    return merlot_launch_status("merlot_gemm_bf16_tn(p8)");
+}
+
 int gemm_tn_dispatch(GemmTNArgs& a, int accumulate, float* ws, int64_t ws_bytes, hipStream_t s) {
     if (!tn_ring_ok(a)) return tn_launch(a, accumulate, s);
+    int tn_kernel = (tn_p8_shape(a.M, a.N, a.R / 64 * 64) && (int64_t)a.R * a.lda * 2 < (1LL << 31) &&
+                     (int64_t)a.R * a.ldb * 2 < (1LL << 31)) ? 1 : 0;
+#ifdef MERLOT_EXPERIMENTS
+    if (const char* e = getenv("MERLOT_TN_P8")) tn_kernel = atoi(e);
+#endif
+    if (tn_kernel) {
+        const int R = a.R;
+        const int r_main = R / 64 * 64;
+        GemmTNArgs m = a;
+        m.R = r_main;
+        int rc = tn_p8_launch(m, accumulate, ws, ws_bytes, s);
+        if (rc != MERLOT_OK || r_main == R) return rc;
+        GemmTNArgs t = a;                                // < 64 reduction rows left: the register-staged kernel adds them
+        t.A = a.A + (int64_t)r_main * a.lda;
+        t.B = a.B + (int64_t)r_main * a.ldb;
+        t.R = R - r_main;
+        return tn_launch(t, 1, s);
+    }
     // main part: the first floor(R/32)*32 reduction rows through the ring kernel; the (< 32 row) tail, if any,
     // through the register-staged kernel accumulating on top.
     const int R = a.R;
@@ -1722,8 +1785,15 @@ extern "C" int merlot_gemm_bf16_nt_plan(int64_t M, int64_t N, int64_t K) {
 
 extern "C" int64_t merlot_gemm_bf16_tn_workspace_bytes(int64_t M, int64_t N, int64_t R) {
     if (M <= 0 || N <= 0 || R < 8 * TnRingC::BK) return 0;
+    // the larger of what the two split plans need: which kernel runs also depends on the leading dimensions (32-bit offsets)
     const TnPlan pl = tn_plan(M, N, R / TnRingC::BK * TnRingC::BK);
-    return pl.splits > 1 ? (int64_t)pl.splits * M * N * 4 : 0;
+    int64_t need = pl.splits > 1 ? (int64_t)pl.splits * M * N * 4 : 0;
+    if (tn_p8_shape(M, N, R / 64 * 64)) {
+        const TnP8Plan p8 = tn_p8_plan(M, N, R / 64 * 64);
+        const int64_t n8 = p8.splits > 1 ? (int64_t)p8.splits * M * N * 4 : 0;
+        if (n8 > need) need = n8;
+    }
+    return need;
 }
 
 extern "C" int merlot_gemm_bf16_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,

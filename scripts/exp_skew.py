@@ -13,8 +13,9 @@ from exp_epi import bench
 dev = 'cuda'
 T = int(os.environ.get('T', 101376))
 torch.manual_seed(0)
-for name, N, K, epi in [('qkv', 2304, 768, 'none'), ('proj', 768, 768, 'residual'), ('fc1', 3072, 768, 'gelu'), ('fc2', 768, 3072, 'residual'),
-                        ('dgrad_fc1', 768, 3072, 'none'), ('dgrad_fc2', 3072, 768, 'dgelu')]:
+ROWS = os.environ.get('ROWS')
+for name, N, K, epi in [r for r in [('qkv', 2304, 768, 'none'), ('proj', 768, 768, 'residual'), ('fc1', 3072, 768, 'gelu'), ('fc2', 768, 3072, 'residual'),
+                        ('dgrad_fc1', 768, 3072, 'none'), ('dgrad_fc2', 3072, 768, 'dgelu'), ('dgrad_proj', 768, 768, 'none')] if not ROWS or r[0] in ROWS.split(',')]:
     a = torch.randn(T, K, device=dev).bfloat16()
     b = (torch.randn(N, K, device=dev) * 0.02).bfloat16()
     bias = torch.randn(N, device=dev) * 0.1

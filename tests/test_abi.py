@@ -50,7 +50,7 @@ def test_nt_plan_is_a_pure_function_of_the_shape():
     d = lib.LIB.load()
     assert d.merlot_gemm_bf16_nt_plan(101376, 2304, 768) == 22        # ViT QKV at the bench batch: persistent ping-pong
     assert d.merlot_gemm_bf16_nt_plan(101376, 768, 3072) == 22        # fc2
-    assert d.merlot_gemm_bf16_nt_plan(101376, 768, 768) == 11         # out-projection: 128x256 ring, 2 WG / CU
+    assert d.merlot_gemm_bf16_nt_plan(101376, 768, 768) == 22         # out-projection: ping-pong persistent too (round 2)
     assert d.merlot_gemm_bf16_nt_plan(4000, 768, 768) == 11
     assert d.merlot_gemm_bf16_nt_plan(50176, 64, 576) == 14
     assert d.merlot_gemm_bf16_nt_plan(128, 128, 100) == -1            # K % 64 != 0 is rejected by the entry point

@@ -286,9 +286,9 @@ def test_attention_fwd_fused_colsum(ops, B, S, pad, vq):
     lo, hi = torch.full((B, S), 0.5).cuda(), torch.full((B, S), -0.25).cuda()
     o, lse = ops.attention_fwd(qkv.cuda(), B, S, heads, vc, colsum_lo=lo, colsum_hi=hi, qsplit=split, valid_q_only=vq, weight=1 / heads)
     assert rel_l2(lo, lo_r) < 5e-3 and rel_l2(hi, hi_r) < 5e-3
-    o2, lse2 = ops.attention_fwd(qkv.cuda(), B, S, heads, vc)
-    assert torch.equal(o, o2) and torch.equal(lse, lse2)
-    assert rel_l2(o, o_ref) < 8e-3
+    o2, lse2 = ops.attention_fwd(qkv.cuda(), B, S, heads, vc)        # the plain call runs the tiled kernel (64-key tiles): same
+    assert rel_l2(o, o2) < 4e-3 and float((lse - lse2).abs().max()) < 2e-3     # values up to bf16 rounding of P and O
+    assert rel_l2(o, o_ref) < 8e-3 and float((lse.cpu() - lse_ref).abs().max()) < 2e-2
     # only the low half requested (the text-only pass: every query row counts, qsplit = S)
     lo1, lo1_r = torch.zeros(B, S).cuda(), torch.zeros(B, S)
     E.attention_colsum(qkv, lse_ref, B, S, heads, lo1_r, None, valid=valid, valid_q_only=False, weight=1 / heads)
