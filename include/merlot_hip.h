@@ -53,11 +53,15 @@ enum merlot_epilogue {
  * the same mask.  GELU / GELU' in the epilogues are the exact-erf forms of utils/model_utils.py:96-110 evaluated by
  * degree-12 polynomials (abs error 2.5e-6 / 4.2e-6, far below the bf16 rounding of C).
  * Large problems run on a persistent kernel whose tile claims use a device-side pool of self-resetting counters (the
- * only state this library keeps); concurrent launches on different streams take different slots. */
+ * only state this library keeps); concurrent launches on different streams take different slots.
+ * colsum_out (optional, f32 [N], ACCUMULATED; bf16 output only): column sums of the stored C -- the bias gradient of the
+ * layer whose output gradient this launch produces (utils/transformer.py:149-153) -- fused into the epilogue of the
+ * persistent kernel, otherwise computed by merlot_colsum_bf16 right behind the GEMM. */
 int merlot_gemm_bf16_nt(const void* A, int64_t lda, const void* Bt, int64_t ldb, void* C, int64_t ldc,
                         int64_t M, int64_t N, int64_t K, float alpha, int epilogue, int out_f32, int accumulate,
                         const float* bias, const void* aux_in, int64_t ld_aux_in, void* aux_out,
-                        int64_t ld_aux_out, float dropout_p, uint64_t dropout_seed, merlot_stream_t stream);
+                        int64_t ld_aux_out, float dropout_p, uint64_t dropout_seed, float* colsum_out,
+                        merlot_stream_t stream);
 
 /* Which kernel merlot_gemm_bf16_nt runs for a problem size (the choice depends on M, N, K only); -1 for sizes the
  * entry point rejects.  Tests use it to assert that a shape exercises the kernel they mean to check. */

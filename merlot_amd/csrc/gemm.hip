@@ -22,6 +22,9 @@
 #include "common.h"
 #include "gemm_ring.h"
 
+extern "C" int merlot_colsum_bf16(const void* x, int64_t ld, float* out, int64_t T, int64_t N, int accumulate,
+                                  merlot_stream_t stream);
+
 namespace {
 
 constexpr int BM = 128;
@@ -45,6 +48,8 @@ struct GemmNTArgs {
     float drop_scale;
     uint64_t drop_seed;
     int accumulate;
+    float* colsum;        // optional f32 [N], ACCUMULATED: column sums of the stored (bf16-rounded) C -- the bias gradient of the
+                          // layer whose output gradient this GEMM produces; only kernels that say so support it (else host fallback)
     int ntm, ntn;
     int cg;               // persistent kernel: tiles are enumerated in groups of `cg` tile columns (0: plain row-major)
     int dbg;              // experiments only: 1 = skip epilogue, 2 = skip main loop
@@ -389,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTNArgs p) {
 // pre-activation loads and the bias loads are all 16-32 B per lane and 128-512 contiguous bytes per row.
 // ------------------------------------------------------------------------------------------------
 template <int EPI, bool OUT_F32>
-__device__ __forceinline__ void epilogue_row8(const GemmNTArgs& p, int m, int n, float (&v)[8]) {
+__device__ __forceinline__ void epilogue_row8(const GemmNTArgs& p, int m, int n, float (&v)[8], float* cacc = nullptr) {
     // v = alpha * acc for columns n..n+7 of row m; n + 7 < N guaranteed, 16-B alignment guaranteed by the caller
     if DBG_BIT(p, 8) {                                     // experiments: epilogue arithmetic + staging, no memory ops
         if (v[0] == 12345.678f) *reinterpret_cast<float*>(p.C) = v[1];
@@ -464,6 +469,23 @@ __device__ __forceinline__ void epilogue_row8(const GemmNTArgs& p, int m, int n,
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
         *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + n) = o;
+        if (cacc) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cacc[e] += (float)o[e];
+        }
+    }
+}
+
+// column sums of a 64-column slab: lane (lane & 7) owns 8 columns, the 8 lanes lane >> 3 own different rows.  Fold the rows,
+// then one atomic per column from lanes 0..7.
+__device__ __forceinline__ void colsum_flush(float* colsum, int n0, int lane, float (&cacc)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float t = cacc[e];
+        t += __shfl_xor(t, 8, 64);
+        t += __shfl_xor(t, 16, 64);
+        t += __shfl_xor(t, 32, 64);
+        if (lane < 8) atomicAdd(colsum + n0 + lane * 8 + e, t);
     }
 }
 
@@ -746,6 +768,7 @@ __device__ __forceinline__ void slab_epilogue(const GemmNTArgs& p, const f32x16&
     __builtin_amdgcn_wave_barrier();
     const bool aligned = ((p.ldc & 7) == 0) && ((p.ld_aux_in & 7) == 0) && ((p.ld_aux_out & 7) == 0) &&
                          ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0);
+    float cacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
         const int r = ps * 8 + (lane >> 3);
@@ -762,7 +785,7 @@ __device__ __forceinline__ void slab_epilogue(const GemmNTArgs& p, const f32x16&
                 v[e] = x0[e];
                 v[4 + e] = x1[e];
             }
-            epilogue_row8<EPI, OUT_F32>(p, m, n, v);
+            epilogue_row8<EPI, OUT_F32>(p, m, n, v, (!OUT_F32 && p.colsum) ? cacc : nullptr);
         } else {
             float q0[4] = {x0[0], x0[1], x0[2], x0[3]}, q1[4] = {x1[0], x1[1], x1[2], x1[3]};
             const bool vec_ok = ((p.ldc & 3) == 0) && ((p.ld_aux_in & 3) == 0) && ((p.ld_aux_out & 3) == 0);
@@ -770,6 +793,8 @@ __device__ __forceinline__ void slab_epilogue(const GemmNTArgs& p, const f32x16&
             if (n + 4 < p.N) nt_epilogue_quad<EPI, OUT_F32>(p, m, n + 4, q1, vec_ok);
         }
     }
+    // (the host only passes `colsum` to this path when N % 8 == 0 and everything is 16-B aligned: row8 branch above)
+    if (!OUT_F32 && p.colsum && n_base + 64 <= p.N) colsum_flush(p.colsum, n_base, lane, cacc);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 }
@@ -811,6 +836,12 @@ __device__ __forceinline__ void fast_tile_epilogue(const GemmNTArgs& p, f32x16 (
         for (int q = 0; q < PF; ++q) aux[q] = *reinterpret_cast<const bf16x8*>(aux_addr(q));
         __builtin_amdgcn_sched_barrier(0);               // keep the prefetch up here (the scheduler sinks loads)
     }
+    const bool want_cs = !OUT_F32 && p.colsum != nullptr;       // wave-uniform
+    float cacc[NFP][8];
+#pragma unroll
+    for (int fp = 0; fp < NFP; ++fp)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cacc[fp][e] = 0.f;
 #pragma unroll
     for (int sl = 0; sl < 4; ++sl) {
         const int fi = sl / NFP, fp = sl % NFP;
@@ -892,10 +923,18 @@ __device__ __forceinline__ void fast_tile_epilogue(const GemmNTArgs& p, f32x16 (
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
                 *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + n) = o;
+                if (want_cs) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) cacc[fp][e] += (float)o[e];
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
+    }
+    if (want_cs) {
+#pragma unroll
+        for (int fp = 0; fp < NFP; ++fp) colsum_flush(p.colsum, n_base + fp * 64, lane, cacc[fp]);
     }
 }
 
@@ -1534,6 +1573,17 @@ int gemm_nt_dispatch(GemmNTArgs& a, int epilogue, int out_f32, hipStream_t s) {
     if (const char* e = getenv("MERLOT_NT_CFG_DYN")) cfg = atoi(e);
 #endif
     if (cfg == MERLOT_NT_KERNEL_P8 && !p8_ok(a)) cfg = MERLOT_NT_KERNEL_PERSIST_DYN;   // operands beyond 2 GiB: 64-bit addressing
+    // fused column sums of C (bias gradient): in the ping-pong kernel's epilogue when its row-contiguous path applies,
+    // otherwise the stand-alone column-sum kernel right behind the GEMM (same stream, same result up to summation order)
+    float* const colsum = a.colsum;
+    const bool cs_fused = colsum && cfg == MERLOT_NT_KERNEL_P8 && !out_f32 && (a.N % 8 == 0) && (a.ldc % 8 == 0) &&
+                          (a.ld_aux_in % 8 == 0) && (a.ld_aux_out % 8 == 0) && (((uintptr_t)a.C | (uintptr_t)colsum) & 15) == 0;
+    if (!cs_fused) a.colsum = nullptr;
+    if (colsum && !cs_fused) {
+        const int rc = gemm_nt_dispatch(a, epilogue, out_f32, s);
+        if (rc != MERLOT_OK) return rc;
+        return merlot_colsum_bf16(a.C, a.ldc, colsum, a.M, a.N, 1, s);
+    }
     switch (cfg) {
         case MERLOT_NT_KERNEL_RING_128x256: return launch_ring<RingK>(a, epilogue, out_f32, s);
         case MERLOT_NT_KERNEL_RING_256x64: return launch_ring<RingN64>(a, epilogue, out_f32, s);
@@ -1752,8 +1802,9 @@ extern "C" int merlot_gemm_bf16_nt(const void* A, int64_t lda, const void* Bt, i
                                    int64_t M, int64_t N, int64_t K, float alpha, int epilogue, int out_f32,
                                    int accumulate, const float* bias, const void* aux_in, int64_t ld_aux_in,
                                    void* aux_out, int64_t ld_aux_out, float dropout_p, uint64_t dropout_seed,
-                                   merlot_stream_t stream) {
+                                   float* colsum_out, merlot_stream_t stream) {
     MERLOT_CHECK(A && Bt && C, MERLOT_ESHAPE, "merlot_gemm_bf16_nt: null operand");
+    MERLOT_CHECK(!(colsum_out && out_f32), MERLOT_EDTYPE, "merlot_gemm_bf16_nt: colsum_out needs a bf16 output");
     MERLOT_CHECK(M > 0 && N > 0 && K > 0 && M < (1LL << 31) && N < (1LL << 31), MERLOT_ESHAPE,
                  "merlot_gemm_bf16_nt: bad dims M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
     MERLOT_CHECK(K % BK == 0, MERLOT_ESHAPE, "merlot_gemm_bf16_nt: K=%lld must be a multiple of %d", (long long)K, BK);
@@ -1775,6 +1826,7 @@ extern "C" int merlot_gemm_bf16_nt(const void* A, int64_t lda, const void* Bt, i
     a.drop_scale = 1.0f / (1.0f - dropout_p);
     a.drop_seed = dropout_seed;
     a.accumulate = accumulate;
+    a.colsum = colsum_out;
     return gemm_nt_dispatch(a, epilogue, out_f32, (hipStream_t)stream);
 }
 

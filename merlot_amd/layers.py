@@ -118,8 +118,7 @@ class TransformerStackFn(torch.autograd.Function):
             ctx.saved[l] = None
             # ---- MLP branch: h_out = h_mid + drop(fc2(gelu(fc1(LN2(h_mid)))))          db2 = d(fc2 output)
             ops.gemm_tn(db2, a, w.fc2.gw)                                       # dW2[H, I]
-            du = ops.gemm_nt(db2, w.fc2.wbT, epilogue=EPI_DGELU, aux_in=u)      # [T, I]
-            ops.colsum_bf16(du, w.fc1.gb)
+            du = ops.gemm_nt(db2, w.fc2.wbT, epilogue=EPI_DGELU, aux_in=u, colsum_out=w.fc1.gb)   # [T, I] + fc1's bias grad
             ops.gemm_tn(du, x2, w.fc1.gw)                                       # dW1[I, H]
             dx2 = ops.gemm_nt(du, w.fc1.wbT)
             dh_mid, db1 = ops.ln_bwd(dx2, h_mid, mean2, rstd2, w.ln2.gamma, w.ln2.ggamma, w.ln2.gbeta, dres=dh,

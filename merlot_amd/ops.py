@@ -58,9 +58,11 @@ def _chk(t, dtype, name):
 
 
 def gemm_nt(a, bt, *, bias=None, epilogue=EPI_NONE, out=None, out_dtype=BF16, accumulate=False, alpha=1.0,
-            aux_in=None, aux_out=None, dropout_p=0.0, dropout_seed=0, n=None):
-    """C[M,N] = epi(alpha * a[M,K] @ bt[N,K]^T).  a, bt bf16 2-D (row stride = leading dim)."""
+            aux_in=None, aux_out=None, dropout_p=0.0, dropout_seed=0, n=None, colsum_out=None):
+    """C[M,N] = epi(alpha * a[M,K] @ bt[N,K]^T).  a, bt bf16 2-D (row stride = leading dim).
+    colsum_out (f32 [N], accumulated): column sums of the stored bf16 C from the same launch (a bias gradient)."""
     _chk(a, BF16, 'a'); _chk(bt, BF16, 'bt'); _chk(bias, F32, 'bias'); _chk(aux_in, BF16, 'aux_in'); _chk(aux_out, BF16, 'aux_out')
+    _chk(colsum_out, F32, 'colsum_out')
     M, K = a.shape
     N = bt.shape[0] if n is None else n
     if bt.shape[1] != K:
@@ -73,7 +75,7 @@ def gemm_nt(a, bt, *, bias=None, epilogue=EPI_NONE, out=None, out_dtype=BF16, ac
         call('merlot_gemm_bf16_nt', _p(a), a.stride(0), _p(bt), bt.stride(0), _p(out), out.stride(0), M, N, K,
              float(alpha), int(epilogue), 1 if out.dtype == F32 else 0, 1 if accumulate else 0, _p(bias), _p(aux_in),
              aux_in.stride(0) if aux_in is not None else 0, _p(aux_out), aux_out.stride(0) if aux_out is not None else 0,
-             float(dropout_p), int(dropout_seed) & 0xFFFFFFFFFFFFFFFF, _stream())
+             float(dropout_p), int(dropout_seed) & 0xFFFFFFFFFFFFFFFF, _p(colsum_out), _stream())
 
     if TIMER is not None:
         TIMER.time('gemm_nt', 2.0 * M * N * K, launch)

@@ -23,7 +23,7 @@ def _gelu_grad(x):
 
 
 def gemm_nt(a, bt, *, bias=None, epilogue=EPI_NONE, out=None, out_dtype=BF16, accumulate=False, alpha=1.0,
-            aux_in=None, aux_out=None, dropout_p=0.0, dropout_seed=0, n=None):
+            aux_in=None, aux_out=None, dropout_p=0.0, dropout_seed=0, n=None, colsum_out=None):
     N = bt.shape[0] if n is None else n
     v = alpha * (a.float() @ bt[:N].float().t())
     if bias is not None:
@@ -44,6 +44,8 @@ def gemm_nt(a, bt, *, bias=None, epilogue=EPI_NONE, out=None, out_dtype=BF16, ac
         out[:, :N] += v.to(out.dtype)
     else:
         out[:, :N] = v.to(out.dtype)
+    if colsum_out is not None:                             # column sums of the STORED (rounded) values
+        colsum_out[:N] += out[:, :N].float().sum(0)
     return out
 
 

@@ -59,7 +59,7 @@ def test_nt_plan_is_a_pure_function_of_the_shape():
 def test_argument_validation_happens_before_any_launch():
     """error convention: negative status + message, no exception from C, no GPU needed for the shape checks."""
     d = lib.LIB.load()
-    rc = d.merlot_gemm_bf16_nt(None, 8, None, 8, None, 8, 4, 4, 64, 1.0, 0, 0, 0, None, None, 0, None, 0, 0.0, 0, None)
+    rc = d.merlot_gemm_bf16_nt(None, 8, None, 8, None, 8, 4, 4, 64, 1.0, 0, 0, 0, None, None, 0, None, 0, 0.0, 0, None, None)
     assert rc == -1 and b'null operand' in d.merlot_last_error()
     rc = d.merlot_ln_fwd(1, 0, 1, 1, 1, None, None, None, 4, 700, 1e-5, None)
     assert rc == -1 and b'H=700' in d.merlot_last_error()

@@ -155,3 +155,24 @@ def test_persist_dyn_back_to_back_launches_reuse_counter_slots(ops):
     first = ops.gemm_nt(a, bt)
     for _ in range(40):
         assert torch.equal(ops.gemm_nt(a, bt), first)
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(101376, 3072, 768, 'dgelu'), (42084, 3072, 768, 'dgelu'), (42084, 2304, 768, 'none'),
+                                        (300, 768, 768, 'dgelu')])
+def test_fused_column_sums_bias_gradient(ops, M, N, K, epi):
+    """colsum_out: the column sums of the stored bf16 output from the GEMM's own epilogue (ping-pong kernel: interior AND
+    ragged tiles; small problems: the stand-alone kernel behind the GEMM) == merlot_colsum_bf16 of that output; the output
+    itself is unchanged; the sums ACCUMULATE into the buffer.  Replaces the separate pass over dU for fc1's bias
+    gradient (utils/transformer.py:149-153)."""
+    a, bt = dev_rand((M, K), 31), dev_rand((N, K), 32, 0.05)
+    u = dev_rand((M, N), 33, 1.5)
+    kw = dict(epilogue=ops.EPI_DGELU, aux_in=u) if epi == 'dgelu' else dict(bias=dev_rand((N,), 34, 0.1, F32))
+    plain = ops.gemm_nt(a, bt, **kw)
+    cs = torch.full((N,), 2.0, device='cuda')
+    fused = ops.gemm_nt(a, bt, colsum_out=cs, **kw)
+    assert torch.equal(plain, fused)
+    ref = torch.full((N,), 2.0, device='cuda')
+    ops.colsum_bf16(plain, ref)
+    exact = plain.double().sum(0).float() + 2.0
+    scale = plain.float().abs().sum(0) + 1.0                      # cancellation-aware: errors relative to the L1 mass
+    assert float(((cs - exact).abs() / scale).max()) < 2e-6 and float(((ref - exact).abs() / scale).max()) < 2e-6
