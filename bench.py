@@ -117,26 +117,45 @@ def cpu_baseline():
     return {'value': None, 'unit': 'segments/s', 'cores': usable_cores(), 'kind': 'port', 'sample': why}
 
 
+GEMM_SOURCES = ('gemm.hip', 'gemm_p8.inc', 'gemm_ring.h', 'common.h')
+
+
+def gemm_source_hash():
+    """sha256 (first 16 hex digits) of the sources of the dominant kernel: ties a PMC traffic file to the binary it measured."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in GEMM_SOURCES:
+        h.update(open(os.path.join(ROOT, 'merlot_amd', 'csrc', f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic():
     """HBM-side bytes per launch of the representative dominant launch (M=101376 N=3072 K=768, bias epilogue), from the
-    TCC counters collected in separate rocprofv3 --pmc passes (profiles/r01_f_traffic.txt, scripts/gpu_traffic.sh):
-    2 * FETCH_SIZE (gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE, in bytes.  None if the file is absent."""
-    path = os.path.join(ROOT, 'profiles', 'r01_f_traffic.txt')
+    TCC counters collected in separate rocprofv3 --pmc passes over THIS kernel (profiles/r02_traffic.txt, written by
+    scripts/gpu_traffic.sh): 2 * FETCH_SIZE (gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE, in bytes.  The
+    file records the hash of the GEMM sources it was measured on; if the sources changed since, the figure is STALE and
+    is not reported (traffic: null, with the reason)."""
+    path = os.path.join(ROOT, 'profiles', 'r02_traffic.txt')
     if not os.path.exists(path):
-        return None
-    fetch = write = None
+        return {'bytes_per_launch': None, 'why': 'profiles/r02_traffic.txt absent'}
+    fetch = write = src = None
     for line in open(path):
-        if 'gemm_nt_persist_dyn_kernel<0, false>' in line:
+        if line.startswith('gemm_source_hash'):
+            src = line.split()[-1]
+        if 'gemm_nt_p8_kernel<0, false>' in line:
             kb = float(line.split()[-2])
             if line.startswith('FETCH_SIZE'):
                 fetch = kb
             elif line.startswith('WRITE_SIZE'):
                 write = kb
     if fetch is None or write is None:
-        return None
+        return {'bytes_per_launch': None, 'why': 'profiles/r02_traffic.txt holds no gemm_nt_p8_kernel<0, false> rows'}
+    if src != gemm_source_hash():
+        return {'bytes_per_launch': None, 'why': f'profiles/r02_traffic.txt was measured on GEMM sources {src}, the tree has '
+                                                 f'{gemm_source_hash()}: stale, re-run scripts/gpu_traffic.sh'}
     return {'bytes_per_launch': (2.0 * fetch + write) * 1024.0, 'algorithmic_bytes_per_launch': 783.3e6,
-            'launch': 'QKV-shaped forward M=101376 N=3072 K=768, plain epilogue (gemm_nt_persist_dyn_kernel<0,false>)',
-            'source': 'profiles/r01_f_traffic.txt'}
+            'launch': 'QKV-shaped forward M=101376 N=3072 K=768, plain epilogue (gemm_nt_p8_kernel<0,false>)',
+            'source': 'profiles/r02_traffic.txt', 'gemm_source_hash': src}
 
 
 def main():
@@ -150,6 +169,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--cpu-baseline-worker', type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument('--cpu-emulate', action='store_true', help=argparse.SUPPRESS)   # tests only: gloo + torch-CPU emulated ops, tiny model
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         cpu_baseline_worker(args.cpu_baseline_worker)
@@ -166,16 +186,41 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    if args.cpu_emulate:
+        # tests/test_dist_cpu.py: THIS file's code path (launch contract, barrier + max-over-ranks timing, the JSON line) on
+        # 2 gloo ranks with the HIP ops swapped for their torch-CPU emulation and the 2-layer 64x64 model of config #1
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        import emu_ops
+
+        class _MP(object):
+            def setattr(self, o, n, v):
+                setattr(o, n, v)
+        emu_ops.install(_MP())
+        torch.cuda.synchronize = lambda *a, **k: None
+        ops.KernelTimer = None
+        device = torch.device('cpu')
+    else:
+        torch.cuda.set_device(local_rank)
+        device = torch.device('cuda', local_rank)
     ctx = None
     force_dist = os.environ.get('MERLOT_FORCE_DIST', '0') == '1' and 'RANK' in os.environ
     if world > 1 or force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        # RCCL's kernels each hold a CU while a collective runs and a 160 KiB-LDS GEMM workgroup cannot share that CU: cap
+        # the channels so the overlapped gradient all-reduce takes at most 16 of the 256 CUs (the GEMMs claim their tiles
+        # dynamically and absorb that, profiles/r02_c_dp_contention.txt).  Override by exporting NCCL_MAX_NCHANNELS.
+        os.environ.setdefault('NCCL_MAX_NCHANNELS', '16')
+        if args.cpu_emulate:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=device)
         ctx = DistContext()
 
     config = NeatConfig.from_yaml(os.path.join(ROOT, 'merlot_amd', 'configs', 'pretrain_4seg_224.yaml'))
+    if args.cpu_emulate:
+        config.model.update(image_size=[64, 64], num_hidden_layers=2, num_vision_transformer_hidden_layers=2,
+                            num_lang_transformer_hidden_layers=2, hidden_dropout_prob=0.0)    # the emulation has no dropout
+        config.data['num_chunks'] = 4
     train_gflop = TRAIN_GFLOP_PER_SEGMENT
     if args.resnet_stem:
         config.model['resnet_layers'] = [3, 4, 9]
@@ -195,7 +240,7 @@ def main():
     # per-launch HIP events (on the launch stream) for the roofline figure: recorded during the LAST step of the timed
     # region only -- ~700 GEMM launches are sample enough, and bracketing every launch of every step with two events
     # costs ~3 % of the step (151 -> 156 ms), which would be charged to `value`.
-    timer = None if args.no_kernel_timing else ops.KernelTimer()
+    timer = None if (args.no_kernel_timing or args.cpu_emulate) else ops.KernelTimer()
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -245,7 +290,7 @@ def main():
             f, t, n = summ.get('gemm_nt', (0.0, 1.0, 0))
             traffic = measured_traffic()                     # PMC bytes of the representative launch, or None
             res['roofline'] = {'bound': 'mfma',
-                               'kernel': 'merlot_gemm_bf16_nt = gemm_nt_persist_dyn_kernel<EPI,OUT> + gemm_nt_ring_kernel<Cfg<2,4,2,2,32,3>,EPI,OUT> '
+                               'kernel': 'merlot_gemm_bf16_nt = gemm_nt_p8_kernel<EPI,OUT> (persistent ping-pong 256x256) + gemm_nt_ring_kernel<Cfg<2,4,2,2,32,3>,EPI,OUT> '
                                          '(bf16 MFMA 32x32x16, all epilogues; the dominant kernel family of the step)',
                                'achieved': f / t / 1e12, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                                'frac': f / t / 1e12 / PEAK_BF16_TFLOPS, 'traffic': (traffic or {}).get('bytes_per_launch'),
@@ -255,10 +300,10 @@ def main():
                                'timed_steps': timed_steps}
             if 'gemm_tn' in summ:
                 f2, t2, n2 = summ['gemm_tn']
-                res['roofline_wgrad'] = {'kernel': 'merlot_gemm_bf16_tn = gemm_tn_ring_kernel + tn_reduce_kernel', 'achieved': f2 / t2 / 1e12, 'unit': 'TFLOP/s',
+                res['roofline_wgrad'] = {'kernel': 'merlot_gemm_bf16_tn = gemm_tn_p8_kernel (+ gemm_tn_ring_kernel for small shapes) + tn_reduce_kernel', 'achieved': f2 / t2 / 1e12, 'unit': 'TFLOP/s',
                                          'frac': f2 / t2 / 1e12 / PEAK_BF16_TFLOPS, 'launches': n2,
                                          'share_of_step_time': t2 / timed_steps / (elapsed / args.steps)}
-        if world == 1 and not args.no_cpu_baseline and not args.resnet_stem:
+        if world == 1 and not args.no_cpu_baseline and not args.resnet_stem and not args.cpu_emulate:
             res['cpu_baseline'] = cpu_baseline()
         print(json.dumps(res), flush=True)
     if world > 1 or force_dist:

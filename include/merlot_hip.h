@@ -73,6 +73,23 @@ int merlot_gemm_bf16_nt(const void* A, int64_t lda, const void* Bt, int64_t ldb,
 #define MERLOT_NT_KERNEL_P8 22              /* gemm_nt_p8_kernel: persistent 256x256, BK 64, two wave groups in ping-pong */
 int merlot_gemm_bf16_nt_plan(int64_t M, int64_t N, int64_t K);
 
+/* ---- fp8 (OCP e4m3fn) forward path of BASELINE config #5.  No reference counterpart (the reference's precision policy is
+ * bf16 compute / fp32 parameters, utils/model_utils.py:572-602); contract: SURVEY.md 7(vii).
+ * merlot_quantize_e4m3: y[rows, cols] (1 byte per element) = e4m3(clamp(x * s, +-448)), s = 448 / max|x| over the whole
+ * tensor (per-tensor "current" scaling), x bf16.  scale = device float[3], written: {s, 1/s, max|x|}.
+ * cols, ldx, ldy multiples of 8. */
+int merlot_quantize_e4m3(const void* x, int64_t rows, int64_t cols, int64_t ldx, void* y, int64_t ldy, float* scale,
+                         merlot_stream_t stream);
+/* C[M,N] = epilogue(alpha * scale_a[0] * scale_b[0] * A8[M,K] * B8t[N,K]^T + bias): merlot_gemm_bf16_nt on e4m3 operands.
+ * scale_a / scale_b point at the DEQUANTISATION factor of each operand in device memory (&scale[1] of
+ * merlot_quantize_e4m3).  fp32 accumulation; epilogues, bias, aux_in / aux_out, dropout and the C dtypes as for the bf16
+ * entry.  K % 128 == 0, K >= 256, lda / ldb in elements (= bytes) and multiples of 16. */
+int merlot_gemm_fp8_nt(const void* A8, int64_t lda, const float* scale_a, const void* B8t, int64_t ldb,
+                       const float* scale_b, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, float alpha,
+                       int epilogue, int out_f32, const float* bias, const void* aux_in, int64_t ld_aux_in,
+                       void* aux_out, int64_t ld_aux_out, float dropout_p, uint64_t dropout_seed,
+                       merlot_stream_t stream);
+
 /* Weight gradient: C[M,N] (f32) (+)= alpha * sum_r A[r,M] * B[r,N].  A, B bf16 row-major with the
  * reduction index r as the SLOW dim (activations / output grads as stored).  M, N even.
  * The reduction is split over the grid; partial tiles go through the caller-owned `workspace` (f32, at least

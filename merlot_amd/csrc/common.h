@@ -15,6 +15,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
 
 // Experiment switches (scripts/ only).  The product library is compiled WITHOUT MERLOT_EXPERIMENTS: no getenv, no
 // debug bits in any kernel, no probe exports -- `build.sh exp` builds libmerlot_hip_exp.so with them.

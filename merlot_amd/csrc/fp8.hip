@@ -1,0 +1,91 @@
+// fp8 (OCP e4m3fn) operand preparation for BASELINE config #5's GEMM path: per-tensor scaling, "current" (the scale comes
+// from the tensor being quantised, not from a history).  The reference has no fp8 path at all (its precision policy is
+// bf16 compute / fp32 params, utils/model_utils.py:572-602); the contract is SURVEY.md 7(vii): per-tensor scales, fp32
+// accumulation, loss within 2e-2 of the bf16 path.
+//
+//   scale[0] = s = 448 / amax(|x|)      (1 if the tensor is all zeros)
+//   scale[1] = 1 / s                    -- what merlot_gemm_fp8_nt multiplies its accumulators by
+//   scale[2] = amax (bit pattern of a non-negative float, max-ed with integer atomics)
+//   y = e4m3( clamp(x * s, -448, 448) ) round-to-nearest-even
+//
+// Two passes over x (HBM-bound, 2 + 2 + 1 bytes per element): amax, then convert.  x is read as 16-B vectors, y written
+// as 8-B vectors; rows may be strided (ldx, ldy in elements).
+#include "common.h"
+
+namespace {
+
+constexpr float E4M3_MAX = 448.f;
+
+__global__ __launch_bounds__(256) void amax_bf16_kernel(const bf16* __restrict__ x, int64_t rows, int cols8, int64_t ldx,
+                                                        unsigned int* __restrict__ amax_bits) {
+    const int64_t total = rows * cols8;
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols8;
+        const int c = (int)(i - r * cols8);
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + r * ldx + (int64_t)c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf((float)v[e]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+        atomicMax(amax_bits, __float_as_uint(m));        // non-negative floats order like their bit patterns
+    }
+}
+
+__device__ __forceinline__ float scale_from_amax(float amax) { return amax > 0.f ? E4M3_MAX / amax : 1.f; }
+
+__global__ __launch_bounds__(256) void quantize_e4m3_kernel(const bf16* __restrict__ x, int64_t rows, int cols8, int64_t ldx,
+                                                            uint8_t* __restrict__ y, int64_t ldy, float* __restrict__ scale) {
+    const float s = scale_from_amax(scale[2]);
+    const int64_t total = rows * cols8;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols8;
+        const int c = (int)(i - r * cols8);
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + r * ldx + (int64_t)c * 8);
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = __builtin_fminf(__builtin_fmaxf((float)v[e] * s, -E4M3_MAX), E4M3_MAX);
+        u32x2 o;
+        int w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w, true);
+        o[0] = (uint32_t)w;
+        w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w, true);
+        o[1] = (uint32_t)w;
+        *reinterpret_cast<u32x2*>(y + r * ldy + (int64_t)c * 8) = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {           // every reader derives s from scale[2] itself: no ordering needed
+        scale[0] = s;
+        scale[1] = 1.f / s;
+    }
+}
+
+}  // namespace
+
+extern "C" int merlot_quantize_e4m3(const void* x, int64_t rows, int64_t cols, int64_t ldx, void* y, int64_t ldy,
+                                    float* scale, merlot_stream_t stream) {
+    MERLOT_CHECK(x && y && scale, MERLOT_ESHAPE, "merlot_quantize_e4m3: null argument");
+    MERLOT_CHECK(rows > 0 && cols > 0 && cols % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= cols && ldy >= cols, MERLOT_ESHAPE,
+                 "merlot_quantize_e4m3: rows=%lld cols=%lld ldx=%lld ldy=%lld (cols, ldx, ldy multiples of 8)", (long long)rows,
+                 (long long)cols, (long long)ldx, (long long)ldy);
+    MERLOT_CHECK(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0, MERLOT_EALIGN, "merlot_quantize_e4m3: x 16-byte, y 8-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(scale, 0, 3 * sizeof(float), s);
+    MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "merlot_quantize_e4m3: memset failed: %s", hipGetErrorString(e));
+    const int cols8 = (int)(cols / 8);
+    const int64_t total = rows * cols8;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(amax_bf16_kernel, dim3(grid), dim3(256), 0, s, (const bf16*)x, rows, cols8, ldx,
+                       reinterpret_cast<unsigned int*>(scale + 2));
+    hipLaunchKernelGGL(quantize_e4m3_kernel, dim3(grid), dim3(256), 0, s, (const bf16*)x, rows, cols8, ldx, (uint8_t*)y, ldy, scale);
+    return merlot_launch_status("merlot_quantize_e4m3");
+}

@@ -50,6 +50,8 @@ struct GemmNTArgs {
     int accumulate;
     float* colsum;        // optional f32 [N], ACCUMULATED: column sums of the stored (bf16-rounded) C -- the bias gradient of the
                           // layer whose output gradient this GEMM produces; only kernels that say so support it (else host fallback)
+    const float* scale_a; // fp8 kernels only: device scalars, the per-tensor dequantisation factors of A and B (alpha *= both)
+    const float* scale_b;
     int ntm, ntn;
     int cg;               // persistent kernel: tiles are enumerated in groups of `cg` tile columns (0: plain row-major)
     int dbg;              // experiments only: 1 = skip epilogue, 2 = skip main loop
@@ -1828,6 +1830,38 @@ extern "C" int merlot_gemm_bf16_nt(const void* A, int64_t lda, const void* Bt, i
     a.accumulate = accumulate;
     a.colsum = colsum_out;
     return gemm_nt_dispatch(a, epilogue, out_f32, (hipStream_t)stream);
+}
+
+// C = epilogue(alpha * scale_a[0] * scale_b[0] * A8 * B8^T + bias): e4m3 operands (merlot_quantize_e4m3), fp32 accumulation on the
+// MX-scaled MFMA with unit block scales, the bf16 kernel's epilogues.  ONE kernel (the 256 x 256 ping-pong kernel) -- shapes
+// it cannot take are an error, not a fallback.
+extern "C" int merlot_gemm_fp8_nt(const void* A8, int64_t lda, const float* scale_a, const void* B8t, int64_t ldb,
+                                  const float* scale_b, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, float alpha,
+                                  int epilogue, int out_f32, const float* bias, const void* aux_in, int64_t ld_aux_in,
+                                  void* aux_out, int64_t ld_aux_out, float dropout_p, uint64_t dropout_seed,
+                                  merlot_stream_t stream) {
+    MERLOT_CHECK(A8 && B8t && C && scale_a && scale_b, MERLOT_ESHAPE, "merlot_gemm_fp8_nt: null operand");
+    MERLOT_CHECK(M > 0 && N > 0 && K > 0 && M < (1LL << 31) && N < (1LL << 31), MERLOT_ESHAPE,
+                 "merlot_gemm_fp8_nt: bad dims M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
+    MERLOT_CHECK(((uintptr_t)A8 & 15) == 0 && ((uintptr_t)B8t & 15) == 0, MERLOT_EALIGN, "merlot_gemm_fp8_nt: A8/B8t must be 16-byte aligned");
+    MERLOT_CHECK(dropout_p >= 0.f && dropout_p < 1.f, MERLOT_ESHAPE, "merlot_gemm_fp8_nt: dropout_p out of range");
+    if (epilogue == MERLOT_EPI_RESIDUAL || epilogue == MERLOT_EPI_DGELU)
+        MERLOT_CHECK(aux_in != nullptr, MERLOT_ESHAPE, "merlot_gemm_fp8_nt: epilogue %d needs aux_in", epilogue);
+    GemmNTArgs a{};
+    a.A = (const bf16*)A8; a.B = (const bf16*)B8t; a.C = C;
+    a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+    a.M = (int)M; a.N = (int)N; a.K = (int)K;
+    a.alpha = alpha; a.bias = bias;
+    a.scale_a = scale_a; a.scale_b = scale_b;
+    a.aux_in = (const bf16*)aux_in; a.ld_aux_in = aux_in ? ld_aux_in : 0;
+    a.aux_out = (bf16*)aux_out; a.ld_aux_out = aux_out ? ld_aux_out : 0;
+    a.drop_thresh = dropout_p > 0.f ? (uint32_t)((double)dropout_p * 4294967296.0) : 0u;
+    a.drop_scale = 1.0f / (1.0f - dropout_p);
+    a.drop_seed = dropout_seed;
+    MERLOT_CHECK(p8_fp8_ok(a), MERLOT_ESHAPE,
+                 "merlot_gemm_fp8_nt: needs K %% 128 == 0, K >= 256, lda/ldb %% 16 == 0 and operands under 2 GiB (K=%lld lda=%lld ldb=%lld)",
+                 (long long)K, (long long)lda, (long long)ldb);
+    return launch_p8(a, epilogue, out_f32, (hipStream_t)stream, true);
 }
 
 extern "C" int merlot_gemm_bf16_nt_plan(int64_t M, int64_t N, int64_t K) {

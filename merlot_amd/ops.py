@@ -84,6 +84,48 @@ def gemm_nt(a, bt, *, bias=None, epilogue=EPI_NONE, out=None, out_dtype=BF16, ac
     return out
 
 
+FP8 = torch.float8_e4m3fn
+
+
+def quantize_e4m3(x, out=None):
+    """x bf16 [rows, cols] -> (y e4m3 [rows, cols], scale f32[3] = {s, 1/s, max|x|}), s = 448 / max|x| over the whole tensor."""
+    _chk(x, BF16, 'x')
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty((rows, cols), device=x.device, dtype=FP8)
+    _chk(out, FP8, 'out')
+    scale = torch.empty(3, device=x.device, dtype=F32)
+    call('merlot_quantize_e4m3', _p(x), rows, cols, x.stride(0), _p(out), out.stride(0), _p(scale), _stream())
+    return out, scale
+
+
+def gemm_fp8_nt(a8, a_scale, bt8, b_scale, *, bias=None, epilogue=EPI_NONE, out=None, out_dtype=BF16, alpha=1.0,
+                aux_in=None, aux_out=None, dropout_p=0.0, dropout_seed=0):
+    """C[M,N] = epi(alpha / (sa * sb) * a8[M,K] @ bt8[N,K]^T): gemm_nt on e4m3 operands; a_scale / b_scale are the f32[3]
+    tensors quantize_e4m3 returned (their [1] entry, the dequantisation factor, is read on the device)."""
+    _chk(a8, FP8, 'a8'); _chk(bt8, FP8, 'bt8'); _chk(a_scale, F32, 'a_scale'); _chk(b_scale, F32, 'b_scale')
+    _chk(bias, F32, 'bias'); _chk(aux_in, BF16, 'aux_in'); _chk(aux_out, BF16, 'aux_out')
+    M, K = a8.shape
+    N = bt8.shape[0]
+    if bt8.shape[1] != K:
+        raise ValueError(f"gemm_fp8_nt: K mismatch {a8.shape} vs {bt8.shape}")
+    if out is None:
+        out = torch.empty((M, N), device=a8.device, dtype=out_dtype)
+    _chk(out, out.dtype, 'out')
+
+    def launch():
+        call('merlot_gemm_fp8_nt', _p(a8), a8.stride(0), a_scale.data_ptr() + 4, _p(bt8), bt8.stride(0), b_scale.data_ptr() + 4,
+             _p(out), out.stride(0), M, N, K, float(alpha), int(epilogue), 1 if out.dtype == F32 else 0, _p(bias), _p(aux_in),
+             aux_in.stride(0) if aux_in is not None else 0, _p(aux_out), aux_out.stride(0) if aux_out is not None else 0,
+             float(dropout_p), int(dropout_seed) & 0xFFFFFFFFFFFFFFFF, _stream())
+
+    if TIMER is not None:
+        TIMER.time('gemm_fp8_nt', 2.0 * M * N * K, launch)
+    else:
+        launch()
+    return out
+
+
 def gemm_tn(a, b, out, *, accumulate=True, alpha=1.0, m=None, n=None):
     """out[M,N] (f32) (+)= alpha * a[R,M]^T @ b[R,N]."""
     _chk(a, BF16, 'a'); _chk(b, BF16, 'b'); _chk(out, F32, 'out')

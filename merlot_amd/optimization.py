@@ -30,7 +30,7 @@ class AdamOptimizer(object):
     def __init__(self, store, learning_rate, num_train_steps, num_warmup_steps, weight_decay_rate=1e-4,
                  param_overrides=None, freeze_scope=None, epsilon=1e-6, beta_2=0.98, use_bfloat16_adam=False,
                  clip_norm=1.0, grad_reduce='sum', world_size=1, beta_1=0.9, do_param_scale=False,
-                 decay_beta2_adafactor=False, **kwargs):
+                 decay_beta2_adafactor=False, grad_reduce_dtype='float32', **kwargs):
         self.clip_norm = float(clip_norm or 0.0)
         self.store = store
         self.lr, self.nts, self.nws = learning_rate, num_train_steps, num_warmup_steps

@@ -61,12 +61,20 @@ class DistContext(object):
 class GradReducer(object):
     """Bucketed, overlapped all-reduce of the ParamStore gradient arena."""
 
-    def __init__(self, store, ctx, expected_passes=None, defer=False):
+    def __init__(self, store, ctx, expected_passes=None, defer=False, payload='fp32'):
         """defer=True: nothing is launched from inside the backward; `finish()` reduces the whole arena (needed when the
-        local gradients are clipped by their global norm before the cross-replica sum, utils/optimization.py:233-245)."""
+        local gradients are clipped by their global norm before the cross-replica sum, utils/optimization.py:233-245).
+        payload='bf16': each bucket travels as bf16 (half the xGMI bytes and half the time RCCL's kernels hold CUs beside
+        the backward GEMMs); the sum is formed on bf16-rounded addends and written back to the fp32 arena.  The reference
+        reduces fp32 (utils/optimization.py:241-245), so 'fp32' is the default and 'bf16' an opt-in
+        (`optimizer.grad_reduce_dtype: bfloat16`)."""
+        if payload not in ('fp32', 'bf16'):
+            raise ValueError("payload must be 'fp32' or 'bf16'")
         self.store = store
         self.ctx = ctx
         self.defer = defer
+        self.payload = payload
+        self._staged = []        # [(start, end, bf16 buffer)] waiting to be copied back after their all-reduce
         self.expected = dict(expected_passes or {})
         self._seen = {}
         self._done = []          # [(start, end)]
@@ -95,7 +103,12 @@ class GradReducer(object):
         self._launch(s, e)
 
     def _launch(self, s, e):
-        w = dist.all_reduce(self.store.grad[s:e], op=dist.ReduceOp.SUM, group=self.ctx.group, async_op=True)
+        if self.payload == 'bf16':
+            buf = self.store.grad[s:e].to(torch.bfloat16)
+            w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.ctx.group, async_op=True)
+            self._staged.append((s, e, buf))
+        else:
+            w = dist.all_reduce(self.store.grad[s:e], op=dist.ReduceOp.SUM, group=self.ctx.group, async_op=True)
         self._work.append(w)
         self._done.append((s, e))
 
@@ -110,4 +123,6 @@ class GradReducer(object):
                 pos = max(pos, e)
             for w in self._work:
                 w.wait()
-        self._work, self._done, self._seen = [], [], {}
+            for s, e, buf in self._staged:
+                self.store.grad[s:e].copy_(buf)
+        self._work, self._done, self._seen, self._staged = [], [], {}, []

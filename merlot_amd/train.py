@@ -54,9 +54,10 @@ class Trainer(object):
         if dist_ctx is not None and (world > 1 or FORCE):
             # encoder weights receive gradients from the joint AND the text-only pass before they may be reduced
             shared = 2 if config.model.get('share_params', True) else 1
+            payload = 'bf16' if str(config.optimizer.get('grad_reduce_dtype', 'float32')) in ('bfloat16', 'bf16') else 'fp32'
             self.reducer = GradReducer(self.store, dist_ctx,
                                        expected_passes={'encoder': shared, 'encoder/LayerNorm_ln_final': shared, '*': 1},
-                                       defer=self.opt.clip_norm > 0.0)
+                                       defer=self.opt.clip_norm > 0.0, payload=payload)
         self.step_idx = 0
         # model/modeling.py:724-738: variables the init checkpoint also holds (weights and, since this is the training
         # graph, the Adam slots) start from it; global_step does not.

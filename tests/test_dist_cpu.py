@@ -183,3 +183,28 @@ def test_train_loop_two_replicas(tmp_path):
     assert len(set(r0['seeds'] + r1['seeds'])) == 6 and not torch.equal(r0['gumbel'], r1['gumbel'])
     prefix = ck.latest_checkpoint(str(tmp_path / 'out'))
     assert prefix.endswith('model.ckpt-2') and int(ck.load_variable(prefix, 'global_step')) == 2
+
+
+@pytest.mark.timeout(900)
+def test_bench_py_code_path_two_ranks_emulated(tmp_path):
+    """bench.py's OWN code path at world_size 2 -- the torch.distributed.run launch contract (RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_*), Trainer with the overlapped GradReducer and the contrastive all-gather, barrier +
+    max-over-ranks timing, one JSON line from rank 0 with the whole-job aggregate -- on gloo with the HIP ops emulated
+    (`--cpu-emulate`: 2-layer 64x64 model).  No throughput claim: a plumbing test."""
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    port = _free_port()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+           '--examples', '2', '--cpu-emulate']
+    env = dict(os.environ, OMP_NUM_THREADS='4')
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=850, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]                   # rank 0 only
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['steps'] == 2 and res['warmup'] == 1 and res['scaling'] == 'weak'
+    assert res['config']['parallelism'] == 'dp2' and res['config']['segments_per_gpu_per_step'] == 8
+    assert abs(res['value'] - 2 * 8 * 2 / (res['ms_per_step'] * 2 / 1e3)) < 1e-6 * res['value']     # whole-job aggregate
+    assert res['config']['final_loss'] == res['config']['final_loss'] and res['config']['final_loss'] < 30.0
