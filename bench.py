@@ -24,6 +24,22 @@ TRAIN_GFLOP_PER_SEGMENT = 170.4          # 56.79 fwd x 3, num_ch
 # patch conv (2*MACs over the convolutions of utils/vision_transformer.py:114-170, 213-223 at 224^2)
 TRAIN_GFLOP_PER_SEGMENT_RESNET = 170.4 + 3.0 * (10.041 - 0.231)
 PEAK_BF16_TFLOPS = 2500.0                # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_FP8_TFLOPS = 5000.0                 # MI355X dense fp8 MFMA (MX-scaled K=64/128 forms; same guide)
+
+
+def fwd_gflop_per_segment(image, n_group, text_len=32, hidden=768, inter=3072, layers=12, patch=16, ncls=2, pool=2):
+    """forward GFLOP of one frame-caption segment (2 x MACs of the GEMMs and the attention contractions), the closed form
+    behind SURVEY.md 8(d)'s 56.79 (224^2, groups of 4): ViT on 2 + (image/16)^2 tokens, the joint encoder on a group of
+    n x (1 + pooled grid + text_len) tokens, the text-only encoder on text_len tokens, + 1.09 for the heads."""
+    lin = 2.0 * (4 * hidden * hidden + 2 * hidden * inter)             # per token and layer
+    att = lambda s: 4.0 * s * s * hidden                               # per sequence and layer: QK^T + PV
+    grid = (image // patch) ** 2
+    sv = ncls + grid
+    sj = n_group * (1 + grid // (pool * pool) + text_len)
+    vit = layers * (lin * sv + att(sv)) + 2.0 * grid * hidden * patch * patch * 3
+    joint = layers * (lin * sj + att(sj)) / n_group
+    text = layers * (lin * text_len + att(text_len))
+    return (vit + joint + text) / 1e9 + 1.09
 
 
 def usable_cores():
@@ -163,7 +179,11 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--examples', type=int, default=32, help='examples (x16 segments) per GPU per step')
+    ap.add_argument('--examples', type=int, default=None, help='examples (x16 segments) per GPU per step (default 32; config 5: 12)')
+    ap.add_argument('--config', type=int, default=2, choices=(2, 5),
+                    help='BASELINE.json configs[]: 2 = the headline 4-segment 224^2 bf16 workload (configs[1]; DP over --gpus); '
+                         '5 = NOT the headline: the 16-segment 384^2 long-video variant with fp8 forward GEMMs (configs[4])')
+    ap.add_argument('--bf16', action='store_true', help='with --config 5: keep every GEMM in bf16 (the comparison line)')
     ap.add_argument('--resnet-stem', action='store_true',
                     help='NOT the headline config: swap the patch stem for the ResNet-hybrid stem of merlot.yaml:30 (resnet_layers [3, 4, 9])')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -181,6 +201,8 @@ def main():
     from merlot_amd.parallel import DistContext
     from merlot_amd.train import Trainer, synthetic_batch
 
+    if args.examples is None:
+        args.examples = 12 if args.config == 5 else 32
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -222,6 +244,12 @@ def main():
                             num_lang_transformer_hidden_layers=2, hidden_dropout_prob=0.0)    # the emulation has no dropout
         config.data['num_chunks'] = 4
     train_gflop = TRAIN_GFLOP_PER_SEGMENT
+    fp8 = False
+    if args.config == 5:
+        # BASELINE configs[4]: 16 segments per group at 384^2 (Sv = 578, joint S = 2832); everything else as merlot.yaml
+        fp8 = not args.bf16
+        config.model.update(image_size=[384, 384], num_chunks_in_group=16, fp8_forward=fp8)
+        train_gflop = 3.0 * fwd_gflop_per_segment(384, 16)
     if args.resnet_stem:
         config.model['resnet_layers'] = [3, 4, 9]
         train_gflop = TRAIN_GFLOP_PER_SEGMENT_RESNET
@@ -269,12 +297,20 @@ def main():
     if rank == 0:
         value = world * seg_per_gpu * args.steps / elapsed
         res = {
-            'metric': 'frame-caption segments/sec/node (4-seg, 224^2, bf16)', 'value': value, 'unit': 'segments/s',
+            'metric': 'frame-caption segments/sec/node (4-seg, 224^2, bf16)' if args.config == 2 else
+                      'frame-caption segments/sec/node (16-seg, 384^2, %s)' % ('fp8 forward GEMMs' if fp8 else 'bf16'),
+            'value': value, 'unit': 'segments/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': ('merlot.yaml 4-segment ResNet-hybrid [3,4,9] + ViT-B/16' if args.resnet_stem else
-                                    'merlot.yaml 4-segment full ViT-B/16 (patch stem)') + ' + 12-layer joint + 12-layer text-only, '
-                                   '224^2 frames, 32-token captions, fwd+bwd+DP all-reduce+AdamW, dropout 0.1',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'fp8 (e4m3 operands, fp32 accumulate: QKV / fc1 / fc2 forward GEMMs; bf16 elsewhere)' if fp8 else 'bf16',
+            'data': 'synthetic',
+            'config': {'workload': (('merlot.yaml 4-segment ResNet-hybrid [3,4,9] + ViT-B/16' if args.resnet_stem else
+                                     'merlot.yaml 4-segment full ViT-B/16 (patch stem)') + ' + 12-layer joint + 12-layer text-only, '
+                                    '224^2 frames, 32-token captions, fwd+bwd+DP all-reduce+AdamW, dropout 0.1') if args.config == 2 else
+                                   ('BASELINE configs[4]: 16-segment long-video variant, full ViT-B/16 at 384^2 (578 tokens/frame) + '
+                                    '12-layer joint over 2832-token groups + 12-layer text-only, fwd+bwd+AdamW, dropout 0.1; '
+                                    + ('fp8 forward GEMMs' if fp8 else 'all-bf16 comparison run')),
+                       'baseline_config': args.config,
                        'segments_per_gpu_per_step': seg_per_gpu, 'examples_per_gpu': args.examples,
                        'num_chunks': config.data['num_chunks'], 'parallelism': f'dp{world}', 'grad_reduce': 'sum',
                        'stem': 'resnet-hybrid [3,4,9] (merlot.yaml:30)' if args.resnet_stem else 'patch 16x16 (north_star)',
@@ -298,12 +334,18 @@ def main():
                                'avg_launch_us': 1e6 * t / max(n, 1), 'gflop_per_launch': f / max(n, 1) / 1e9,
                                'share_of_step_time': t / timed_steps / (elapsed / args.steps),
                                'timed_steps': timed_steps}
+            if 'gemm_fp8_nt' in summ:
+                f8, t8, n8 = summ['gemm_fp8_nt']
+                res['roofline_fp8'] = {'bound': 'mfma', 'kernel': 'merlot_gemm_fp8_nt = gemm_nt_p8_kernel<EPI,OUT,FP8> (v_mfma_scale_f32_32x32x64_f8f6f4, unit block scales)',
+                                       'achieved': f8 / t8 / 1e12, 'peak': PEAK_FP8_TFLOPS, 'unit': 'TFLOP/s',
+                                       'frac': f8 / t8 / 1e12 / PEAK_FP8_TFLOPS, 'launches': n8,
+                                       'share_of_step_time': t8 / timed_steps / (elapsed / args.steps)}
             if 'gemm_tn' in summ:
                 f2, t2, n2 = summ['gemm_tn']
                 res['roofline_wgrad'] = {'kernel': 'merlot_gemm_bf16_tn = gemm_tn_p8_kernel (+ gemm_tn_ring_kernel for small shapes) + tn_reduce_kernel', 'achieved': f2 / t2 / 1e12, 'unit': 'TFLOP/s',
                                          'frac': f2 / t2 / 1e12 / PEAK_BF16_TFLOPS, 'launches': n2,
                                          'share_of_step_time': t2 / timed_steps / (elapsed / args.steps)}
-        if world == 1 and not args.no_cpu_baseline and not args.resnet_stem and not args.cpu_emulate:
+        if world == 1 and not args.no_cpu_baseline and not args.resnet_stem and not args.cpu_emulate and args.config == 2:
             res['cpu_baseline'] = cpu_baseline()
         print(json.dumps(res), flush=True)
     if world > 1 or force_dist:

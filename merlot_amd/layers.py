@@ -41,6 +41,17 @@ class StackW(object):
         self.ln_final = store.ln(f'{scope}/LayerNorm_ln_final')
 
 
+def _fwd_linear(x, lin, fp8, **kw):
+    """One forward Linear of the stack.  fp8 (BASELINE config #5, `model.fp8_forward`): both operands are quantised to e4m3
+    with per-tensor current scaling and the product runs on the fp8 kernel with fp32 accumulation; bias, epilogue and output
+    dtype are those of the bf16 path.  The backward always consumes the bf16 tensors (x is saved as before)."""
+    if not fp8:
+        return ops.gemm_nt(x, lin.wb, bias=lin.b, **kw)
+    x8, sx = ops.quantize_e4m3(x)
+    w8, sw = ops.quantize_e4m3(lin.wb)
+    return ops.gemm_fp8_nt(x8, sx, w8, sw, bias=lin.b, **kw)
+
+
 def _site_seed(seed, layer, site):
     return (int(seed) * 1000003 + layer * 16 + site) & 0xFFFFFFFFFFFFFFFF
 
@@ -48,7 +59,7 @@ def _site_seed(seed, layer, site):
 class TransformerStackFn(torch.autograd.Function):
     """hidden [B*S, H] bf16 -> LN_final(stack(hidden)) [B*S, H] bf16.
 
-    opts: dict(heads, dropout_p, seed, colsum (f32 [B,S] accumulated over layers, all query rows, weight 1/heads),
+    opts: dict(heads, dropout_p, seed, fp8 (QKV / fc1 / fc2 forward GEMMs on e4m3 operands), colsum (f32 [B,S] accumulated over layers, all query rows, weight 1/heads),
                log_lo / log_hi (f32 [B,S], valid pairs only, queries < / >= log_split), num_layers,
                seg (int32 [S]: the disable_pairwise_lang_attn block mask, model/modeling.py:160-168))
     """
@@ -62,13 +73,14 @@ class TransformerStackFn(torch.autograd.Function):
         colsum = opts.get('colsum')
         log_lo, log_hi = opts.get('log_lo'), opts.get('log_hi')
         seg = opts.get('seg')                              # int32 [S] block mask of disable_pairwise_lang_attn, or None
+        fp8 = bool(opts.get('fp8', False))
         need_bwd = ctx.needs_input_grad[0]
         saved = []
         h = h.contiguous()
         for l in range(nl):
             w = stack.layers[l]
             x1, _, mean1, rstd1 = ops.ln_fwd(h, w.ln1.gamma, w.ln1.beta)
-            qkv = ops.gemm_nt(x1, w.qkv.wb, bias=w.qkv.b)
+            qkv = _fwd_linear(x1, w.qkv, fp8)
             # the attention-probability side outputs (a7) come out of the forward launch: K is still resident in LDS
             if colsum is not None and log_lo is None:
                 ctx_, lse = ops.attention_fwd(qkv, B, S, heads, valid, seg=seg, colsum_lo=colsum, valid_q_only=False,
@@ -88,8 +100,8 @@ class TransformerStackFn(torch.autograd.Function):
                                 dropout_seed=_site_seed(seed, l, 0))
             x2, _, mean2, rstd2 = ops.ln_fwd(h_mid, w.ln2.gamma, w.ln2.beta)
             u = torch.empty((x2.shape[0], w.fc1.wb.shape[0]), device=h.device, dtype=BF16)
-            a = ops.gemm_nt(x2, w.fc1.wb, bias=w.fc1.b, epilogue=EPI_GELU, aux_out=u)
-            h_out = ops.gemm_nt(a, w.fc2.wb, bias=w.fc2.b, epilogue=EPI_RESIDUAL, aux_in=h_mid, dropout_p=p,
+            a = _fwd_linear(x2, w.fc1, fp8, epilogue=EPI_GELU, aux_out=u)
+            h_out = _fwd_linear(a, w.fc2, fp8, epilogue=EPI_RESIDUAL, aux_in=h_mid, dropout_p=p,
                                 dropout_seed=_site_seed(seed, l, 1))
             if need_bwd:
                 saved.append((h, mean1, rstd1, x1, qkv, ctx_, lse, h_mid, mean2, rstd2, x2, u, a))

@@ -178,7 +178,8 @@ class MerlotModel(object):
         x = L.layer_norm(x, st.ln(f'{vs}/LayerNorm_ctx_patches_pre_ln'), out_bf16=True)
         vit_p = cfg.get('vit_hidden_dropout_prob', cfg['hidden_dropout_prob']) if is_training else 0.0
         hs = L.transformer_stack(x, self._vit, N, Sv, None,
-                                 dict(heads=heads, dropout_p=vit_p, seed=self.seed * 4 + 0, num_layers=nl_vit))
+                                 dict(heads=heads, dropout_p=vit_p, seed=self.seed * 4 + 0, num_layers=nl_vit,
+                                      fp8=cfg.get('fp8_forward', False)))
         hs3 = hs.view(N, Sv, H)
         sp = cfg['spatial_pool_size']
         h2, w2 = h1 // sp, w1 // sp
@@ -216,7 +217,7 @@ class MerlotModel(object):
         is_valid = torch.cat([p['is_valid'] for p in self.encoder_pieces], 1)
         Sj = self.P + self.L
         opts = dict(heads=heads, dropout_p=self.dropout_prob if is_training else 0.0, seed=self.seed * 4 + 2,
-                    num_layers=cfg['num_hidden_layers'])
+                    num_layers=cfg['num_hidden_layers'], fp8=cfg.get('fp8_forward', False))
         if cfg.get('disable_pairwise_lang_attn', False):                          # :160-168, as a segment vector
             opts['seg'] = torch.cat([torch.zeros(self.P, dtype=torch.int32),
                                      1 + torch.arange(self.L, dtype=torch.int32) // self.lang_chunk_length]).to(dev)
@@ -354,7 +355,8 @@ class MerlotModel(object):
         hs = L.transformer_stack(emb.reshape(R * Sl, H), self._lang_enc, R, Sl, valid,
                                  dict(heads=cfg['num_attention_heads'],
                                       dropout_p=self.dropout_prob if self.is_training else 0.0, seed=self.seed * 4 + 1,
-                                      num_layers=cfg['num_lang_transformer_hidden_layers'], colsum=summ))
+                                      num_layers=cfg['num_lang_transformer_hidden_layers'], colsum=summ,
+                                      fp8=cfg.get('fp8_forward', False)))
         pool = hs.view(self.batch_size * self.num_chunks, self.lang_chunk_length, H)[:, 0].float()   # :372-378
         info = {'_hidden_state_flat': hs, 'hidden_state': hs.view(R, Sl, H), 'attention_summs': summ}
         return pool, info
