@@ -158,19 +158,19 @@ def measured_traffic():
     for line in open(path):
         if line.startswith('gemm_source_hash'):
             src = line.split()[-1]
-        if 'gemm_nt_p8_kernel<0, false>' in line:
-            kb = float(line.split()[-2])
+        if 'gemm_nt_p8_kernel<0, false, false>' in line and line.split(' | ')[0] in ('FETCH_SIZE', 'WRITE_SIZE'):
+            kb = float(line.split()[-1])                      # '<counter> | <kernel> | launches n | KB_per_launch v'
             if line.startswith('FETCH_SIZE'):
                 fetch = kb
-            elif line.startswith('WRITE_SIZE'):
+            else:
                 write = kb
     if fetch is None or write is None:
-        return {'bytes_per_launch': None, 'why': 'profiles/r02_traffic.txt holds no gemm_nt_p8_kernel<0, false> rows'}
+        return {'bytes_per_launch': None, 'why': 'profiles/r02_traffic.txt holds no gemm_nt_p8_kernel<0, false, false> rows'}
     if src != gemm_source_hash():
         return {'bytes_per_launch': None, 'why': f'profiles/r02_traffic.txt was measured on GEMM sources {src}, the tree has '
                                                  f'{gemm_source_hash()}: stale, re-run scripts/gpu_traffic.sh'}
     return {'bytes_per_launch': (2.0 * fetch + write) * 1024.0, 'algorithmic_bytes_per_launch': 783.3e6,
-            'launch': 'QKV-shaped forward M=101376 N=3072 K=768, plain epilogue (gemm_nt_p8_kernel<0,false>)',
+            'launch': 'forward Linear M=101376 N=3072 K=768, bias epilogue, bf16 out (gemm_nt_p8_kernel<0,false,false>)',
             'source': 'profiles/r02_traffic.txt', 'gemm_source_hash': src}
 
 

@@ -137,6 +137,7 @@ class MerlotModel(object):
         st = params
         st.refresh()
         self._anchor = torch.zeros(1, device=dev, requires_grad=True)
+        self._token_id_flags = []                            # device bools: embed_words saw an id outside [0, vocab)
         nl_vit = cfg.get('num_vision_transformer_hidden_layers', cfg['num_hidden_layers'])
         nl_enc = max(cfg['num_hidden_layers'], cfg.get('num_lang_transformer_hidden_layers', 0))
         self._vit = StackW(st, 'vision_backbone/vision_transformer', nl_vit)
@@ -313,6 +314,18 @@ class MerlotModel(object):
         return self.config.get('use_bfloat16', True)
 
     # ------------------------------------------------------------------------------------------------
+    def token_id_flag(self):
+        """device bool: any embed_words call of this model saw a token id outside [0, vocab_size) (None if none ran)."""
+        if not self._token_id_flags:
+            return None
+        return torch.stack(self._token_id_flags).any()
+
+    def check_token_ids(self):
+        """the range assertion of utils/model_utils.py:256-258 (synchronises with the GPU)."""
+        f = self.token_id_flag()
+        if f is not None and bool(f):
+            raise ValueError("token id out of range")
+
     def embed_words(self, input_ids_2d, norm_scope_name='position_embeddings'):
         """model/modeling.py:262-297: LN(word_emb[ids] + pos_emb[0:L]) -> dropout -> bf16 [R, L, H]."""
         st = self.params
@@ -321,9 +334,14 @@ class MerlotModel(object):
         R, Lq = ids.shape
         if Lq > self.config['max_position_embeddings']:
             raise ValueError("sequence longer than max_position_embeddings")
-        if int(ids.min()) < 0 or int(ids.max()) > self.vocab_size - 1:          # utils/model_utils.py:256-258
-            raise ValueError("token id out of range")
-        idx_w = ids.reshape(-1).int().contiguous()
+        # utils/model_utils.py:256-258 asserts the id range INSIDE the graph (the error surfaces when the step's results are
+        # fetched); same here: the flag stays on the device -- no host round trip in the middle of the step, the trainer
+        # fetches it one step late (`check_token_ids`) -- and the gather below is made memory-safe by clamping.
+        bad = (ids.min() < 0) | (ids.max() > self.vocab_size - 1)
+        self._token_id_flags.append(bad)
+        if not self.is_training:
+            self.check_token_ids()
+        idx_w = ids.reshape(-1).clamp(0, self.vocab_size - 1).int().contiguous()
         idx_p = torch.arange(Lq, device=self.device).repeat(R).int().contiguous()
         emb = L.gather_add(None, None,
                            [(st.p('word_embeddings/word_embeddings'), st.g('word_embeddings/word_embeddings'), idx_w),
@@ -575,6 +593,6 @@ def model_fn_builder(config):
         losses.update({f'contr/{k}': v for k, v in contr_losses.items()})
         losses.update({f'temporal/{k}': v for k, v in temp_losses.items()})
         loss = lang_loss + contr_loss + temp_loss                               # :713
-        return {'loss': loss, 'metrics': losses, 'model': model}
+        return {'loss': loss, 'metrics': losses, 'model': model, 'token_id_out_of_range': model.token_id_flag()}
 
     return model_fn

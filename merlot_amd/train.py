@@ -59,6 +59,7 @@ class Trainer(object):
                                        expected_passes={'encoder': shared, 'encoder/LayerNorm_ln_final': shared, '*': 1},
                                        defer=self.opt.clip_norm > 0.0, payload=payload)
         self.step_idx = 0
+        self._pending_check = None       # (pinned host bool, event, step): last step's token-id range flag, fetched one step late
         # model/modeling.py:724-738: variables the init checkpoint also holds (weights and, since this is the training
         # graph, the Adam slots) start from it; global_step does not.
         self.initialized_variable_names = {}
@@ -90,9 +91,42 @@ class Trainer(object):
         with torch.no_grad():
             return self.model_fn(features, None, 'train', {'store': self.store, 'dist': self.dist, 'seed': self.step_seed()})
 
+    def check_inputs(self, wait=True):
+        """raise if an earlier step embedded a token id outside [0, vocab) (utils/model_utils.py:256-258's in-graph assertion).
+        The flag was copied to pinned host memory asynchronously; by the time the next step has been enqueued it is there."""
+        if self._pending_check is None:
+            return
+        host, ev, step = self._pending_check
+        if not wait and not ev.query():
+            return
+        ev.synchronize()
+        self._pending_check = None
+        if bool(host):
+            raise ValueError(f"token id out of range (training step {step})")
+
+    def _defer_check(self, flag):
+        if flag is None:
+            return
+        if flag.is_cuda:
+            host = torch.empty((), dtype=torch.bool, pin_memory=True)
+            host.copy_(flag, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        else:
+            class _Done(object):
+                def query(self):
+                    return True
+
+                def synchronize(self):
+                    pass
+            host, ev = flag, _Done()
+        self._pending_check = (host, ev, self.step_idx)
+
     def step(self, features):
         self.store.zero_grad()
         out = self.model_fn(features, None, 'train', {'store': self.store, 'dist': self.dist, 'seed': self.step_seed()})
+        self.check_inputs()                                  # the PREVIOUS step's flag (long since on the host)
+        self._defer_check(out.get('token_id_out_of_range'))
         out['loss'].backward()
         if self.opt.clip_norm > 0.0:                         # clip the local gradients, then sum across replicas
             out['grad_norm'] = self.opt.clip_local_gradients()

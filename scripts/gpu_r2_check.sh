@@ -1,7 +1,9 @@
 #!/bin/bash
-# round 2: all -m gpu tests (new persistent-kernel / depth-12 / shuffle fixture tests included), smoke, bench
+# full GPU check: tests, smoke, bench line
 mkdir -p gpurun_out
-export TMPDIR=/tmp
-timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --durations=8 2>&1 | tail -80 > gpurun_out/${TAG:-r2}_pytest_gpu.log; tail -5 gpurun_out/${TAG:-r2}_pytest_gpu.log
-timeout 300 python __graft_entry__.py smoke 2>&1 | tail -1
-timeout 600 python bench.py --steps ${STEPS:-6} --warmup 3 ${EXTRA:---no-cpu-baseline} > gpurun_out/${TAG:-r2}_bench.log 2>&1; tail -1 gpurun_out/${TAG:-r2}_bench.log | cut -c1-1500
+T=${TAG:-r2}
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > gpurun_out/${T}_pytest_gpu.log
+cat gpurun_out/${T}_pytest_gpu.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
+timeout 900 python bench.py > gpurun_out/${T}_bench.log 2>gpurun_out/${T}_bench.err
+tail -2 gpurun_out/${T}_bench.err; cat gpurun_out/${T}_bench.log

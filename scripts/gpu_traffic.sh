@@ -1,5 +1,8 @@
 #!/bin/bash
-# HBM traffic of the GEMM kernels from the TCC counters (separate passes, as MI355X_MICROARCH.md prescribes)
+# HBM traffic of the dominant kernels from the TCC counters -- separate --pmc passes with --kernel-trace only, as
+# MI355X_MICROARCH.md prescribes -- over the PRODUCT library.  Writes gpurun_out/r02_traffic.txt; copy it to profiles/.
+# The file records the hash of the GEMM sources (bench.py refuses a file whose hash differs from the tree's) and the
+# sha256 of the measured libmerlot_hip.so.
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
@@ -9,16 +12,33 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o g -- python $R/scripts/pmc_gemm.py > $R/gpurun_out/pmc_$c.log 2>&1
   cp /tmp/pmc_$c/g_counter_collection.csv $R/gpurun_out/pmc_$c.csv
 done
-python - <<PY
-import csv, collections
+cd $R
+python - <<'PY' > gpurun_out/r02_traffic.txt
+import csv, collections, hashlib, os, sys
+sys.path.insert(0, os.getcwd())
+import bench
+print('# rocprofv3 --pmc <counter> --kernel-trace -- python scripts/pmc_gemm.py   (one pass per counter; MI355X, gfx950)')
+print('# KB = TCC counter value per launch as reported (FETCH_SIZE / WRITE_SIZE in KiB); HBM bytes = (2*FETCH + WRITE) * 1024')
+print('#   (the gfx950 correction of MI355X_MICROARCH.md: FETCH_SIZE counts 64-B units as if they were 32-B)')
+print('gemm_source_hash', bench.gemm_source_hash())
+print('libmerlot_hip.so sha256', hashlib.sha256(open('merlot_amd/libmerlot_hip.so', 'rb').read()).hexdigest())
+vals = {}
 for c in ['FETCH_SIZE', 'WRITE_SIZE']:
-    rows = list(csv.DictReader(open('$R/gpurun_out/pmc_%s.csv' % c)))
+    rows = list(csv.DictReader(open('gpurun_out/pmc_%s.csv' % c)))
     agg = collections.OrderedDict()
     for r in rows:
-        k = r['Kernel_Name'][:80]
-        if 'gemm' not in k and 'attn' not in k: continue
+        k = r['Kernel_Name']
+        if not any(t in k for t in ('gemm', 'attn', 'quantize', 'amax', 'tn_reduce')):
+            continue
+        k = k.replace('(anonymous namespace)::', '').split('(')[0][:90]
         d = agg.setdefault(k, [0.0, 0])
         d[0] += float(r['Counter_Value']); d[1] += 1
     for k, (v, n) in agg.items():
-        print(c, k, 'per-launch KB:', v / n)
+        vals.setdefault(k, {})[c] = v / n
+        print('%s | %s | launches %d | KB_per_launch %.1f' % (c, k, n, v / n))
+print('# kernel | HBM MB per launch = (2*FETCH + WRITE) KiB / 1024')
+for k, d in vals.items():
+    if 'FETCH_SIZE' in d and 'WRITE_SIZE' in d:
+        print('HBM_MB | %s | %.1f' % (k, (2 * d['FETCH_SIZE'] + d['WRITE_SIZE']) / 1024.0))
 PY
+cat gpurun_out/r02_traffic.txt

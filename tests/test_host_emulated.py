@@ -337,3 +337,35 @@ def test_config_variants_match_reference_program(emu, name):
         if k.startswith(p + 'grad/'):
             n = k[len(p) + 5:]
             assert rel_l2(torch.from_numpy(head(gt[n].numpy())), torch.from_numpy(fx[k])) < 0.12, n
+
+
+def test_token_id_range_assertion_is_deferred_not_dropped(emu, oracle_run):
+    """utils/model_utils.py:256-258 asserts 0 <= id < vocab inside the graph.  Here the flag is computed on the device (no
+    host round trip in the middle of the step), the lookup is clamped (memory-safe), and the error is raised by
+    `check_token_ids()` / by the trainer one step late -- and at once in inference mode."""
+    from merlot_amd import MerlotModel, ParamStore, model_fn_builder
+    from merlot_amd.config import NeatConfig
+    from merlot_amd.train import Trainer
+    cfg, w, b, m, loss, info = oracle_run
+    st = ParamStore(cfg, 'cpu', seed=0)
+    good = MerlotModel(cfg, True, False, b['image'], b['input_ids'], mask_input=True, shuffled_idx_img=torch.from_numpy(b['shuffled_idx_img']),
+                       params=st, noise={k: torch.from_numpy(v) for k, v in b['noise'].items()})
+    good.check_token_ids()
+    assert not bool(good.token_id_flag())
+    ids = b['input_ids'].clone()
+    ids[0, 0, 3] = cfg['vocab_size']                      # one past the end
+    bad = MerlotModel(cfg, True, False, b['image'], ids, mask_input=True, shuffled_idx_img=torch.from_numpy(b['shuffled_idx_img']),
+                      params=st, noise={k: torch.from_numpy(v) for k, v in b['noise'].items()})
+    assert bool(bad.token_id_flag())
+    with pytest.raises(ValueError, match='out of range'):
+        bad.check_token_ids()
+    # the trainer: the step that embedded the bad id completes, the next call raises and names it
+    config = NeatConfig.from_dict({'model': dict(cfg), 'data': {'num_chunks': 4, 'chunk_text_len': 32},
+                                   'device': {'use_tpu': False, 'output_dir': '/tmp/unused'},
+                                   'optimizer': {'type': 'adam_optimizer', 'learning_rate': 1e-4, 'num_train_steps': 10, 'num_warmup_steps': 0}})
+    tr = Trainer(config, 'cpu', None, seed=0)
+    feats = {'images': b['image'], 'input_ids': ids, 'shuffled_idx_img': torch.from_numpy(b['shuffled_idx_img']),
+             'video_src_ids': torch.from_numpy(b['video_src_ids']), 'noise': {k: torch.from_numpy(v) for k, v in b['noise'].items()}}
+    tr.step(feats)
+    with pytest.raises(ValueError, match='training step 0'):
+        tr.check_inputs()
