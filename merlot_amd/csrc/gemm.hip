@@ -1516,9 +1516,6 @@ int launch_persist_dyn_one(GemmNTArgs& a, hipStream_t s) {
 #endif
     int grid = a.ntm * a.ntn;
     if (grid > 256) grid = 256;
-#ifdef MERLOT_EXPERIMENTS
-    if (const char* e = getenv("MERLOT_NT_GRID")) grid = min(grid, atoi(e));      // experiments: fewer workgroups than CUs
-#endif
     const int slot = (int)(g_persist_seq.fetch_add(1) % PERSIST_SLOTS);   // counter slots are handed out round-robin; a slot is
                                                                           // free again long before 1024 later launches are issued
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), PERSIST_LDS, s, a, slot);

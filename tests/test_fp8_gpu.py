@@ -141,7 +141,8 @@ def test_config5_geometry_fp8_forward_loss_within_2e2_of_bf16():
     out = {}
     b = None
     for fp8 in (False, True):
-        cfg = tiny_config(image_size=[384, 384], num_chunks_in_group=16, max_position_embeddings=1024, fp8_forward=fp8)
+        cfg = tiny_config(image_size=[384, 384], num_chunks_in_group=16, max_position_embeddings=1024, fp8_forward=fp8,
+                          masking_use_attn=False)      # MLM targets from the noise alone: identical in both runs
         if b is None:
             b = synth_batch(cfg, E=1, num_chunks=16, seed=3)
             w = mo.init_weights(cfg, 0)
@@ -161,13 +162,9 @@ def test_config5_geometry_fp8_forward_loss_within_2e2_of_bf16():
     for a, c in zip(out[False]['losses'], out[True]['losses']):
         assert abs(a - c) < 2e-2, (out[False]['losses'], out[True]['losses'])
     assert abs(sum(out[False]['losses']) - sum(out[True]['losses'])) < 2e-2
-    assert rel_l2(out[True]['viz'], out[False]['viz']) < 5e-2
-    # the text side only where both runs masked the same tokens (the top-k of the attention sums may flip on near-ties,
-    # and a flipped choice replaces that position's input): most choices must agree, and there the states must too
-    ma, mb = set(out[False]['masked'].flatten().tolist()), set(out[True]['masked'].flatten().tolist())
-    assert len(ma & mb) >= 0.6 * len(ma)          # (random-init attention is near uniform: its top-k is noise-sensitive)
-    if ma == mb:
-        assert rel_l2(out[True]['lang'], out[False]['lang']) < 5e-2
-    rels = [rel_l2(out[True]['grads'][k], g) for k, g in out[False]['grads'].items() if float(g.norm()) > 0]
+    assert torch.equal(out[True]['masked'], out[False]['masked'])
+    for k in ('viz', 'lang'):
+        assert rel_l2(out[True][k], out[False][k]) < 5e-2, k
     assert all(torch.isfinite(g).all() for g in out[True]['grads'].values())
+    rels = [rel_l2(out[True]['grads'][k], g) for k, g in out[False]['grads'].items() if float(g.norm()) > 0]
     assert sorted(rels)[len(rels) // 2] < 0.15, sorted(rels)[len(rels) // 2]
