@@ -26,6 +26,12 @@ int merlot_probe_cu_hog(int blocks, int lds_bytes, int64_t cycles, void* sink, m
  * come from those reads).  out: int64 [blocks][4] = {shader-clock delta, 100 MHz wall-clock delta, 0, 0}. */
 int merlot_probe_mfma_rate(int blocks, int iters, int mode, void* out, void* sink, merlot_stream_t stream);
 
+/* experiment helper: `blocks` 8-wave workgroups each write `tiles` 256 x 256 bf16 tiles of a [tiles_m * 256, ...] matrix (row stride ld)
+ * with the GEMM epilogue's store pattern; rows_per_instr 8 / 4 / 2 / 1 = 128 / 256 / 512 / 1024 contiguous bytes per row and
+ * instruction; mode bit 0: vmcnt(0) + barrier per tile, bit 1: 160 KiB LDS per workgroup.  clk: int64 [blocks] shader clocks. */
+int merlot_probe_store(void* out, int64_t ld, int tiles_m, int blocks, int tiles, int rows_per_instr, int mode, void* clk,
+                       merlot_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,6 +54,7 @@ struct GemmNTArgs {
     const float* scale_b;
     int ntm, ntn;
     int cg;               // persistent kernel: tiles are enumerated in groups of `cg` tile columns (0: plain row-major)
+    int dephase;          // experiments only: workgroup i of an XCD starts ((i * 5) & 7) * dephase shader cycles late (0: off)
     int dbg;              // experiments only: 1 = skip epilogue, 2 = skip main loop
 };
 
@@ -1092,8 +1093,8 @@ constexpr int PERSIST_SLOTS = 1024;
 // experiments (dbg & 512): per-workgroup timeline, [wg][tile-slot][0..2] = s_memtime at tile start / loop end / epilogue end
 constexpr int TRACE_TILES = 32;
 #ifdef MERLOT_EXPERIMENTS
-__device__ long long g_persist_trace[256 * TRACE_TILES * 4];
-#define PERSIST_TRACE(i, j, v) g_persist_trace[((i) * TRACE_TILES + trace_i) * 4 + (j)] = (v)
+__device__ long long g_persist_trace[256 * TRACE_TILES * 8];
+#define PERSIST_TRACE(i, j, v) g_persist_trace[((i) * TRACE_TILES + trace_i) * 8 + (j)] = (v)
 #else
 #define PERSIST_TRACE(i, j, v) ((void)0)
 #endif
@@ -1923,7 +1924,7 @@ extern "C" int merlot_patch_embed_wgrad(const void* patches, int64_t rows, int K
 
 #ifdef MERLOT_EXPERIMENTS
 extern "C" int merlot_probe_persist_trace(void* dst, int64_t bytes, merlot_stream_t stream) {
-    MERLOT_CHECK(dst && bytes > 0 && bytes <= (int64_t)sizeof(long long) * 256 * TRACE_TILES * 4, MERLOT_ESHAPE,
+    MERLOT_CHECK(dst && bytes > 0 && bytes <= (int64_t)sizeof(long long) * 256 * TRACE_TILES * 8, MERLOT_ESHAPE,
                  "merlot_probe_persist_trace: bad size");
     hipError_t e = hipMemcpyFromSymbolAsync(dst, HIP_SYMBOL(g_persist_trace), (size_t)bytes, 0, hipMemcpyDeviceToDevice,
                                             (hipStream_t)stream);

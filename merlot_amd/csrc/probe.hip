@@ -107,6 +107,48 @@ __global__ __launch_bounds__(512) void probe_mfma_rate_kernel(int iters, int mod
         out[blockIdx.x * 4 + 1] = r1 - r0;
     }
 }
+
+// Store-rate probe (experiments): `blocks` 8-wave workgroups each write `tiles` output tiles of 256 x 256 bf16 (row stride ld
+// elements) the way the GEMM epilogue does -- wave w owns rows (w >> 2) * 128 .. + 127, columns (w & 3) * 64 .. + 63, one
+// 16-B store per lane and instruction -- with `rows_per_instr` rows covered by one instruction (8: 128 B per row, the
+// epilogue's pattern; 4 / 2 / 1 emulate 256 / 512 / 1024 contiguous bytes per row by letting the wave own a wider strip).
+// mode bit 0: s_waitcnt vmcnt(0) + s_barrier after every tile (as the epilogue does); bit 1: 160 KiB of LDS (one workgroup per CU).
+__global__ __launch_bounds__(512) void probe_store_kernel(bf16* __restrict__ out, long long ld, int tiles_m, int tiles, int rows_per_instr,
+                                                          int mode, long long* __restrict__ clk) {
+    extern __shared__ char pst_lds[];
+    if (mode & 2) pst_lds[threadIdx.x] = 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lanes_per_row = 64 / rows_per_instr;          // 8, 16, 32, 64 lanes x 16 B
+    const int cols_per_wave = lanes_per_row * 8;            // 64 .. 512 columns
+    const int strips = 256 / cols_per_wave > 0 ? 256 / cols_per_wave : 1;   // column strips per tile
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (bf16)(float)(lane + e);
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    for (int t = 0; t < tiles; ++t) {
+        const int tile = blockIdx.x + t * gridDim.x;
+        const int tm = tile % tiles_m, tn = tile / tiles_m;
+        bf16* base = out + (long long)tm * 256 * ld + (long long)tn * 256;
+        // every wave writes 8192 elements = 16 instructions
+        const int rows_per_wave = 8192 / (cols_per_wave < 256 ? cols_per_wave : 256);
+        const int strip = wave % strips, rblk = wave / strips;
+        const int wcols = cols_per_wave < 256 ? cols_per_wave : 256;
+        for (int i = 0; i < 16; ++i) {
+            const int idx = i * 64 + lane;                  // 16-B unit inside the wave's block, row-major
+            const int units_per_row = wcols / 8;
+            const int r = rblk * rows_per_wave + idx / units_per_row;
+            const int c = strip * wcols + (idx % units_per_row) * 8;
+            *reinterpret_cast<bf16x8*>(base + (long long)r * ld + c) = v;
+        }
+        if (mode & 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) clk[blockIdx.x] = t1 - t0;
+}
 }  // namespace
 
 extern "C" int merlot_probe_mfma_rate(int blocks, int iters, int mode, void* out, void* sink, merlot_stream_t stream) {
@@ -138,4 +180,19 @@ extern "C" int merlot_probe_cu_hog(int blocks, int lds_bytes, int64_t cycles, vo
     hipLaunchKernelGGL(probe_cu_hog_kernel, dim3(blocks), dim3(64), lds_bytes, (hipStream_t)stream, (long long)cycles,
                        (unsigned int*)sink);
     return merlot_launch_status("merlot_probe_cu_hog");
+}
+
+extern "C" int merlot_probe_store(void* out, int64_t ld, int tiles_m, int blocks, int tiles, int rows_per_instr, int mode, void* clk,
+                                  merlot_stream_t stream) {
+    MERLOT_CHECK(out && clk && blocks > 0 && tiles > 0 && (rows_per_instr == 8 || rows_per_instr == 4 || rows_per_instr == 2 || rows_per_instr == 1),
+                 MERLOT_ESHAPE, "merlot_probe_store: bad arguments");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(probe_store_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(probe_store_kernel, dim3(blocks), dim3(512), (mode & 2) ? 160 * 1024 : 1024, (hipStream_t)stream, (bf16*)out,
+                       (long long)ld, tiles_m, tiles, rows_per_instr, mode, (long long*)clk);
+    return merlot_launch_status("merlot_probe_store");
 }

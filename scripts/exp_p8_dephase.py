@@ -10,7 +10,7 @@ from exp_epi import bench
 T = int(os.environ.get('T', 101376))
 torch.manual_seed(0)
 os.environ['MERLOT_NT_CFG_DYN'] = '22'
-for name, N, K, epi in [('qkv', 2304, 768, 'none'), ('fc1', 3072, 768, 'gelu'), ('fc2', 768, 3072, 'residual'), ('dgrad_fc2', 3072, 768, 'dgelu')]:
+for name, N, K, epi in [('qkv', 2304, 768, 'none'), ('proj', 768, 768, 'residual'), ('fc1', 3072, 768, 'gelu'), ('fc2', 768, 3072, 'residual'), ('dgrad_fc2', 3072, 768, 'dgelu')]:
     a = torch.randn(T, K, device='cuda').bfloat16()
     b = (torch.randn(N, K, device='cuda') * 0.02).bfloat16()
     bias = torch.randn(N, device='cuda') * 0.1
@@ -23,7 +23,7 @@ for name, N, K, epi in [('qkv', 2304, 768, 'none'), ('fc1', 3072, 768, 'gelu'), 
     os.environ['MERLOT_P8_DEPHASE'] = '0'
     bench(fn, 40)
     row = []
-    for unit in (0, 3000, 6000, 12000, 24000, 0):
+    for unit in (0, 2000, 4000, 8000, 16000, 0):
         os.environ['MERLOT_P8_DEPHASE'] = str(unit)
         t = bench(fn, 30)
         row.append(f'{unit}: {t:6.1f} us')
