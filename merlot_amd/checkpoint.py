@@ -432,9 +432,21 @@ def write_checkpoint(prefix, tensors, block_size=262144, update_state=True):
     os.replace(prefix + '.data-00000-of-00001.tmp', prefix + '.data-00000-of-00001')
     os.replace(prefix + '.index.tmp', prefix + '.index')
     if update_state:
+        # the `checkpoint` state file of tf.train.Saver: newest prefix + every prefix still on disk (the reference's
+        # RunConfig keeps them all: keep_checkpoint_max=None, model/train.py), written atomically
         base = os.path.basename(prefix)
-        with open(os.path.join(d or '.', 'checkpoint'), 'w') as f:
-            f.write(f'model_checkpoint_path: "{base}"\nall_model_checkpoint_paths: "{base}"\n')
+        state = os.path.join(d or '.', 'checkpoint')
+        older = []
+        if os.path.exists(state):
+            for line in open(state):
+                m = re.match(r'^all_model_checkpoint_paths: "(.*)"\s*$', line)
+                if m and m.group(1) != base and os.path.exists(os.path.join(d or '.', m.group(1) + '.index')):
+                    older.append(m.group(1))
+        with open(state + '.tmp', 'w') as f:
+            f.write(f'model_checkpoint_path: "{base}"\n')
+            for b in older + [base]:
+                f.write(f'all_model_checkpoint_paths: "{b}"\n')
+        os.replace(state + '.tmp', state)
 
 
 # ---- the reference's use of checkpoints -------------------------------------------------------------------------------
@@ -468,6 +480,17 @@ def variable_names(store, optimizer=None):
     return names
 
 
+def _check_slot_dtypes(sub, flat, slot, where):
+    """Adam slots are stored in the optimizer's own dtype (bf16 m; bf16 v with the update's sign bit folded in under
+    use_bfloat16_adam, utils/optimization.py:267-288).  Loading them into an optimizer that keeps the other encoding would
+    turn the sign-encoded v into negative second moments (NaN at the first sqrt) or silently drop the encoding."""
+    for name, t in sub.items():
+        have = t.dtype if isinstance(t, torch.Tensor) else torch.as_tensor(np.asarray(t)).dtype
+        if have != flat.dtype:
+            raise CheckpointError(f'{where}: {name} is stored as {have} but this optimizer keeps its {slot[1:]} slots as '
+                                  f'{flat.dtype} (optimizer.use_bfloat16_adam differs from the run that wrote the checkpoint)')
+
+
 def init_from_checkpoint(store, init_checkpoint, optimizer=None, reference_name_transform=None):
     """model/modeling.py:724-738: every variable of the model (and, when training, of the optimizer) that the
     checkpoint also holds under the same name is overwritten; the rest keep their initial values; `global_step` is
@@ -481,6 +504,7 @@ def init_from_checkpoint(store, init_checkpoint, optimizer=None, reference_name_
         for slot, flat in (('/adam_m', optimizer.m), ('/adam_v', optimizer.v)):
             sub = {k: v for k, v in loaded.items() if k.endswith(slot)}
             if sub:
+                _check_slot_dtypes(sub, flat, slot, reader.prefix)
                 store.load_tf_weights(sub, strict=False, getter=lambda n, flat=flat: store.view(flat, n), suffix=slot)
     return initialized
 
@@ -514,6 +538,7 @@ def restore_checkpoint(model_dir_or_prefix, store, optimizer=None):
     if optimizer is not None:
         for slot, flat in (('/adam_m', optimizer.m), ('/adam_v', optimizer.v)):
             sub = {k: v for k, v in loaded.items() if k.endswith(slot)}
+            _check_slot_dtypes(sub, flat, slot, reader.prefix)
             store.load_tf_weights(sub, strict=True, getter=lambda n, flat=flat: store.view(flat, n), suffix=slot)
         optimizer.step_count = step
     return step

@@ -15,6 +15,7 @@ and tests can inject the exact draws the reference graph consumed.  There is no 
 import glob
 import io
 import os
+import itertools
 import queue
 import struct
 import threading
@@ -458,6 +459,9 @@ def collate(examples, config, noise, device, is_training=True, packed=None, stag
                                                      torch.from_numpy(noise['u_sel']).to(device),
                                                      torch.from_numpy(noise['u_perm']).to(device), B, n, 16)
     feats['images'] = images                                # [bs * nc, H, W, 3]
+    if 'mask' in noise:
+        feats['noise'] = {k: (v.pin_memory() if torch.device(device).type == 'cuda' else v).to(device, non_blocking=True)
+                          for k, v in noise['mask'].items()}
     if config.get('transpose_input', False):
         feats['images'] = images.permute(1, 2, 3, 0).contiguous()
     return feats
@@ -561,14 +565,35 @@ class InputPipeline(object):
         self._stream = None
 
     def _records(self):
+        """model/dataloader.py:139-150: shuffled file list -> `parallel_interleave(TFRecordDataset, cycle_length =
+        min(num_threads, num_files), sloppy)` when training: ONE record at a time from each of cycle_length open files in
+        turn (an exhausted file is replaced by the next one of the list), so a batch mixes many files before the shuffle
+        buffer even sees it; evaluation reads the files one after another in order."""
         while True:
             files = list(self.files)
-            if self.is_training:
-                self.rng.shuffle(files)
-            for f in files:
-                yield from scan_tfrecords(f)              # (path, offset, length): whoever parses the record reads it
             if not self.is_training:
+                for f in files:
+                    yield from scan_tfrecords(f)          # (path, offset, length): whoever parses the record reads it
                 return
+            self.rng.shuffle(files)
+            pending = iter(files)
+            cycle = max(1, min(int(self.merged.get('num_threads', 64)), len(files)))   # the yaml's value, not the core-bounded one
+            open_its = [scan_tfrecords(f) for f in itertools.islice(pending, cycle)]
+            while open_its:
+                nxt = []
+                for it in open_its:
+                    rec = next(it, None)
+                    if rec is None:                          # this file is done: open the next one in its slot
+                        f = next(pending, None)
+                        if f is None:
+                            continue
+                        it = scan_tfrecords(f)
+                        rec = next(it, None)
+                        if rec is None:
+                            continue
+                    yield rec
+                    nxt.append(it)
+                open_its = nxt
 
     def _shuffled(self):
         if not self.is_training:
@@ -606,7 +631,16 @@ class InputPipeline(object):
                 for shm in shms:
                     shm.close()
                     shm.unlink()
-                yield examples, draw_batch_noise(self.rng, self.batch_size, nc, self.merged), packed
+                noise = draw_batch_noise(self.rng, self.batch_size, nc, self.merged)
+                if self.is_training and 'vocab_size' in self.merged:
+                    # the random draws of mask_inputs (model/modeling.py:445-481), made HERE in the loader thread from the
+                    # rank-keyed generator: the training step neither draws on the host nor uploads synchronously
+                    from .modeling import draw_mask_noise
+                    n = self.merged['num_chunks_in_group']
+                    g = torch.Generator().manual_seed(int(self.rng.integers(0, 2 ** 62)))
+                    noise['mask'] = draw_mask_noise(self.batch_size * nc // n, n * self.merged.get('chunk_text_len', 32), self.merged,
+                                                    self.merged['vocab_size'], g)
+                yield examples, noise, packed
                 batch = []
 
     def close(self):

@@ -230,3 +230,24 @@ def test_table_round_trip_and_corruption_properties():
             assert got == items
 
     run()
+
+
+def test_slot_dtype_mismatch_is_an_error_and_the_state_file_keeps_every_checkpoint(tmp_path):
+    """a use_bfloat16_adam checkpoint (sign-encoded bf16 v) restored into an fp32 optimizer would give negative
+    second moments; and the `checkpoint` state file lists every prefix still on disk (keep_checkpoint_max=None), written
+    atomically."""
+    cfg, st, opt = _store_and_opt(1, bf16_adam=True)
+    p1 = ck.save_checkpoint(str(tmp_path), st, opt)
+    opt.step_count = 5000
+    p2 = ck.save_checkpoint(str(tmp_path), st, opt)
+    state = open(tmp_path / 'checkpoint').read().splitlines()
+    assert state[0] == 'model_checkpoint_path: "model.ckpt-5000"'
+    assert state[1:] == ['all_model_checkpoint_paths: "model.ckpt-4321"', 'all_model_checkpoint_paths: "model.ckpt-5000"']
+    assert not os.path.exists(tmp_path / 'checkpoint.tmp')
+    assert ck.latest_checkpoint(str(tmp_path)) == p2 and p1 != p2
+    _, st32, opt32 = _store_and_opt(2, bf16_adam=False)
+    with pytest.raises(ck.CheckpointError, match='use_bfloat16_adam'):
+        ck.restore_checkpoint(str(tmp_path), st32, opt32)
+    with pytest.raises(ck.CheckpointError, match='use_bfloat16_adam'):
+        ck.init_from_checkpoint(st32, p2, opt32)
+    ck.init_from_checkpoint(st32, p2, None)                # weights alone are always fine

@@ -197,7 +197,7 @@ def test_bench_py_code_path_two_ranks_emulated(tmp_path):
     port = _free_port()
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
-           '--examples', '2', '--cpu-emulate']
+           '--examples', '1', '--cpu-emulate']
     env = dict(os.environ, OMP_NUM_THREADS='4')
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=850, env=env, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -205,6 +205,6 @@ def test_bench_py_code_path_two_ranks_emulated(tmp_path):
     assert len(lines) == 1, out.stdout[-2000:]                   # rank 0 only
     res = json.loads(lines[0])
     assert res['n_gpus'] == 2 and res['steps'] == 2 and res['warmup'] == 1 and res['scaling'] == 'weak'
-    assert res['config']['parallelism'] == 'dp2' and res['config']['segments_per_gpu_per_step'] == 8
-    assert abs(res['value'] - 2 * 8 * 2 / (res['ms_per_step'] * 2 / 1e3)) < 1e-6 * res['value']     # whole-job aggregate
+    assert res['config']['parallelism'] == 'dp2' and res['config']['segments_per_gpu_per_step'] == 4
+    assert abs(res['value'] - 2 * 4 * 2 / (res['ms_per_step'] * 2 / 1e3)) < 1e-6 * res['value']     # whole-job aggregate
     assert res['config']['final_loss'] == res['config']['final_loss'] and res['config']['final_loss'] < 30.0
