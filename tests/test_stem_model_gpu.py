@@ -62,4 +62,56 @@ def test_hip_model_with_resnet_stem_forward_backward():
     rels = {k: rel_l2(gt[k], v.grad) for k, v in w.items()
             if v.grad is not None and ('resnet50lite' in k or 'conv_postresnet_proj' in k)}
     assert len(rels) == 56
-    assert max(rels.values()) < 0.45 and np.median(list(rels.values())) < 0.25, sorted(rels.items(), key=lambda kv: -kv[1])[:5]
+    # two realisations of the bf16 value + gradient rounding through 23 GroupNorm'd layers: 0.18-0.20 median, 0.29-0.33 max at every
+    # frame size (scripts/exp_stem_grad_tol.py) -- noise, not bias: the directions agree (cosine), and see the next test
+    assert max(rels.values()) < 0.36 and np.median(list(rels.values())) < 0.22, sorted(rels.items(), key=lambda kv: -kv[1])[:5]
+    cos = {k: float(torch.dot(gt[k].flatten().float().cpu(), w[k].grad.flatten()) / (gt[k].float().norm().cpu() * w[k].grad.norm() + 1e-30))
+           for k in rels}
+    assert min(cos.values()) > 0.93 and np.median(list(cos.values())) > 0.975, sorted(cos.items(), key=lambda kv: kv[1])[:5]
+
+
+def test_hip_stem_gradient_is_the_derivative_of_the_hip_forward():
+    """VERDICT r1 weak f: a parity check of the stem's backward that the bf16 rounding noise of a per-tensor comparison cannot
+    blur.  L(w) = <viz hidden states, cot> is evaluated by the HIP forward at w +- h d for directions d built from the
+    ORACLE's gradients (all 56 stem tensors together, and each third of the stem alone, every tensor normalised): the central
+    difference, <g_hip, d> and <g_oracle, d> must agree -- the sum over ~10^5 parameters averages the rounding noise away,
+    a wrong scale / missing term in any layer's backward does not average away."""
+    from merlot_amd import MerlotModel, ParamStore
+    cfg = tiny_config(resnet_layers=[1, 1, 2])
+    w = mo.init_weights(cfg, 2)
+    for t in w.values():
+        t.requires_grad_(True)
+    b = synth_batch(cfg, E=1, num_chunks=4, seed=4)
+    with mo.bf16_stem():
+        m = mo.MerlotOracle(cfg, w, b['image'], b['input_ids'], mask_input=False, shuffled_idx_img=b['shuffled_idx_img'])
+    cot = torch.randn(m.encoder_hidden_states['viz'].shape, generator=torch.Generator().manual_seed(0))
+    (m.encoder_hidden_states['viz'] * cot).sum().backward()
+    stem = sorted(k for k, v in w.items() if v.grad is not None and ('resnet50lite' in k or 'conv_postresnet_proj' in k))
+    assert len(stem) == 56
+
+    def hip(weights, backward):
+        st = ParamStore(cfg, 'cuda', seed=0)
+        st.load_tf_weights({k: v.detach() for k, v in weights.items()})
+        st.zero_grad()
+        ctx = torch.enable_grad() if backward else torch.no_grad()
+        with ctx:
+            pm = MerlotModel(cfg, True, False, b['image'].cuda(), b['input_ids'].cuda(), mask_input=False,
+                             shuffled_idx_img=torch.from_numpy(b['shuffled_idx_img']).cuda(), params=st)
+            loss = (pm.encoder_hidden_states['viz'].double() * cot.cuda().double()).sum()
+            if backward:
+                loss.float().backward()
+        torch.cuda.synchronize()
+        return float(loss), (st.export_tf_grads() if backward else None)
+
+    _, g_hip = hip(w, True)
+    thirds = [stem[i::3] for i in range(3)]
+    for names in [stem] + thirds:
+        d = {k: (w[k].grad / (w[k].grad.norm() + 1e-30)) * w[k].detach().norm() for k in names}     # a 1.0-relative move of every tensor ...
+        h = 1e-4     # ... scaled to 1e-4: L is strongly curved along d (central differences: 142 k at 2e-2, 591 k at 5e-4, 623 k at 1e-4)
+        plus = {k: (v.detach() + h * d[k]) if k in d else v.detach() for k, v in w.items()}
+        minus = {k: (v.detach() - h * d[k]) if k in d else v.detach() for k, v in w.items()}
+        fd = (hip(plus, False)[0] - hip(minus, False)[0]) / (2 * h)
+        a_hip = sum(float((g_hip[k].float().cpu() * d[k]).sum()) for k in names)
+        a_orc = sum(float((w[k].grad * d[k]).sum()) for k in names)
+        assert abs(a_hip - a_orc) < 0.04 * abs(a_orc), (len(names), a_hip, a_orc, fd)          # measured: 1.7 %
+        assert abs(a_hip - fd) < 0.04 * abs(fd), (len(names), a_hip, a_orc, fd)                # measured: 1.2 %
