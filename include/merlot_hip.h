@@ -82,9 +82,10 @@ int merlot_quantize_e4m3(const void* x, int64_t rows, int64_t cols, int64_t ldx,
                          merlot_stream_t stream);
 /* C[M,N] = epilogue(alpha * scale_a[0] * scale_b[0] * A8[M,K] * B8t[N,K]^T + bias): merlot_gemm_bf16_nt on e4m3 operands.
  * scale_a / scale_b point at the DEQUANTISATION factor of each operand in device memory (&scale[1] of
- * merlot_quantize_e4m3).  fp32 accumulation; epilogues, bias, aux_in / aux_out, dropout and the C dtypes as for the bf16
+ * merlot_quantize_e4m3).  A may instead (or also) carry per-ROW factors row_scale_a (f32 [M], from merlot_ln_fwd_q8;
+ * then scale_a may be NULL): C[m, :] is multiplied by row_scale_a[m].  fp32 accumulation; epilogues, bias, aux_in / aux_out, dropout and the C dtypes as for the bf16
  * entry.  K % 128 == 0, K >= 256, lda / ldb in elements (= bytes) and multiples of 16. */
-int merlot_gemm_fp8_nt(const void* A8, int64_t lda, const float* scale_a, const void* B8t, int64_t ldb,
+int merlot_gemm_fp8_nt(const void* A8, int64_t lda, const float* scale_a, const float* row_scale_a, const void* B8t, int64_t ldb,
                        const float* scale_b, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, float alpha,
                        int epilogue, int out_f32, const float* bias, const void* aux_in, int64_t ld_aux_in,
                        void* aux_out, int64_t ld_aux_out, float dropout_p, uint64_t dropout_seed,
@@ -120,6 +121,11 @@ int merlot_patch_embed_wgrad(const void* patches, int64_t rows, int K, const voi
  * (may be NULL when no backward is needed).  H % 256 == 0, H <= 2048. */
 int merlot_ln_fwd(const void* x, int x_f32, const float* gamma, const float* beta, void* y_bf16, float* y_f32,
                   float* mean, float* rstd, int64_t rows, int H, float eps, merlot_stream_t stream);
+/* merlot_ln_fwd that ALSO emits the e4m3 copy the fp8 GEMM behind this LayerNorm consumes (config #5: QKV, fc1):
+ * y_fp8[rows, H] = e4m3(bf16(y) * 448 / max|bf16(y[row])|), row_scale[row] = max|.| / 448 (per-ROW scaling: the wave that
+ * normalises a row owns all of it).  y_bf16 may be NULL when no consumer needs it. */
+int merlot_ln_fwd_q8(const void* x, int x_f32, const float* gamma, const float* beta, void* y_bf16, void* y_fp8,
+                     float* row_scale, float* mean, float* rstd, int64_t rows, int H, float eps, merlot_stream_t stream);
 /* dx = LN'(dy) (+ dres) ; dgamma/dbeta (f32 [H]) are ACCUMULATED with atomics.  dy, x, dres, dx each bf16
  * or f32 per flag; dres may be NULL.
  * Optional fused tail for the residual stream (all NULL/0 to disable): dcolsum[H] += column sums of d_branch, where

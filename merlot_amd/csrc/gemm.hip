@@ -52,6 +52,7 @@ struct GemmNTArgs {
                           // layer whose output gradient this GEMM produces; only kernels that say so support it (else host fallback)
     const float* scale_a; // fp8 kernels only: device scalars, the per-tensor dequantisation factors of A and B (alpha *= both)
     const float* scale_b;
+    const float* row_scale;  // fp8 kernels only, optional: device f32 [M], per-ROW dequantisation factors of A (merlot_ln_fwd_q8)
     int ntm, ntn;
     int cg;               // persistent kernel: tiles are enumerated in groups of `cg` tile columns (0: plain row-major)
     int dephase;          // experiments only: workgroup i of an XCD starts ((i * 5) & 7) * dephase shader cycles late (0: off)
@@ -751,19 +752,23 @@ __global__ __launch_bounds__(C::NT) void gemm_nt_ring_kernel(const GemmNTArgs p)
 // Counted vmcnt stays valid across the epilogue's own loads/stores: loads complete in order, so "<= (S-2)*LOADS
 // outstanding" still implies stage t has landed; stores only make the wait more conservative.
 // ------------------------------------------------------------------------------------------------
-template <int EPI, bool OUT_F32>
+template <int EPI, bool OUT_F32, bool RS = false>
 __device__ __forceinline__ void slab_epilogue(const GemmNTArgs& p, const f32x16& acc0, const f32x16& acc1, char* slab,
                                               int m_base, int n_base, int lane) {
     // slab: [32 rows][64 cols] fp32, 16-B chunk index XOR (row & 15); acc0 = columns 0..31, acc1 = columns 32..63
     const int hi = lane >> 5;
     const int row = lane & 31;
+    float ra = p.alpha;                                  // RS (fp8 operands): times this row's dequantisation factor
+    if (RS) {
+        if (p.row_scale && m_base + row < p.M) ra *= p.row_scale[m_base + row];
+    }
 #pragma unroll
     for (int fj = 0; fj < 2; ++fj)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 t;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) t[e] = (fj ? acc1[4 * q + e] : acc0[4 * q + e]) * p.alpha;
+            for (int e = 0; e < 4; ++e) t[e] = (fj ? acc1[4 * q + e] : acc0[4 * q + e]) * ra;
             const int chunk = fj * 8 + 2 * q + hi;
             *reinterpret_cast<f32x4*>(slab + row * 256 + ((chunk ^ (row & 15)) << 4)) = t;
         }
@@ -808,7 +813,7 @@ __device__ __forceinline__ void slab_epilogue(const GemmNTArgs& p, const f32x16&
 // cost as much as the whole K=768 main loop was LATENCY: `bias` was re-loaded after every store (may alias C) and
 // each residual / pre-activation row segment was loaded right where it was consumed, 16 dependent round trips per
 // wave per tile.  Here bias is read once per tile and the auxiliary operand runs PF passes (1 KiB each) ahead.
-template <int EPI, bool OUT_F32, int FM = 2, int FN = 4, int PF = 8>
+template <int EPI, bool OUT_F32, int FM = 2, int FN = 4, int PF = 8, bool RS = false>
 __device__ __forceinline__ void fast_tile_epilogue(const GemmNTArgs& p, f32x16 (&acc)[FM][FN], char* slab, int m_base,
                                                    int n_base, int lane) {
     static_assert(FM * FN == 8, "a wave owns 8 accumulators = 4 slabs of 32 x 64");
@@ -848,13 +853,17 @@ __device__ __forceinline__ void fast_tile_epilogue(const GemmNTArgs& p, f32x16 (
 #pragma unroll
     for (int sl = 0; sl < 4; ++sl) {
         const int fi = sl / NFP, fp = sl % NFP;
+        float ra = p.alpha;                              // RS (fp8 operands): times this row's dequantisation factor
+        if (RS) {
+            if (p.row_scale) ra *= p.row_scale[m_base + fi * 32 + row];
+        }
 #pragma unroll
         for (int fj = 0; fj < 2; ++fj)
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
                 f32x4 t;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) t[e] = acc[fi][2 * fp + fj][4 * q4 + e] * p.alpha;
+                for (int e = 0; e < 4; ++e) t[e] = acc[fi][2 * fp + fj][4 * q4 + e] * ra;
                 const int chunk = fj * 8 + 2 * q4 + hi;
                 *reinterpret_cast<f32x4*>(slab + row * 256 + ((chunk ^ (row & 15)) << 4)) = t;
             }
@@ -1836,12 +1845,12 @@ extern "C" int merlot_gemm_bf16_nt(const void* A, int64_t lda, const void* Bt, i
 // C = epilogue(alpha * scale_a[0] * scale_b[0] * A8 * B8^T + bias): e4m3 operands (merlot_quantize_e4m3), fp32 accumulation on the
 // MX-scaled MFMA with unit block scales, the bf16 kernel's epilogues.  ONE kernel (the 256 x 256 ping-pong kernel) -- shapes
 // it cannot take are an error, not a fallback.
-extern "C" int merlot_gemm_fp8_nt(const void* A8, int64_t lda, const float* scale_a, const void* B8t, int64_t ldb,
+extern "C" int merlot_gemm_fp8_nt(const void* A8, int64_t lda, const float* scale_a, const float* row_scale_a, const void* B8t, int64_t ldb,
                                   const float* scale_b, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, float alpha,
                                   int epilogue, int out_f32, const float* bias, const void* aux_in, int64_t ld_aux_in,
                                   void* aux_out, int64_t ld_aux_out, float dropout_p, uint64_t dropout_seed,
                                   merlot_stream_t stream) {
-    MERLOT_CHECK(A8 && B8t && C && scale_a && scale_b, MERLOT_ESHAPE, "merlot_gemm_fp8_nt: null operand");
+    MERLOT_CHECK(A8 && B8t && C && (scale_a || row_scale_a) && scale_b, MERLOT_ESHAPE, "merlot_gemm_fp8_nt: null operand");
     MERLOT_CHECK(M > 0 && N > 0 && K > 0 && M < (1LL << 31) && N < (1LL << 31), MERLOT_ESHAPE,
                  "merlot_gemm_fp8_nt: bad dims M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
     MERLOT_CHECK(((uintptr_t)A8 & 15) == 0 && ((uintptr_t)B8t & 15) == 0, MERLOT_EALIGN, "merlot_gemm_fp8_nt: A8/B8t must be 16-byte aligned");
@@ -1853,7 +1862,7 @@ extern "C" int merlot_gemm_fp8_nt(const void* A8, int64_t lda, const float* scal
     a.lda = lda; a.ldb = ldb; a.ldc = ldc;
     a.M = (int)M; a.N = (int)N; a.K = (int)K;
     a.alpha = alpha; a.bias = bias;
-    a.scale_a = scale_a; a.scale_b = scale_b;
+    a.scale_a = scale_a; a.scale_b = scale_b; a.row_scale = row_scale_a;
     a.aux_in = (const bf16*)aux_in; a.ld_aux_in = aux_in ? ld_aux_in : 0;
     a.aux_out = (bf16*)aux_out; a.ld_aux_out = aux_out ? ld_aux_out : 0;
     a.drop_thresh = dropout_p > 0.f ? (uint32_t)((double)dropout_p * 4294967296.0) : 0u;

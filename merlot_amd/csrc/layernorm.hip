@@ -37,7 +37,8 @@ template <int NS, typename TX>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, bf16* __restrict__ y16,
                                                      float* __restrict__ y32, float* __restrict__ mean_out,
-                                                     float* __restrict__ rstd_out, int64_t rows, float eps) {
+                                                     float* __restrict__ rstd_out, int64_t rows, float eps,
+                                                     uint8_t* __restrict__ y8 = nullptr, float* __restrict__ row_scale = nullptr) {
     constexpr int H = NS * 256;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
         }
     const float var = wave_sum(ss) * (1.0f / H);
     const float rstd = rsqrtf(var + eps);
+    float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         float g[4], bt[4], o[4];
@@ -73,6 +75,31 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
         }
         if (y16) store4(y16 + row * H + i * 256 + lane * 4, o);
         if (y32) store4(y32 + row * H + i * 256 + lane * 4, o);
+        if (y8) {                                        // keep what the bf16 consumer sees: quantise the bf16-ROUNDED row
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[i][e] = (float)(bf16)o[e];
+                amax = fmaxf(amax, fabsf(v[i][e]));
+            }
+        }
+    }
+    if (y8) {
+        // per-ROW e4m3 copy for the fp8 GEMM that consumes this LayerNorm (QKV / fc1): the wave owns the whole row, so the
+        // scale costs one wave reduction and the copy one extra byte per element in the pass that is already running
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+        const float sq = amax > 0.f ? 448.f / amax : 1.f;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            float f[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) f[e] = __builtin_fminf(__builtin_fmaxf(v[i][e] * sq, -448.f), 448.f);
+            int w = 0;
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w, false);
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w, true);
+            *reinterpret_cast<int*>(y8 + row * H + i * 256 + lane * 4) = w;
+        }
+        if (lane == 0) row_scale[row] = 1.f / sq;
     }
     if (lane == 0) {
         if (mean_out) mean_out[row] = mean;
@@ -174,14 +201,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
 
 template <int NS>
 int ln_fwd_launch(const void* x, int x_f32, const float* gamma, const float* beta, void* y16, float* y32, float* mean,
-                  float* rstd, int64_t rows, float eps, hipStream_t s) {
+                  float* rstd, int64_t rows, float eps, hipStream_t s, void* y8 = nullptr, float* row_scale = nullptr) {
     const dim3 grid(cdiv(rows, 4)), block(256);
     if (x_f32)
         hipLaunchKernelGGL((ln_fwd_kernel<NS, float>), grid, block, 0, s, (const float*)x, gamma, beta, (bf16*)y16, y32,
-                           mean, rstd, rows, eps);
+                           mean, rstd, rows, eps, (uint8_t*)y8, row_scale);
     else
         hipLaunchKernelGGL((ln_fwd_kernel<NS, bf16>), grid, block, 0, s, (const bf16*)x, gamma, beta, (bf16*)y16, y32,
-                           mean, rstd, rows, eps);
+                           mean, rstd, rows, eps, (uint8_t*)y8, row_scale);
     return merlot_launch_status("merlot_ln_fwd");
 }
 
@@ -231,6 +258,14 @@ extern "C" int merlot_ln_fwd(const void* x, int x_f32, const float* gamma, const
     MERLOT_CHECK(rows > 0, MERLOT_ESHAPE, "merlot_ln_fwd: rows must be > 0");
     hipStream_t s = (hipStream_t)stream;
     LN_DISPATCH_H(H, (ln_fwd_launch<NS>(x, x_f32, gamma, beta, y_bf16, y_f32, mean, rstd, rows, eps, s)));
+}
+
+extern "C" int merlot_ln_fwd_q8(const void* x, int x_f32, const float* gamma, const float* beta, void* y_bf16, void* y_fp8,
+                                float* row_scale, float* mean, float* rstd, int64_t rows, int H, float eps, merlot_stream_t stream) {
+    MERLOT_CHECK(x && gamma && beta && y_fp8 && row_scale, MERLOT_ESHAPE, "merlot_ln_fwd_q8: null operand");
+    MERLOT_CHECK(rows > 0, MERLOT_ESHAPE, "merlot_ln_fwd_q8: rows must be > 0");
+    hipStream_t s = (hipStream_t)stream;
+    LN_DISPATCH_H(H, (ln_fwd_launch<NS>(x, x_f32, gamma, beta, y_bf16, nullptr, mean, rstd, rows, eps, s, y_fp8, row_scale)));
 }
 
 extern "C" int merlot_ln_bwd(const void* dy, int dy_f32, const void* x, int x_f32, const float* mean, const float* rstd,

@@ -41,14 +41,18 @@ class StackW(object):
         self.ln_final = store.ln(f'{scope}/LayerNorm_ln_final')
 
 
-def _fwd_linear(x, lin, fp8, **kw):
-    """One forward Linear of the stack.  fp8 (BASELINE config #5, `model.fp8_forward`): both operands are quantised to e4m3
-    with per-tensor current scaling and the product runs on the fp8 kernel with fp32 accumulation; bias, epilogue and output
-    dtype are those of the bf16 path.  The backward always consumes the bf16 tensors (x is saved as before)."""
+def _fwd_linear(x, lin, fp8, x8=None, row_scale=None, **kw):
+    """One forward Linear of the stack.  fp8 (BASELINE config #5, `model.fp8_forward`): e4m3 operands, fp32 accumulation on the
+    fp8 kernel; bias, epilogue and output dtype are those of the bf16 path.  The activation arrives either already quantised
+    with per-ROW scales by the LayerNorm that produced it (x8, row_scale: QKV and fc1) or is quantised here with one
+    per-tensor scale (two passes over x: fc2); weights: per-tensor, per call.  The backward always consumes the bf16
+    tensors (x is saved as before)."""
     if not fp8:
         return ops.gemm_nt(x, lin.wb, bias=lin.b, **kw)
-    x8, sx = ops.quantize_e4m3(x)
     w8, sw = ops.quantize_e4m3(lin.wb)
+    if x8 is not None:
+        return ops.gemm_fp8_nt(x8, None, w8, sw, bias=lin.b, a_row_scale=row_scale, **kw)
+    x8, sx = ops.quantize_e4m3(x)
     return ops.gemm_fp8_nt(x8, sx, w8, sw, bias=lin.b, **kw)
 
 
@@ -59,7 +63,8 @@ def _site_seed(seed, layer, site):
 class TransformerStackFn(torch.autograd.Function):
     """hidden [B*S, H] bf16 -> LN_final(stack(hidden)) [B*S, H] bf16.
 
-    opts: dict(heads, dropout_p, seed, fp8 (QKV / fc1 / fc2 forward GEMMs on e4m3 operands), colsum (f32 [B,S] accumulated over layers, all query rows, weight 1/heads),
+    opts: dict(heads, dropout_p, seed, fp8 (True: QKV / fc1 / fc2 forward GEMMs on e4m3 operands; 'ln': only the two fed by a
+               LayerNorm, whose e4m3 copy costs no extra pass), colsum (f32 [B,S] accumulated over layers, all query rows, weight 1/heads),
                log_lo / log_hi (f32 [B,S], valid pairs only, queries < / >= log_split), num_layers,
                seg (int32 [S]: the disable_pairwise_lang_attn block mask, model/modeling.py:160-168))
     """
@@ -74,13 +79,18 @@ class TransformerStackFn(torch.autograd.Function):
         log_lo, log_hi = opts.get('log_lo'), opts.get('log_hi')
         seg = opts.get('seg')                              # int32 [S] block mask of disable_pairwise_lang_attn, or None
         fp8 = bool(opts.get('fp8', False))
+        fp8_fc2 = fp8 and opts.get('fp8') != 'ln'
         need_bwd = ctx.needs_input_grad[0]
         saved = []
         h = h.contiguous()
         for l in range(nl):
             w = stack.layers[l]
-            x1, _, mean1, rstd1 = ops.ln_fwd(h, w.ln1.gamma, w.ln1.beta)
-            qkv = _fwd_linear(x1, w.qkv, fp8)
+            if fp8:
+                x1, x1q, rs1, mean1, rstd1 = ops.ln_fwd_q8(h, w.ln1.gamma, w.ln1.beta)
+                qkv = _fwd_linear(x1, w.qkv, True, x8=x1q, row_scale=rs1)
+            else:
+                x1, _, mean1, rstd1 = ops.ln_fwd(h, w.ln1.gamma, w.ln1.beta)
+                qkv = _fwd_linear(x1, w.qkv, False)
             # the attention-probability side outputs (a7) come out of the forward launch: K is still resident in LDS
             if colsum is not None and log_lo is None:
                 ctx_, lse = ops.attention_fwd(qkv, B, S, heads, valid, seg=seg, colsum_lo=colsum, valid_q_only=False,
@@ -98,10 +108,14 @@ class TransformerStackFn(torch.autograd.Function):
                                          valid_q_only=True, weight=1.0 / heads, seg=seg)
             h_mid = ops.gemm_nt(ctx_, w.proj.wb, bias=w.proj.b, epilogue=EPI_RESIDUAL, aux_in=h, dropout_p=p,
                                 dropout_seed=_site_seed(seed, l, 0))
-            x2, _, mean2, rstd2 = ops.ln_fwd(h_mid, w.ln2.gamma, w.ln2.beta)
+            if fp8:
+                x2, x2q, rs2, mean2, rstd2 = ops.ln_fwd_q8(h_mid, w.ln2.gamma, w.ln2.beta)
+            else:
+                x2, _, mean2, rstd2 = ops.ln_fwd(h_mid, w.ln2.gamma, w.ln2.beta)
+                x2q = rs2 = None
             u = torch.empty((x2.shape[0], w.fc1.wb.shape[0]), device=h.device, dtype=BF16)
-            a = _fwd_linear(x2, w.fc1, fp8, epilogue=EPI_GELU, aux_out=u)
-            h_out = _fwd_linear(a, w.fc2, fp8, epilogue=EPI_RESIDUAL, aux_in=h_mid, dropout_p=p,
+            a = _fwd_linear(x2, w.fc1, fp8, x8=x2q, row_scale=rs2, epilogue=EPI_GELU, aux_out=u)
+            h_out = _fwd_linear(a, w.fc2, fp8_fc2, epilogue=EPI_RESIDUAL, aux_in=h_mid, dropout_p=p,
                                 dropout_seed=_site_seed(seed, l, 1))
             if need_bwd:
                 saved.append((h, mean1, rstd1, x1, qkv, ctx_, lse, h_mid, mean2, rstd2, x2, u, a))

@@ -100,10 +100,15 @@ def quantize_e4m3(x, out=None):
 
 
 def gemm_fp8_nt(a8, a_scale, bt8, b_scale, *, bias=None, epilogue=EPI_NONE, out=None, out_dtype=BF16, alpha=1.0,
-                aux_in=None, aux_out=None, dropout_p=0.0, dropout_seed=0):
+                aux_in=None, aux_out=None, dropout_p=0.0, dropout_seed=0, a_row_scale=None):
     """C[M,N] = epi(alpha / (sa * sb) * a8[M,K] @ bt8[N,K]^T): gemm_nt on e4m3 operands; a_scale / b_scale are the f32[3]
     tensors quantize_e4m3 returned (their [1] entry, the dequantisation factor, is read on the device)."""
     _chk(a8, FP8, 'a8'); _chk(bt8, FP8, 'bt8'); _chk(a_scale, F32, 'a_scale'); _chk(b_scale, F32, 'b_scale')
+    _chk(a_row_scale, F32, 'a_row_scale')
+    if a_scale is None and a_row_scale is None:
+        raise ValueError("gemm_fp8_nt: a8 needs its per-tensor scale or per-row scales")
+    if a_row_scale is not None and a_row_scale.numel() != a8.shape[0]:
+        raise ValueError("gemm_fp8_nt: a_row_scale must have one entry per row of a8")
     _chk(bias, F32, 'bias'); _chk(aux_in, BF16, 'aux_in'); _chk(aux_out, BF16, 'aux_out')
     M, K = a8.shape
     N = bt8.shape[0]
@@ -114,7 +119,8 @@ def gemm_fp8_nt(a8, a_scale, bt8, b_scale, *, bias=None, epilogue=EPI_NONE, out=
     _chk(out, out.dtype, 'out')
 
     def launch():
-        call('merlot_gemm_fp8_nt', _p(a8), a8.stride(0), a_scale.data_ptr() + 4, _p(bt8), bt8.stride(0), b_scale.data_ptr() + 4,
+        call('merlot_gemm_fp8_nt', _p(a8), a8.stride(0), a_scale.data_ptr() + 4 if a_scale is not None else None, _p(a_row_scale),
+             _p(bt8), bt8.stride(0), b_scale.data_ptr() + 4,
              _p(out), out.stride(0), M, N, K, float(alpha), int(epilogue), 1 if out.dtype == F32 else 0, _p(bias), _p(aux_in),
              aux_in.stride(0) if aux_in is not None else 0, _p(aux_out), aux_out.stride(0) if aux_out is not None else 0,
              float(dropout_p), int(dropout_seed) & 0xFFFFFFFFFFFFFFFF, _stream())
@@ -182,6 +188,22 @@ def ln_fwd(x, gamma, beta, *, out_bf16=True, out_f32=False, save_stats=True, eps
     call('merlot_ln_fwd', _p(x), 1 if x.dtype == F32 else 0, _p(gamma), _p(beta), _p(y16), _p(y32), _p(mean), _p(rstd),
          rows, H, float(eps), _stream())
     return y16, y32, mean, rstd
+
+
+def ln_fwd_q8(x, gamma, beta, *, out_bf16=True, save_stats=True, eps=1e-5):
+    """ln_fwd that also emits the per-row e4m3 copy of its (bf16-rounded) output: -> (y16, y8, row_scale f32[rows], mean, rstd)."""
+    assert x.dtype in (BF16, F32) and x.is_contiguous()
+    _chk(gamma, F32, 'gamma'); _chk(beta, F32, 'beta')
+    H = x.shape[-1]
+    rows = x.numel() // H
+    y16 = torch.empty(x.shape, device=x.device, dtype=BF16) if out_bf16 else None
+    y8 = torch.empty(x.shape, device=x.device, dtype=FP8)
+    rs = torch.empty(rows, device=x.device, dtype=F32)
+    mean = torch.empty(rows, device=x.device, dtype=F32) if save_stats else None
+    rstd = torch.empty(rows, device=x.device, dtype=F32) if save_stats else None
+    call('merlot_ln_fwd_q8', _p(x), 1 if x.dtype == F32 else 0, _p(gamma), _p(beta), _p(y16), _p(y8), _p(rs), _p(mean), _p(rstd),
+         rows, H, float(eps), _stream())
+    return y16, y8, rs, mean, rstd
 
 
 def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, dres=None, dx_dtype=None, branch_bias_grad=None, drop_p=0.0,

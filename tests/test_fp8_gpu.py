@@ -118,6 +118,57 @@ def test_gemm_fp8_epilogues_match_the_bf16_kernels_epilogues():
             assert (z8 != z16).float().mean().item() < 1e-3
 
 
+@pytest.mark.parametrize('rows,H', [(1000, 768), (37, 256), (4, 1024)])
+def test_ln_fwd_q8_emits_the_per_row_e4m3_copy_of_its_own_bf16_output(rows, H):
+    """merlot_ln_fwd_q8: y_bf16 / mean / rstd identical to merlot_ln_fwd, y_fp8 = e4m3(bf16(y) * 448 / max|bf16(y[row])|) bit for bit
+    against torch's conversion, row_scale = max / 448; an all-zero row (gamma = beta = 0) gets scale 1."""
+    ops = _ops()
+    g = torch.Generator(device='cpu').manual_seed(rows + H)
+    x = (torch.randn(rows, H, generator=g) * 3 + 0.5).to(torch.bfloat16).to(_dev())
+    gamma = (1 + 0.2 * torch.randn(H, generator=g)).to(_dev())
+    beta = (0.1 * torch.randn(H, generator=g)).to(_dev())
+    y16, _, mean, rstd = ops.ln_fwd(x, gamma, beta)
+    q16, q8, rs, qmean, qrstd = ops.ln_fwd_q8(x, gamma, beta)
+    assert torch.equal(q16, y16) and torch.equal(qmean, mean) and torch.equal(qrstd, rstd)
+    amax = y16.float().abs().amax(dim=1)
+    s = torch.tensor(448.0, device=x.device) / amax
+    assert torch.allclose(rs, 1.0 / s, rtol=2e-7, atol=0)
+    want = (y16.float() * s[:, None]).clamp(-448.0, 448.0).to(E4M3)
+    assert torch.equal(q8.view(torch.uint8), want.view(torch.uint8))
+    z16, z8, zs, _, _ = ops.ln_fwd_q8(x, torch.zeros_like(gamma), torch.zeros_like(beta))
+    assert int(z8.view(torch.uint8).max()) == 0 and float(zs.min()) == 1.0 == float(zs.max())
+
+
+@pytest.mark.parametrize('M,N,K', [(512, 768, 768), (4000, 2304, 768), (777, 1000, 384)])
+def test_gemm_fp8_with_per_row_scales(M, N, K):
+    """a_row_scale: row m of the product is multiplied by its own dequantisation factor -- interior and edge tiles, bf16 and
+    f32 outputs, with the GELU epilogue (the scale must be applied BEFORE bias and activation)."""
+    ops = _ops()
+    g = torch.Generator(device='cpu').manual_seed(M * 3 + N)
+    a = (torch.randn(M, K, generator=g) * torch.logspace(-2, 1, M)[:, None]).to(torch.bfloat16).to(_dev())   # rows of very different size
+    b = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).to(_dev())
+    bias = torch.randn(N, generator=g).to(_dev())
+    amax = a.float().abs().amax(dim=1)
+    s = 448.0 / amax
+    a8 = (a.float() * s[:, None]).clamp(-448, 448).to(E4M3)
+    rs = (1.0 / s).contiguous()
+    b8, sb = ops.quantize_e4m3(b)
+    out = ops.gemm_fp8_nt(a8, None, b8, sb, bias=bias, out_dtype=torch.float32, a_row_scale=rs)
+    want = ((a8.double() @ b8.double().t()) * rs.double()[:, None] * sb[1].double() + bias.double()).float()   # exact products, fp64 sums
+    # per row (the rows differ by 3 orders of magnitude), relative to the row's largest output
+    assert ((out - want).abs().amax(dim=1) / want.abs().amax(dim=1)).max().item() <= 1e-4      # measured 3.0e-5 (the MFMA's fp32 tree sum); a neighbouring row's scale would be 1.4e-2 off
+    exact = torch.addmm(bias, a.float(), b.float().t())
+    # per-row scaling keeps the SMALL rows accurate too (a per-tensor scale would flush them): row-wise relative error
+    rel_rows = (out - exact).norm(dim=1) / exact.norm(dim=1)
+    assert rel_rows.max().item() < 8e-2
+    u8 = torch.empty(M, N, device=_dev(), dtype=torch.bfloat16)
+    o8 = ops.gemm_fp8_nt(a8, None, b8, sb, bias=bias, epilogue=ops.EPI_GELU, aux_out=u8, a_row_scale=rs)
+    assert (u8.float() - want).abs().max().item() <= 2.0 ** -7 * want.abs().max().item()
+    assert (o8.float() - torch.nn.functional.gelu(want)).abs().max().item() <= 2.0 ** -7 * want.abs().max().item() + 1e-3
+    with pytest.raises(ValueError, match='one entry per row'):
+        ops.gemm_fp8_nt(a8, None, b8, sb, a_row_scale=rs[:-1])
+
+
 def test_gemm_fp8_rejects_what_the_kernel_cannot_take():
     ops = _ops()
     a = torch.randn(256, 192, device=_dev()).to(torch.bfloat16)
@@ -140,7 +191,7 @@ def test_config5_geometry_fp8_forward_loss_within_2e2_of_bf16():
     from oracle import merlot_oracle as mo
     out = {}
     b = None
-    for fp8 in (False, True):
+    for fp8 in (False, True, 'ln'):
         cfg = tiny_config(image_size=[384, 384], num_chunks_in_group=16, max_position_embeddings=1024, fp8_forward=fp8,
                           masking_use_attn=False)      # MLM targets from the noise alone: identical in both runs
         if b is None:
@@ -159,12 +210,13 @@ def test_config5_geometry_fp8_forward_loss_within_2e2_of_bf16():
         out[fp8] = dict(losses=[float(l1), float(l2), float(l3)], viz=pm.encoder_hidden_states['viz'].float().cpu(),
                         lang=pm.encoder_hidden_states['lang'].float().cpu(),
                         masked=pm.lang_mask_info['masked_idx'].cpu(), grads={k: v.float().cpu() for k, v in st.export_tf_grads().items()})
-    for a, c in zip(out[False]['losses'], out[True]['losses']):
-        assert abs(a - c) < 2e-2, (out[False]['losses'], out[True]['losses'])
-    assert abs(sum(out[False]['losses']) - sum(out[True]['losses'])) < 2e-2
-    assert torch.equal(out[True]['masked'], out[False]['masked'])
-    for k in ('viz', 'lang'):
-        assert rel_l2(out[True][k], out[False][k]) < 5e-2, k
-    assert all(torch.isfinite(g).all() for g in out[True]['grads'].values())
-    rels = [rel_l2(out[True]['grads'][k], g) for k, g in out[False]['grads'].items() if float(g.norm()) > 0]
-    assert sorted(rels)[len(rels) // 2] < 0.15, sorted(rels)[len(rels) // 2]
+    for mode in (True, 'ln'):                              # QKV + fc1 (per-row, from the LayerNorm) + fc2 (per-tensor) | without fc2
+        for a, c in zip(out[False]['losses'], out[mode]['losses']):
+            assert abs(a - c) < 2e-2, (mode, out[False]['losses'], out[mode]['losses'])
+        assert abs(sum(out[False]['losses']) - sum(out[mode]['losses'])) < 2e-2
+        assert torch.equal(out[mode]['masked'], out[False]['masked'])
+        for k in ('viz', 'lang'):
+            assert rel_l2(out[mode][k], out[False][k]) < 5e-2, (mode, k)
+        assert all(torch.isfinite(g).all() for g in out[mode]['grads'].values())
+        rels = [rel_l2(out[mode]['grads'][k], g) for k, g in out[False]['grads'].items() if float(g.norm()) > 0]
+        assert sorted(rels)[len(rels) // 2] < 0.15, (mode, sorted(rels)[len(rels) // 2])
