@@ -113,5 +113,8 @@ def test_hip_stem_gradient_is_the_derivative_of_the_hip_forward():
         fd = (hip(plus, False)[0] - hip(minus, False)[0]) / (2 * h)
         a_hip = sum(float((g_hip[k].float().cpu() * d[k]).sum()) for k in names)
         a_orc = sum(float((w[k].grad * d[k]).sum()) for k in names)
-        assert abs(a_hip - a_orc) < 0.04 * abs(a_orc), (len(names), a_hip, a_orc, fd)          # measured: 1.7 %
-        assert abs(a_hip - fd) < 0.04 * abs(fd), (len(names), a_hip, a_orc, fd)                # measured: 1.2 %
+        # measured: 1.7 % / 1.2 % for the full direction, up to 4.7 % for a third (fewer parameters average less noise; the
+        # gradient kernels sum with atomics, so runs differ in the last bits) -- a wrong factor or a missing term is >= 30 %
+        tol = 0.05 if len(names) == len(stem) else 0.10
+        assert abs(a_hip - a_orc) < tol * abs(a_orc), (len(names), a_hip, a_orc, fd)
+        assert abs(a_hip - fd) < tol * abs(fd), (len(names), a_hip, a_orc, fd)
