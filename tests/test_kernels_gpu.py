@@ -122,7 +122,9 @@ def test_gemm_nt_dropout_statistics(ops):
 
 
 @pytest.mark.parametrize("R,M,N", [(64, 128, 128), (1000, 768, 768), (777, 2304, 768), (300, 50370, 768), (5000, 768, 3072),
-                                   (130, 4, 768), (4096, 3072, 768), (50, 768, 768)])
+                                   (130, 4, 768), (4096, 3072, 768), (50, 768, 768),
+                                   # the ping-pong TN kernel (R >= 4096) on ragged tiles, a reduction tail (R % 64 != 0) and N % 4 == 2
+                                   (4500, 1000, 770), (8192, 130, 258), (4096, 256, 128), (20000, 2304, 768)])
 def test_gemm_tn(ops, R, M, N):
     g = torch.Generator().manual_seed(R + M)
     a, b = rnd((R, M), g), rnd((R, N), g)
