@@ -184,6 +184,7 @@ def main():
                     help='BASELINE.json configs[]: 2 = the headline 4-segment 224^2 bf16 workload (configs[1]; DP over --gpus); '
                          '5 = NOT the headline: the 16-segment 384^2 long-video variant with fp8 forward GEMMs (configs[4])')
     ap.add_argument('--bf16', action='store_true', help='with --config 5: keep every GEMM in bf16 (the comparison line)')
+    ap.add_argument('--fp8-attn', action='store_true', help='with --config 5: QKV / fc1 / fc2 GEMMs AND the attention forward (Q K^T, P V) on e4m3 operands')
     ap.add_argument('--fp8-fc2', action='store_true', help='with --config 5: also run fc2 on e4m3 operands (its input needs a separate two-pass quantisation)')
     ap.add_argument('--resnet-stem', action='store_true',
                     help='NOT the headline config: swap the patch stem for the ResNet-hybrid stem of merlot.yaml:30 (resnet_layers [3, 4, 9])')
@@ -249,7 +250,7 @@ def main():
     if args.config == 5:
         # BASELINE configs[4]: 16 segments per group at 384^2 (Sv = 578, joint S = 2832); everything else as merlot.yaml
         fp8 = not args.bf16
-        config.model.update(image_size=[384, 384], num_chunks_in_group=16, fp8_forward=(True if args.fp8_fc2 else 'ln') if fp8 else False)
+        config.model.update(image_size=[384, 384], num_chunks_in_group=16, fp8_forward=('all' if args.fp8_attn else True if args.fp8_fc2 else 'ln') if fp8 else False)
         train_gflop = 3.0 * fwd_gflop_per_segment(384, 16)
     if args.resnet_stem:
         config.model['resnet_layers'] = [3, 4, 9]
@@ -299,11 +300,11 @@ def main():
         value = world * seg_per_gpu * args.steps / elapsed
         res = {
             'metric': 'frame-caption segments/sec/node (4-seg, 224^2, bf16)' if args.config == 2 else
-                      'frame-caption segments/sec/node (16-seg, 384^2, %s)' % (('fp8 QKV/fc1/fc2 forward GEMMs' if args.fp8_fc2 else 'fp8 QKV/fc1 forward GEMMs') if fp8 else 'bf16'),
+                      'frame-caption segments/sec/node (16-seg, 384^2, %s)' % (('fp8 QKV/fc1/fc2 GEMMs + attention forward' if args.fp8_attn else 'fp8 QKV/fc1/fc2 forward GEMMs' if args.fp8_fc2 else 'fp8 QKV/fc1 forward GEMMs') if fp8 else 'bf16'),
             'value': value, 'unit': 'segments/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': ('fp8 (e4m3 operands, fp32 accumulate: QKV / fc1%s forward GEMMs; bf16 elsewhere)' % (' / fc2' if args.fp8_fc2 else '')) if fp8 else 'bf16',
+            'dtype': ('fp8 (e4m3 operands, fp32 accumulate: QKV / fc1%s forward GEMMs; bf16 elsewhere)' % (' / fc2 GEMMs, attention QK^T and PV' if args.fp8_attn else ' / fc2' if args.fp8_fc2 else '')) if fp8 else 'bf16',
             'data': 'synthetic',
             'config': {'workload': (('merlot.yaml 4-segment ResNet-hybrid [3,4,9] + ViT-B/16' if args.resnet_stem else
                                      'merlot.yaml 4-segment full ViT-B/16 (patch stem)') + ' + 12-layer joint + 12-layer text-only, '

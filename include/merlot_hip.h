@@ -80,6 +80,16 @@ int merlot_gemm_bf16_nt_plan(int64_t M, int64_t N, int64_t K);
  * cols, ldx, ldy multiples of 8. */
 int merlot_quantize_e4m3(const void* x, int64_t rows, int64_t cols, int64_t ldx, void* y, int64_t ldy, float* scale,
                          merlot_stream_t stream);
+/* amax[g] = max|x[:, g-th of `groups` equal column groups]| over a [rows, cols] bf16 view (row stride ldx), one pass;
+ * amax = device float[groups] (zeroed here), groups <= 4.  Feeds merlot_attention_fwd_fp8: groups = 3 over the fused QKV
+ * tensor gives max|Q|, max|K|, max|V|. */
+int merlot_amax_bf16(const void* x, int64_t rows, int64_t cols, int64_t ldx, int groups, float* amax, merlot_stream_t stream);
+/* merlot_attention_fwd with Q K^T and P V on the e4m3 MFMA (fp32 accumulation; softmax, masks and the lse output unchanged):
+ * Q, K, V are quantised on the fly from the bf16 tensor with ONE scale per tensor, 448 / amax3[0..2] (device memory), P with
+ * 2^8.  No side outputs on this entry (use merlot_attention_colsum).  The backward stays merlot_attention_bwd. */
+int merlot_attention_fwd_fp8(const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse, const uint8_t* valid,
+                             const int32_t* seg, int B, int S, int heads, float scale, const float* amax3,
+                             merlot_stream_t stream);
 /* C[M,N] = epilogue(alpha * scale_a[0] * scale_b[0] * A8[M,K] * B8t[N,K]^T + bias): merlot_gemm_bf16_nt on e4m3 operands.
  * scale_a / scale_b point at the DEQUANTISATION factor of each operand in device memory (&scale[1] of
  * merlot_quantize_e4m3).  A may instead (or also) carry per-ROW factors row_scale_a (f32 [M], from merlot_ln_fwd_q8;

@@ -89,3 +89,56 @@ extern "C" int merlot_quantize_e4m3(const void* x, int64_t rows, int64_t cols, i
     hipLaunchKernelGGL(quantize_e4m3_kernel, dim3(grid), dim3(256), 0, s, (const bf16*)x, rows, cols8, ldx, (uint8_t*)y, ldy, scale);
     return merlot_launch_status("merlot_quantize_e4m3");
 }
+
+namespace {
+// per column GROUP maxima in one pass: cols = groups * gcols8 * 8, amax_bits[g] = max|x[:, g-th group]|
+__global__ __launch_bounds__(256) void amax_groups_bf16_kernel(const bf16* __restrict__ x, int64_t rows, int gcols8, int groups,
+                                                               int64_t ldx, unsigned int* __restrict__ amax_bits) {
+    const int cols8 = gcols8 * groups;
+    const int64_t total = rows * cols8;
+    float m[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols8;
+        const int c = (int)(i - r * cols8);
+        const int g = c / gcols8;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + r * ldx + (int64_t)c * 8);
+        float mm = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mm = fmaxf(mm, fabsf((float)v[e]));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m[k] = (k == g) ? fmaxf(m[k], mm) : m[k];
+    }
+    __shared__ float part[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m[k] = fmaxf(m[k], __shfl_xor(m[k], o, 64));
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][k] = m[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < groups) {
+        const int k = threadIdx.x;
+        atomicMax(amax_bits + k, __float_as_uint(fmaxf(fmaxf(part[0][k], part[1][k]), fmaxf(part[2][k], part[3][k]))));
+    }
+}
+}  // namespace
+
+// amax[g] = max|x[:, g * cols/groups : (g + 1) * cols/groups]| over a [rows, cols] bf16 view (row stride ldx), g < groups <= 4;
+// amax (device float[groups]) is zeroed here, on the stream.
+extern "C" int merlot_amax_bf16(const void* x, int64_t rows, int64_t cols, int64_t ldx, int groups, float* amax, merlot_stream_t stream) {
+    MERLOT_CHECK(x && amax, MERLOT_ESHAPE, "merlot_amax_bf16: null argument");
+    MERLOT_CHECK(rows > 0 && cols > 0 && groups >= 1 && groups <= 4 && cols % (8 * groups) == 0 && ldx % 8 == 0 && ldx >= cols, MERLOT_ESHAPE,
+                 "merlot_amax_bf16: rows=%lld cols=%lld ldx=%lld groups=%d (cols a multiple of 8 * groups, ldx of 8, groups <= 4)",
+                 (long long)rows, (long long)cols, (long long)ldx, groups);
+    MERLOT_CHECK(((uintptr_t)x & 15) == 0, MERLOT_EALIGN, "merlot_amax_bf16: x must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(amax, 0, groups * sizeof(float), s);
+    MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "merlot_amax_bf16: memset failed: %s", hipGetErrorString(e));
+    const int gcols8 = (int)(cols / 8 / groups);
+    const int64_t total = rows * (cols / 8);
+    int grid = (int)((total + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(amax_groups_bf16_kernel, dim3(grid), dim3(256), 0, s, (const bf16*)x, rows, gcols8, groups, ldx,
+                       reinterpret_cast<unsigned int*>(amax));
+    return merlot_launch_status("merlot_amax_bf16");
+}

@@ -64,7 +64,7 @@ class TransformerStackFn(torch.autograd.Function):
     """hidden [B*S, H] bf16 -> LN_final(stack(hidden)) [B*S, H] bf16.
 
     opts: dict(heads, dropout_p, seed, fp8 (True: QKV / fc1 / fc2 forward GEMMs on e4m3 operands; 'ln': only the two fed by a
-               LayerNorm, whose e4m3 copy costs no extra pass), colsum (f32 [B,S] accumulated over layers, all query rows, weight 1/heads),
+               LayerNorm, whose e4m3 copy costs no extra pass; 'all': True + the attention forward's two contractions), colsum (f32 [B,S] accumulated over layers, all query rows, weight 1/heads),
                log_lo / log_hi (f32 [B,S], valid pairs only, queries < / >= log_split), num_layers,
                seg (int32 [S]: the disable_pairwise_lang_attn block mask, model/modeling.py:160-168))
     """
@@ -80,6 +80,7 @@ class TransformerStackFn(torch.autograd.Function):
         seg = opts.get('seg')                              # int32 [S] block mask of disable_pairwise_lang_attn, or None
         fp8 = bool(opts.get('fp8', False))
         fp8_fc2 = fp8 and opts.get('fp8') != 'ln'
+        fp8_attn = opts.get('fp8') == 'all'              # + Q K^T and P V of the forward on the e4m3 MFMA
         need_bwd = ctx.needs_input_grad[0]
         saved = []
         h = h.contiguous()
@@ -92,7 +93,15 @@ class TransformerStackFn(torch.autograd.Function):
                 x1, _, mean1, rstd1 = ops.ln_fwd(h, w.ln1.gamma, w.ln1.beta)
                 qkv = _fwd_linear(x1, w.qkv, False)
             # the attention-probability side outputs (a7) come out of the forward launch: K is still resident in LDS
-            if colsum is not None and log_lo is None:
+            if fp8_attn:
+                ctx_, lse = ops.attention_fwd_fp8(qkv, B, S, heads, valid, seg=seg)
+                if colsum is not None:
+                    ops.attention_colsum(qkv, lse, B, S, heads, colsum, valid=valid, valid_q_only=False, weight=1.0 / heads,
+                                         seg=seg)
+                if log_lo is not None:
+                    ops.attention_colsum(qkv, lse, B, S, heads, log_lo, log_hi, qsplit=opts['log_split'], valid=valid,
+                                         valid_q_only=True, weight=1.0 / heads, seg=seg)
+            elif colsum is not None and log_lo is None:
                 ctx_, lse = ops.attention_fwd(qkv, B, S, heads, valid, seg=seg, colsum_lo=colsum, valid_q_only=False,
                                               weight=1.0 / heads)
             elif log_lo is not None and colsum is None:

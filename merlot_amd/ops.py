@@ -240,6 +240,30 @@ def attention_fwd(qkv, B, S, heads, valid=None, need_lse=True, seg=None, colsum_
     return out, lse
 
 
+def amax_groups(x, groups):
+    """max|x| per equal column group of a bf16 [rows, cols] tensor, one pass -> f32[groups] on the device."""
+    _chk(x, BF16, 'x')
+    rows, cols = x.shape
+    out = torch.empty(groups, device=x.device, dtype=F32)
+    call('merlot_amax_bf16', _p(x), rows, cols, x.stride(0), int(groups), _p(out), _stream())
+    return out
+
+
+def attention_fwd_fp8(qkv, B, S, heads, valid=None, scale=None, seg=None, amax3=None):
+    """attention_fwd with Q K^T and P V on the e4m3 MFMA (per-tensor scales from amax3 = amax_groups(qkv, 3)) -> (out, lse)."""
+    _chk(qkv, BF16, 'qkv')
+    D = heads * 64
+    scale = scale if scale is not None else 1.0 / 8.0
+    if amax3 is None:
+        amax3 = amax_groups(qkv[:, :3 * D], 3)
+    _chk(amax3, F32, 'amax3')
+    out = torch.empty((B * S, D), device=qkv.device, dtype=BF16)
+    lse = torch.empty((B, heads, S), device=qkv.device, dtype=F32)
+    call('merlot_attention_fwd_fp8', _p(qkv), qkv.stride(0), _p(out), out.stride(0), _p(lse), _p(valid), _p(seg), B, S, heads,
+         float(scale), _p(amax3), _stream())
+    return out, lse
+
+
 def attention_bwd(qkv, out, dout, lse, B, S, heads, valid=None, seg=None):
     _chk(dout, BF16, 'dout'); _chk(seg, torch.int32, 'seg')
     dqkv = torch.empty_like(qkv)
