@@ -79,15 +79,17 @@ def run_properties(device, examples=4, layers=12):
         gpe = nc // n                                                  # groups per example
         full = enc(b['images'], b['input_ids'], b['shuffled_idx_img'])
         sub = enc(b['images'][:2 * nc], b['input_ids'][:2], b['shuffled_idx_img'][:2 * nc])
-        assert _rel(sub[0], full[0][:2 * gpe]) < 6e-2 and _rel(sub[1], full[1][:2 * gpe]) < 6e-2
-        assert _rel(sub[2], full[2][:2 * nc]) < 6e-2
+        # measured: exactly 0 -- every kernel of the forward sums each output's K range in the same order whatever the batch
+        # (the ring and the ping-pong GEMMs give bit-identical results, scripts/exp_p8.py), and nothing in it uses atomics
+        assert _rel(sub[0], full[0][:2 * gpe]) <= 1e-6 and _rel(sub[1], full[1][:2 * gpe]) <= 1e-6
+        assert _rel(sub[2], full[2][:2 * nc]) <= 1e-6
         perm = torch.arange(examples)
         perm[0], perm[1] = 1, 0
         img_p = b['images'].reshape(examples, nc, *b['images'].shape[1:])[perm].reshape(b['images'].shape)
         sid_p = b['shuffled_idx_img'].reshape(examples, nc)[perm].reshape(-1)
         sw = enc(img_p, b['input_ids'][perm], sid_p)
         gp = torch.arange(examples * gpe).reshape(examples, gpe)[perm].reshape(-1)
-        assert _rel(sw[0], full[0][gp]) < 6e-2 and _rel(sw[1], full[1][gp]) < 6e-2
+        assert _rel(sw[0], full[0][gp]) <= 1e-6 and _rel(sw[1], full[1][gp]) <= 1e-6
         assert _rel(full[0][:gpe], full[0][gpe:2 * gpe]) > 0.1            # and the two examples really differ
     return float(l1), float(l2), float(l3)
 
