@@ -313,6 +313,34 @@ int merlot_image_frames(const uint8_t* src, int64_t src_bytes, const merlot_imag
                         const merlot_image_job_t* jobs_dev, int n_img, void* dst, int out_h, int out_w, void* workspace,
                         int64_t workspace_bytes, merlot_stream_t stream);
 
+/* ---- JPEG decode (`tf.image.decode_jpeg(x, channels=3)`, model/dataloader.py:72-77) split host / GPU ------------------------
+ * Host: markers + Huffman decode of a baseline 8-bit YCbCr JPEG (4:4:4 or 4:2:0, one interleaved scan, restart intervals ok)
+ * into QUANTISED coefficients, natural order, component planes of whole blocks.  GPU: dequantise, inverse DCT (libjpeg's
+ * jidctint "islow"), h2v2 "fancy" chroma upsampling, YCbCr -> RGB -- bit for bit libjpeg(-turbo)'s default decoder.
+ * MERLOT_JPEG_UNSUPPORTED (progressive, grayscale, CMYK, 4:2:2, 12-bit, ...) means: decode this frame with the host library. */
+#define MERLOT_JPEG_MALFORMED (-20)
+#define MERLOT_JPEG_UNSUPPORTED (-21)
+#define MERLOT_JPEG_CAPACITY (-22)
+typedef struct {
+    int32_t width, height;
+    int32_t subsampling;      /* 1: 4:4:4, 2: 4:2:0 */
+    int32_t blocks_w[3], blocks_h[3];   /* per component, whole MCUs */
+    int64_t coef_offset[3];   /* element offset of the component's first block in the coefficient array */
+    int64_t coef_count;       /* int16 elements in total */
+    int64_t coef_base;        /* set by the CALLER: element offset of this image's coefficients in the batch buffer */
+    int64_t dst_offset;       /* set by the CALLER: byte offset of this image's RGB output (height * width * 3 bytes) */
+    int64_t plane_offset;     /* set by the CALLER: byte offset of this image's component planes in the workspace */
+    uint16_t quant[3][64];    /* natural order */
+} merlot_jpeg_info_t;
+/* coef == NULL: fill `info` only (coef_count says how much room the call needs).  Returns MERLOT_OK or a MERLOT_JPEG_* code. */
+int merlot_jpeg_entropy_decode(const uint8_t* data, int64_t n, merlot_jpeg_info_t* info, int16_t* coef, int64_t coef_capacity);
+/* bytes of the component planes of one image: sum over components of blocks_w * 8 * blocks_h * 8 */
+int64_t merlot_jpeg_plane_bytes(const merlot_jpeg_info_t* info);
+/* n_img images: coef (device int16), infos_host / infos_dev (the same table), workspace (device, the component planes),
+ * dst (device uint8): image i is written as [height, width, 3] RGB at dst + infos[i].dst_offset. */
+int merlot_jpeg_idct_rgb(const int16_t* coef, const merlot_jpeg_info_t* infos_host, const merlot_jpeg_info_t* infos_dev, int n_img,
+                         uint8_t* workspace, int64_t workspace_bytes, uint8_t* dst, int64_t dst_bytes, merlot_stream_t stream);
+
 /* ---- host-side byte work (no GPU, no stream) ---------------------------------------------------------------------
  * CRC-32C (Castagnoli) of `n` bytes, extending `crc` (0 to start).  Used by the TF tensor-bundle checkpoint reader/writer
  * (the files utils/model_utils.py:388-413 and model/modeling.py:724-738 initialise from) and by the TFRecord framing

@@ -7,7 +7,7 @@ set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable"
-SRCS="gemm attention layernorm elementwise index conv image fp8"
+SRCS="gemm attention layernorm elementwise index conv image fp8 jpeg"
 HDRS="common.h gemm_ring.h gemm_p8.inc attention_res.inc ../../include/merlot_hip.h"
 
 newer() {  # newer <target> <deps...>: true when target is missing or older than a dependency
@@ -24,12 +24,12 @@ build_lib() {  # build_lib <objdir> <out> <extra flags>
   for f in $SRCS; do
     if newer $dir/$f.o $f.hip $HDRS; then ( $HIPCC $FLAGS $extra -c $f.hip -o $dir/$f.o ) & pids+=($!); fi
   done
-  for f in capi hostio; do
+  for f in capi hostio jpeg_host; do
     if newer $dir/$f.o $f.cpp ../../include/merlot_hip.h; then ( g++ -O2 -fPIC -std=c++17 $extra -c $f.cpp -o $dir/$f.o ) & pids+=($!); fi
   done
   for p in "${pids[@]}"; do wait $p; done
   local objs=""
-  for f in $SRCS capi hostio; do objs="$objs $dir/$f.o"; done
+  for f in $SRCS capi hostio jpeg_host; do objs="$objs $dir/$f.o"; done
   $HIPCC --offload-arch=gfx950 -shared -fPIC -o $out $objs
   echo "built $(realpath $out)"
 }

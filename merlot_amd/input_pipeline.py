@@ -260,6 +260,25 @@ def encode_string(b, string_len):
     return out
 
 
+class JpegCoef(object):
+    """a frame whose pixels do not exist on the host: the entropy-decoded DCT coefficients of its JPEG file (`data.gpu_jpeg_decode`);
+    dequantisation, IDCT, upsampling and colour conversion run on the GPU at the frame's place in the batch's source buffer."""
+    __slots__ = ('coef', 'info', 'shape', 'nbytes')
+
+    def __init__(self, coef, info):
+        self.coef, self.info = coef, info
+        self.shape = (int(info[0]['height']), int(info[0]['width']), 3)
+        self.nbytes = self.shape[0] * self.shape[1] * 3
+
+
+def decode_jpeg_split(data):
+    """`data.gpu_jpeg_decode`: the host does only the Huffman decode (merlot_jpeg_entropy_decode, C++, releases the GIL); files
+    outside the GPU decoder's subset (progressive, grayscale, CMYK, 4:2:2) take the host library as before."""
+    from . import jpeg
+    got = jpeg.entropy_decode(data)
+    return decode_jpeg(data) if got is None else JpegCoef(*got)
+
+
 def decode_jpeg(data):
     """tf.image.decode_jpeg(x, channels=3) -> uint8 [h, w, 3] (host libjpeg through PIL)."""
     from PIL import Image
@@ -315,7 +334,7 @@ def parse_example_host(record, config, noise):
     }
     frames, jobs = [], np.zeros(num_chunks, JOB_DTYPE)
     for i, c in enumerate(chunks):
-        img = decode_jpeg(c['image/encoded'])
+        img = decode_jpeg_split(c['image/encoded']) if config.get('gpu_jpeg_decode', False) else decode_jpeg(c['image/encoded'])
         n = noise['frames'][i]
         sh, sw, oy, ox = resize_geometry(img.shape[0], img.shape[1], desired, n['scale'], n['u_y'], n['u_x'])
         # utils/model_utils.py:829-830 binds the transform late: every switch_case branch runs the LAST transform
@@ -367,34 +386,61 @@ class Staging(object):
 
 
 def pack_frames(frames_u8, staging=None, pool=None):
-    """-> (flat uint8 host tensor holding every frame, offsets, staging slot or None)"""
+    """-> (flat uint8 host tensor holding every host-decoded frame at its offset, offsets, staging slot or None, jpeg pack or
+    None).  Frames that are JpegCoef leave their bytes of `flat` unwritten; the jpeg pack = (coefficients of all of them
+    concatenated [int16 host tensor], merlot_jpeg_info_t table with coef_base / dst_offset / plane_offset set, plane bytes)."""
     offs, total = frame_offsets(frames_u8)
     slot, flat = staging.take(total) if staging is not None else (None, torch.empty(total, dtype=torch.uint8))
     fnp = flat.numpy()
+    host = [i for i, f in enumerate(frames_u8) if not isinstance(f, JpegCoef)]
 
     def put(i):
         f = frames_u8[i]
         fnp[offs[i]:offs[i] + f.nbytes] = f.reshape(-1)
 
     if pool is not None:
-        list(pool.map(put, range(len(frames_u8))))
+        list(pool.map(put, host))
     else:
-        for i in range(len(frames_u8)):
+        for i in host:
             put(i)
-    return flat[:total], offs, slot
+    jp = None
+    gpu = [i for i, f in enumerate(frames_u8) if isinstance(f, JpegCoef)]
+    if gpu:
+        from . import jpeg
+        infos = np.zeros(len(gpu), jpeg.INFO_DTYPE)
+        cbase = pbase = 0
+        for k, i in enumerate(gpu):
+            f = frames_u8[i]
+            infos[k] = f.info[0]
+            infos[k]['coef_base'], infos[k]['plane_offset'], infos[k]['dst_offset'] = cbase, pbase, offs[i]
+            cbase += f.coef.size
+            pbase += (jpeg.plane_bytes(f.info) + 15) // 16 * 16
+        coef = torch.empty(cbase, dtype=torch.int16)
+        if torch.cuda.is_available():
+            coef = coef.pin_memory()
+        cnp, o = coef.numpy(), 0
+        for i in gpu:
+            c = frames_u8[i].coef
+            cnp[o:o + c.size] = c
+            o += c.size
+        jp = (coef, infos, pbase)
+    return flat[:total], offs, slot, jp
 
 
 def frames_to_device(frames_u8, jobs, out_hw, device, packed=None, staging=None):
     """all frames of a batch -> bf16 [n, H, W, 3] on `device` with one upload and one `merlot_image_frames` call.
-    jobs[i] describes output frame i and reads source frame i (or, with `packed=(flat, offsets, slot)`, the frame at
+    jobs[i] describes output frame i and reads source frame i (or, with `packed=(flat, offsets, slot, jpeg pack)`, the frame at
     jobs['src_offset'][i], already set by the caller)."""
     jobs = jobs.copy()
     if packed is None:
-        flat, offs, slot = pack_frames(frames_u8)
+        flat, offs, slot, jp = pack_frames(frames_u8)
         jobs['src_offset'] = offs
     else:
-        flat, offs, slot = packed
+        flat, offs, slot, jp = packed
     src = flat.to(device, non_blocking=True)
+    if jp is not None:                                      # the JPEG frames are decoded on the GPU straight into their slots of src
+        coef, infos, plane_bytes = jp
+        ops.jpeg_idct_rgb(coef.to(device, non_blocking=True), infos, plane_bytes, src.numel(), dst=src)
     if slot is not None and staging is not None and src.is_cuda:
         ev = torch.cuda.Event()
         ev.record()
@@ -472,6 +518,8 @@ def _worker_parse(task):
     shared-memory block (name returned), not through the result pipe."""
     from multiprocessing import resource_tracker, shared_memory
     record, config, noise = task
+    if config.get('gpu_jpeg_decode', False):
+        config = dict(config, gpu_jpeg_decode=False)         # worker processes hand back pixels (shared memory); the split decode is for the thread path
     feats = parse_example_host(record, config, noise)
     frames = feats.pop('frames_u8')
     offs, total = frame_offsets(frames)

@@ -15,7 +15,9 @@ _CTYPES = {
     'const void*': ctypes.c_void_p, 'void*': ctypes.c_void_p,
     'const float*': ctypes.c_void_p, 'float*': ctypes.c_void_p,
     'const int32_t*': ctypes.c_void_p, 'int32_t*': ctypes.c_void_p, 'int64_t*': ctypes.c_void_p,
-    'const uint8_t*': ctypes.c_void_p, 'const merlot_image_job_t*': ctypes.c_void_p,
+    'const uint8_t*': ctypes.c_void_p, 'uint8_t*': ctypes.c_void_p, 'const merlot_image_job_t*': ctypes.c_void_p,
+    'const int16_t*': ctypes.c_void_p, 'int16_t*': ctypes.c_void_p,
+    'const merlot_jpeg_info_t*': ctypes.c_void_p, 'merlot_jpeg_info_t*': ctypes.c_void_p,
     'int64_t': ctypes.c_int64, 'uint64_t': ctypes.c_uint64, 'int': ctypes.c_int, 'float': ctypes.c_float,
     'double': ctypes.c_double,
     'merlot_stream_t': ctypes.c_void_p,

@@ -512,3 +512,19 @@ def image_frames(src, jobs_host, jobs_dev, n_img, out_h, out_w):
     call('merlot_image_frames', _p(src), src.numel(), jobs_host.data_ptr(), _p(jobs_dev), n_img, _p(out), out_h, out_w,
          _p(ws), nbytes, _stream())
     return out
+
+
+def jpeg_idct_rgb(coef, infos, plane_bytes, dst_bytes, dst=None):
+    """coef: int16 device tensor (all images); infos: numpy array of merlot_jpeg_info_t (coef_base / plane_offset / dst_offset
+    set) -> flat uint8 device tensor of dst_bytes holding the RGB frames (`dst`: write into this existing buffer)."""
+    import numpy as np
+    assert coef.is_cuda and coef.dtype == torch.int16
+    infos_host = torch.from_numpy(np.ascontiguousarray(infos).view(np.uint8).reshape(-1).copy())
+    infos_dev = infos_host.to(coef.device, non_blocking=True)
+    ws = torch.empty(max(int(plane_bytes), 16), device=coef.device, dtype=torch.uint8)
+    if dst is None:
+        dst = torch.empty(max(int(dst_bytes), 16), device=coef.device, dtype=torch.uint8)
+    assert dst.is_cuda and dst.dtype == torch.uint8 and dst.is_contiguous()
+    call('merlot_jpeg_idct_rgb', _p(coef), infos_host.data_ptr(), _p(infos_dev), len(infos), _p(ws), ws.numel(), _p(dst), dst.numel(),
+         _stream())
+    return dst
