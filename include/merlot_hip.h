@@ -277,6 +277,14 @@ int merlot_im2col3x3(const void* x, void* out, int N, int H, int W, int C, int s
 /* input gradient of the same gather: dx[n][y][x][c] = sum over taps of dpatches[(n,yo,xo)][(ky,kx,c)]. */
 int merlot_col2im3x3(const void* dpatches, void* dx, int N, int H, int W, int C, int stride, int Kp,
                      merlot_stream_t stream);
+/* Weight standardisation of the hybrid stem's kernels (utils/vision_transformer.py:52-56): per output channel over (kh, kw, ci),
+ * population variance, eps 1e-5.  k: fp32 master, HWIO = [K, Co].  Writes khat fp32 [K, Co], rstd [Co], the NT operand
+ * wb bf16 [Co, Kp] and the dgrad operand wbT bf16 [Kp, Cop] (paddings untouched: zero them once). */
+int merlot_weight_std_fwd(const float* k, int K, int Co, float* khat, float* rstd, void* wb, int Kp, void* wbT, int Cop,
+                          merlot_stream_t stream);
+/* gk[K, Co] += rstd * (dkhat - mean_K(dkhat) - khat * mean_K(dkhat * khat)); dkhat_t = the wgrad GEMM's output, [Co, ld]. */
+int merlot_weight_std_bwd(const float* dkhat_t, int64_t ld, const float* khat, const float* rstd, int K, int Co, float* gk,
+                          merlot_stream_t stream);
 /* y = [relu]( (x - mean) * rsqrt(var + eps) * gamma + beta [+ res] ), moments per (sample, group) over (H, W, C/G) from
  * one pass (var = E[x^2] - E[x]^2, :196-201).  stats: f32 [N, G, 2] = {mean, rsqrt(var + eps)}, written here, kept
  * for the backward.  res may be NULL. */

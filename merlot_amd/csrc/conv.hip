@@ -435,3 +435,95 @@ extern "C" int merlot_avgpool2_bwd(const void* x, void* dx, int N, int H, int W,
                        (int64_t)N, H, W, C);
     return merlot_launch_status("merlot_avgpool2_bwd");
 }
+
+// ------------------------------------------------------------------------------------------------
+// Weight standardisation of the ResNet-hybrid stem's kernels (utils/vision_transformer.py:52-56): per OUTPUT channel, over
+// (kh, kw, ci): khat = (k - mean) * rsqrt(var + 1e-5), population variance.  k is the fp32 master in HWIO order = [K, Co]
+// row-major (K = kh*kw*ci), so a channel is a strided COLUMN: one workgroup per 16 channels x 16 K-lanes (below).  Outputs: khat fp32 [K, Co] + rstd [Co] (for the backward), the
+// NT operand wb bf16 [Co, Kp] and the dgrad operand wbT bf16 [Kp, Cop] (their padding is zeroed by the caller once).
+// ------------------------------------------------------------------------------------------------
+namespace {
+// block = 16 channels x 16 K-lanes: thread (kl = tid >> 4, cl = tid & 15) walks rows kl, kl + 16, ... of its channel with 8
+// independent loads in flight (the tensors are a few MB: this is a latency problem, not a bandwidth one); LDS reduction over
+// the K-lanes.
+constexpr int WS_C = 16, WS_K = 16;
+__device__ __forceinline__ float ws_reduce(float v, float (&red)[WS_K][WS_C], int kl, int cl) {
+    __syncthreads();
+    red[kl][cl] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < WS_K; ++i) t += red[i][cl];
+    return t;
+}
+__global__ __launch_bounds__(256) void weight_std_fwd_kernel(const float* __restrict__ k, int K, int Co, float* __restrict__ khat,
+                                                             float* __restrict__ rstd_out, bf16* __restrict__ wb, int Kp,
+                                                             bf16* __restrict__ wbT, int Cop) {
+    __shared__ float red[WS_K][WS_C];
+    const int cl = threadIdx.x & 15, kl = threadIdx.x >> 4;
+    const int c = blockIdx.x * WS_C + cl;
+    const bool live = c < Co;
+    const int cc = live ? c : Co - 1;
+    float s = 0.f;
+#pragma unroll 8
+    for (int r = kl; r < K; r += WS_K) s += k[(int64_t)r * Co + cc];
+    const float mean = ws_reduce(s, red, kl, cl) / (float)K;
+    float q = 0.f;
+#pragma unroll 8
+    for (int r = kl; r < K; r += WS_K) {
+        const float d = k[(int64_t)r * Co + cc] - mean;
+        q += d * d;
+    }
+    const float var = ws_reduce(q, red, kl, cl) / (float)K;
+    const float rs = rsqrtf(var + 1e-5f);
+    if (!live) return;
+    if (kl == 0) rstd_out[c] = rs;
+#pragma unroll 8
+    for (int r = kl; r < K; r += WS_K) {
+        const float v = (k[(int64_t)r * Co + c] - mean) * rs;
+        khat[(int64_t)r * Co + c] = v;
+        wb[(int64_t)c * Kp + r] = (bf16)v;
+        wbT[(int64_t)r * Cop + c] = (bf16)v;
+    }
+}
+
+// dk = rstd * (dkhat - mean_K(dkhat) - khat * mean_K(dkhat * khat)), accumulated into the gradient arena.
+// dkhat is read TRANSPOSED from the wgrad GEMM's output [Co(+pad), ld] (row = channel, K contiguous).
+__global__ __launch_bounds__(256) void weight_std_bwd_kernel(const float* __restrict__ dkt, int64_t ld, const float* __restrict__ khat,
+                                                             const float* __restrict__ rstd, int K, int Co, float* __restrict__ gk) {
+    __shared__ float red[WS_K][WS_C];
+    const int cl = threadIdx.x & 15, kl = threadIdx.x >> 4;
+    const int c = blockIdx.x * WS_C + cl;
+    const bool live = c < Co;
+    const int cc = live ? c : Co - 1;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
+    for (int r = kl; r < K; r += WS_K) {
+        const float d = dkt[(int64_t)cc * ld + r];
+        s1 += d;
+        s2 += d * khat[(int64_t)r * Co + cc];
+    }
+    const float m1 = ws_reduce(s1, red, kl, cl) / (float)K;
+    const float m2 = ws_reduce(s2, red, kl, cl) / (float)K;
+    if (!live) return;
+    const float rs = rstd[c];
+#pragma unroll 8
+    for (int r = kl; r < K; r += WS_K)
+        gk[(int64_t)r * Co + c] += rs * (dkt[(int64_t)c * ld + r] - m1 - khat[(int64_t)r * Co + c] * m2);
+}
+}  // namespace
+
+extern "C" int merlot_weight_std_fwd(const float* k, int K, int Co, float* khat, float* rstd, void* wb, int Kp, void* wbT, int Cop,
+                                     merlot_stream_t stream) {
+    MERLOT_CHECK(k && khat && rstd && wb && wbT && K > 0 && Co > 0 && Kp >= K && Cop >= Co, MERLOT_ESHAPE, "merlot_weight_std_fwd: bad arguments");
+    hipLaunchKernelGGL(weight_std_fwd_kernel, dim3((Co + WS_C - 1) / WS_C), dim3(256), 0, (hipStream_t)stream, k, K, Co, khat, rstd, (bf16*)wb, Kp,
+                       (bf16*)wbT, Cop);
+    return merlot_launch_status("merlot_weight_std_fwd");
+}
+
+extern "C" int merlot_weight_std_bwd(const float* dkhat_t, int64_t ld, const float* khat, const float* rstd, int K, int Co, float* gk,
+                                     merlot_stream_t stream) {
+    MERLOT_CHECK(dkhat_t && khat && rstd && gk && K > 0 && Co > 0 && ld >= K, MERLOT_ESHAPE, "merlot_weight_std_bwd: bad arguments");
+    hipLaunchKernelGGL(weight_std_bwd_kernel, dim3((Co + WS_C - 1) / WS_C), dim3(256), 0, (hipStream_t)stream, dkhat_t, ld, khat, rstd, K, Co, gk);
+    return merlot_launch_status("merlot_weight_std_bwd");
+}

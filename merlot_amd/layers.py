@@ -394,18 +394,11 @@ class ResNetStemFn(torch.autograd.Function):
 
     @staticmethod
     def _std_kernel(w_hwio):
+        """utils/vision_transformer.py:52-56 (merlot_weight_std_fwd): khat fp32 [K, Co], rstd [Co], the NT operand [Co, Kp] and the
+        dgrad operand [Kp, Co(+pad)] in bf16, reduction dims padded to 64."""
         kh, kw, ci, co = w_hwio.shape
-        k = w_hwio.reshape(kh * kw * ci, co)
-        mean = k.mean(0, keepdim=True)
-        rstd = torch.rsqrt(((k - mean) ** 2).mean(0, keepdim=True) + 1e-5)
-        khat = (k - mean) * rstd                                      # [K, Co] fp32
         K = kh * kw * ci
-        Kp = (K + 63) // 64 * 64
-        wb = torch.zeros((co, Kp), device=k.device, dtype=BF16)       # NT operand [Co, Kp]
-        wb[:, :K] = khat.t().to(BF16)
-        wbT = torch.zeros((Kp, (co + 63) // 64 * 64), device=k.device, dtype=BF16)   # dgrad operand [Kp, Co(+pad)]
-        wbT[:K, :co] = khat.to(BF16)
-        return khat, rstd, wb, wbT
+        return ops.weight_std_fwd(w_hwio.reshape(K, co), (K + 63) // 64 * 64, (co + 63) // 64 * 64)
 
     @staticmethod
     def forward(ctx, image, store, cfg, anchor):
@@ -492,10 +485,9 @@ class ResNetStemFn(torch.autograd.Function):
             dyf = dyc.reshape(-1, co)
             dk = torch.zeros((co + (co % 2), a.shape[1]), device=dyf.device, dtype=F32)
             ops.gemm_tn(dyf, a, dk, accumulate=False, m=co + (co % 2))                 # dKhat^T [Co, Kp]
-            dkh = dk[:co, :khat.shape[0]].t()                                           # [K, Co]
-            # weight standardisation backward: khat = (k - mean) * rstd per output channel
-            dw = rstd * (dkh - dkh.mean(0, keepdim=True) - khat * (dkh * khat).mean(0, keepdim=True))
-            store.g(name + '/kernel').add_(dw.reshape(store.g(name + '/kernel').shape))
+            # weight standardisation backward (khat = (k - mean) * rstd per output channel), accumulated into the arena
+            gk = store.g(name + '/kernel')
+            ops.weight_std_bwd(dk, khat, rstd, gk.view(khat.shape))
             if not need_dx:
                 return None
             kp_co = wbT.shape[1]

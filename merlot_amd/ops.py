@@ -528,3 +528,24 @@ def jpeg_idct_rgb(coef, infos, plane_bytes, dst_bytes, dst=None):
     call('merlot_jpeg_idct_rgb', _p(coef), infos_host.data_ptr(), _p(infos_dev), len(infos), _p(ws), ws.numel(), _p(dst), dst.numel(),
          _stream())
     return dst
+
+
+def weight_std_fwd(k2d, Kp, Cop):
+    """k2d: fp32 [K, Co] (HWIO kernel flattened) -> (khat fp32 [K, Co], rstd [Co], wb bf16 [Co, Kp], wbT bf16 [Kp, Cop])."""
+    _chk(k2d, F32, 'k2d')
+    assert k2d.is_contiguous()
+    K, Co = k2d.shape
+    khat = torch.empty_like(k2d)
+    rstd = torch.empty(Co, device=k2d.device, dtype=F32)
+    wb = torch.zeros((Co, Kp), device=k2d.device, dtype=BF16) if Kp != K else torch.empty((Co, Kp), device=k2d.device, dtype=BF16)
+    wbT = torch.zeros((Kp, Cop), device=k2d.device, dtype=BF16) if (Kp != K or Cop != Co) else torch.empty((Kp, Cop), device=k2d.device, dtype=BF16)
+    call('merlot_weight_std_fwd', _p(k2d), K, Co, _p(khat), _p(rstd), _p(wb), Kp, _p(wbT), Cop, _stream())
+    return khat, rstd, wb, wbT
+
+
+def weight_std_bwd(dkhat_t, khat, rstd, gk2d):
+    """gk2d [K, Co] (a view of the gradient arena) += the standardisation's backward of dkhat_t [Co(+pad), ld >= K]."""
+    _chk(dkhat_t, F32, 'dkhat_t'); _chk(khat, F32, 'khat'); _chk(rstd, F32, 'rstd'); _chk(gk2d, F32, 'gk2d')
+    assert gk2d.is_contiguous() and khat.is_contiguous()
+    K, Co = khat.shape
+    call('merlot_weight_std_bwd', _p(dkhat_t), dkhat_t.stride(0), _p(khat), _p(rstd), K, Co, _p(gk2d), _stream())

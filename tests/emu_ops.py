@@ -469,7 +469,25 @@ def adamw_step(param, grad, m, v, lr, beta1, beta2, eps, weight_decay, grad_scal
     v.copy_(torch.from_numpy(oo.encode_v(nv.numpy())) if bf else nv)
 
 
-_NAMES = ['gemm_nt', 'gemm_tn', 'patch_embed_fwd', 'patch_embed_wgrad', 'ln_fwd', 'ln_bwd', 'attention_fwd',
+def weight_std_fwd(k2d, Kp, Cop):
+    K, Co = k2d.shape
+    mean = k2d.mean(0, keepdim=True)
+    rstd = torch.rsqrt(((k2d - mean) ** 2).mean(0, keepdim=True) + 1e-5)
+    khat = (k2d - mean) * rstd
+    wb = torch.zeros((Co, Kp), dtype=BF16)
+    wb[:, :K] = khat.t().to(BF16)
+    wbT = torch.zeros((Kp, Cop), dtype=BF16)
+    wbT[:K, :Co] = khat.to(BF16)
+    return khat, rstd.reshape(-1), wb, wbT
+
+
+def weight_std_bwd(dkhat_t, khat, rstd, gk2d):
+    K, Co = khat.shape
+    dkh = dkhat_t[:Co, :K].t()
+    gk2d.add_(rstd[None, :] * (dkh - dkh.mean(0, keepdim=True) - khat * (dkh * khat).mean(0, keepdim=True)))
+
+
+_NAMES = ['weight_std_fwd', 'weight_std_bwd', 'gemm_nt', 'gemm_tn', 'patch_embed_fwd', 'patch_embed_wgrad', 'ln_fwd', 'ln_bwd', 'attention_fwd',
           'attention_bwd', 'attention_colsum', 'cast_bf16', 'cast_transpose_bf16', 'colsum_bf16', 'gather_add4',
           'scatter_add_rows', 'dropout_apply', 'cls_avgpool_fwd', 'cls_avgpool_bwd', 'softmax_ce', 'l2norm_fwd',
           'l2norm_bwd', 'gelu_fwd', 'gelu_bwd', 'mask_inputs', 'temporal_labels', 'shuffled_idx', 'im2col3x3', 'col2im3x3',

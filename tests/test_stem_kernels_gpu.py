@@ -60,3 +60,29 @@ def test_avgpool2(ops):
     assert rel_l2(ops.avgpool2_fwd(x.cuda()).cpu(), emu.avgpool2_fwd(x)) < 3e-3
     dy = torch.randn(3, 6, 4, 64, generator=g).to(BF16)
     assert torch.equal(ops.avgpool2_bwd(dy.cuda()).cpu(), emu.avgpool2_bwd(dy))
+
+
+@pytest.mark.parametrize('kh,ci,co', [(3, 3, 32), (1, 64, 256), (3, 64, 64), (1, 256, 100)])
+def test_weight_standardisation_kernels(kh, ci, co):
+    """merlot_weight_std_fwd / _bwd (utils/vision_transformer.py:52-56) against the torch expression they replaced, and the
+    backward against autograd of that expression."""
+    from merlot_amd import ops
+    g = torch.Generator().manual_seed(kh * 100 + co)
+    w = (torch.randn(kh, kh, ci, co, generator=g) * 0.3 + 0.1)
+    K = kh * kh * ci
+    Kp, Cop = (K + 63) // 64 * 64, (co + 63) // 64 * 64
+    k2 = w.reshape(K, co).clone().requires_grad_(True)
+    mean = k2.mean(0, keepdim=True)
+    khat_ref = (k2 - mean) * torch.rsqrt(((k2 - mean) ** 2).mean(0, keepdim=True) + 1e-5)
+    khat, rstd, wb, wbT = ops.weight_std_fwd(w.reshape(K, co).cuda().contiguous(), Kp, Cop)
+    assert (khat.cpu() - khat_ref.detach()).abs().max().item() < 2e-5
+    assert torch.equal(wb[:, :K].float().cpu(), khat.cpu().t().to(torch.bfloat16).float())
+    assert torch.equal(wbT[:K, :co].float().cpu(), khat.cpu().to(torch.bfloat16).float())
+    assert float(wb[:, K:].float().abs().sum()) == 0.0 and float(wbT[K:].float().abs().sum()) == 0.0
+    dkh = torch.randn(K, co, generator=g)
+    (khat_ref * dkh).sum().backward()
+    dkt = torch.zeros(co + (co % 2), Kp)
+    dkt[:co, :K] = dkh.t()
+    gk = torch.full((K, co), 0.5).cuda()
+    ops.weight_std_bwd(dkt.cuda(), khat, rstd, gk)
+    assert (gk.cpu() - 0.5 - k2.grad).abs().max().item() < 1e-4 * max(1.0, float(k2.grad.abs().max()))
