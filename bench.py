@@ -169,8 +169,8 @@ def measured_traffic():
     if src != gemm_source_hash():
         return {'bytes_per_launch': None, 'why': f'profiles/r02_traffic.txt was measured on GEMM sources {src}, the tree has '
                                                  f'{gemm_source_hash()}: stale, re-run scripts/gpu_traffic.sh'}
-    return {'bytes_per_launch': (2.0 * fetch + write) * 1024.0, 'algorithmic_bytes_per_launch': 2340.4e6,
-            'launch': 'forward Linear M=304128 (= 96 examples x 16 frames x 198 tokens) N=3072 K=768, bias epilogue, bf16 out (gemm_nt_p8_kernel<0,false,false>)',
+    return {'bytes_per_launch': (2.0 * fetch + write) * 1024.0, 'algorithmic_bytes_per_launch': 3119.0e6,
+            'launch': 'forward Linear M=405504 (= 128 examples x 16 frames x 198 tokens) N=3072 K=768, bias epilogue, bf16 out (gemm_nt_p8_kernel<0,false,false>)',
             'source': 'profiles/r02_traffic.txt', 'gemm_source_hash': src}
 
 
@@ -179,8 +179,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--examples', type=int, default=None, help='examples (x16 segments) per GPU per step (default 96 = 1536 segments: the throughput plateau of the batch sweep, '
-                         '165 GB of the 288; round 1 and most of round 2 were quoted at 32; config 5: 12)')
+    ap.add_argument('--examples', type=int, default=None, help='examples (x16 segments) per GPU per step (default 128 = 2048 segments: the throughput plateau of the batch sweep, '
+                         '~220 GB of the 288; round 1 and most of round 2 were quoted at 32; config 5: 12)')
     ap.add_argument('--config', type=int, default=2, choices=(2, 5),
                     help='BASELINE.json configs[]: 2 = the headline 4-segment 224^2 bf16 workload (configs[1]; DP over --gpus); '
                          '5 = NOT the headline: the 16-segment 384^2 long-video variant with fp8 forward GEMMs (configs[4])')
@@ -205,7 +205,7 @@ def main():
     from merlot_amd.train import Trainer, synthetic_batch
 
     if args.examples is None:
-        args.examples = 12 if args.config == 5 else 96
+        args.examples = 12 if args.config == 5 else 128
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))

@@ -1775,8 +1775,8 @@ int tn_p8_launch(GemmTNArgs& a, int accumulate, float* ws, int64_t ws_bytes, hip
 
 int gemm_tn_dispatch(GemmTNArgs& a, int accumulate, float* ws, int64_t ws_bytes, hipStream_t s) {
     if (!tn_ring_ok(a)) return tn_launch(a, accumulate, s);
-    int tn_kernel = (tn_p8_shape(a.M, a.N, a.R / 64 * 64) && (int64_t)a.R * a.lda * 2 < (1LL << 31) &&
-                     (int64_t)a.R * a.ldb * 2 < (1LL << 31)) ? 1 : 0;
+    int tn_kernel = (tn_p8_shape(a.M, a.N, a.R / 64 * 64) && ((int64_t)a.R + 64) * a.lda * 2 < (1LL << 32) &&
+                     ((int64_t)a.R + 64) * a.ldb * 2 < (1LL << 32)) ? 1 : 0;     // unsigned 32-bit byte offsets
 #ifdef MERLOT_EXPERIMENTS
     if (const char* e = getenv("MERLOT_TN_P8")) tn_kernel = atoi(e);
 #endif

@@ -10,7 +10,7 @@ from merlot_amd import ops  # noqa: E402
 BF16 = torch.bfloat16
 g = torch.Generator(device='cuda').manual_seed(0)
 rnd = lambda *s: (torch.randn(s, device='cuda', generator=g) * 0.5).to(BF16)  # noqa: E731
-T = 304128                                    # ViT rows of one bench step (96 examples x 16 frames x 198 tokens)
+T = 405504                                    # ViT rows of one bench step (128 examples x 16 frames x 198 tokens)
 a, w = rnd(T, 768), rnd(3072, 768)
 bias = torch.zeros(3072, device='cuda')
 for _ in range(3):
@@ -26,9 +26,9 @@ dy, x = rnd(T, 3072), rnd(T, 768)
 gw = torch.zeros((3072, 768), device='cuda')
 for _ in range(3):
     ops.gemm_tn(dy, x, gw)                                                  # gemm_tn_p8_kernel + tn_reduce_kernel
-qkv = rnd(1536 * 198, 2304)
+qkv = rnd(2048 * 198, 2304)
 for _ in range(2):
-    o, lse = ops.attention_fwd(qkv, 1536, 198, 12)
-    do = rnd(1536 * 198, 768)
-    ops.attention_bwd(qkv, o, do, lse, 1536, 198, 12)
+    o, lse = ops.attention_fwd(qkv, 2048, 198, 12)
+    do = rnd(2048 * 198, 768)
+    ops.attention_bwd(qkv, o, do, lse, 2048, 198, 12)
 torch.cuda.synchronize()

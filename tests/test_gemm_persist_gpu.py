@@ -176,3 +176,30 @@ def test_fused_column_sums_bias_gradient(ops, M, N, K, epi):
     exact = plain.double().sum(0).float() + 2.0
     scale = plain.float().abs().sum(0) + 1.0                      # cancellation-aware: errors relative to the L1 mass
     assert float(((cs - exact).abs() / scale).max()) < 2e-6 and float(((ref - exact).abs() / scale).max()) < 2e-6
+
+
+def test_operands_between_2_and_4_gib_stay_on_the_ping_pong_kernels():
+    """the ping-pong kernels address their operands with UNSIGNED 32-bit byte offsets: an A operand of 2.5 GB (the fc2 input at 128
+    examples per GPU) must give the same rows as a small GEMM on those rows, for the NT kernel (bottom rows = highest offsets,
+    ragged last tile) and the TN kernel (the last reduction rows)."""
+    from merlot_amd import ops
+    from merlot_amd.lib import LIB
+    M, K, N = 410000 + 37, 3072, 256
+    assert M * K * 2 > 2 ** 31 and (M + 256) * K * 2 < 2 ** 32
+    g = torch.Generator(device='cuda').manual_seed(1)
+    a = (torch.randn(M, K, device='cuda', generator=g) * 0.5).to(torch.bfloat16)
+    b = (torch.randn(N, K, device='cuda', generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, device='cuda', generator=g)
+    assert LIB.query('merlot_gemm_bf16_nt_plan', M, N, K) == 22
+    out = ops.gemm_nt(a, b, bias=bias)
+    for r0 in (0, 200000, M - 300):                        # first rows, the 2 GiB boundary region, the ragged last tile
+        want = torch.addmm(bias, a[r0:r0 + 300].float(), b.float().t())
+        assert rel_l2(out[r0:r0 + 300], want) < 6e-3, r0
+    # TN: dW[m][n] = sum_r A[r][m] B[r][n] with A = [R, 3072] of 2.5 GB
+    bb = (torch.randn(M, N, device='cuda', generator=g) * 0.05).to(torch.bfloat16)
+    dw = torch.zeros(K, N, device='cuda')
+    ops.gemm_tn(a, bb, dw, accumulate=False)
+    want = torch.zeros(K, N, device='cuda', dtype=torch.float64)
+    for r0 in range(0, M, 50000):
+        want += a[r0:r0 + 50000].double().t() @ bb[r0:r0 + 50000].double()
+    assert rel_l2(dw, want.float()) < 2e-3
