@@ -160,9 +160,14 @@ class TransformerStackFn(torch.autograd.Function):
                                      branch_bias_grad=w.proj.gb, drop_p=p, drop_seed=_site_seed(seed, l, 0))
             # ---- attention branch: h_mid = h + drop(proj(attn(qkv(LN1(h)))))             db1 = d(proj output)
             ops.gemm_tn(db1, ctx_, w.proj.gw)
-            dctx = ops.gemm_nt(db1, w.proj.wbT)
+            # bias gradients of the fused QKV projection without a pass over dQKV [T, 3D]:
+            #   V: sum_k dV_k = sum_q dO_q because every softmax row sums to 1 -> the column sums of dO, from the epilogue of the
+            #      GEMM that produces it;  K: identically 0 (adding a constant to every key shifts each query's scores by a
+            #      constant: softmax does not move);  Q: the column sums of the first third of dQKV only.
+            D = heads * 64
+            dctx = ops.gemm_nt(db1, w.proj.wbT, colsum_out=w.qkv.gb[2 * D:3 * D])
             dqkv = ops.attention_bwd(qkv, ctx_, dctx, lse, B, S, heads, valid, seg=ctx.seg)
-            ops.colsum_bf16(dqkv, w.qkv.gb)
+            ops.colsum_bf16(dqkv[:, :D], w.qkv.gb[:D])
             ops.gemm_tn(dqkv, x1, w.qkv.gw)
             dx1 = ops.gemm_nt(dqkv, w.qkv.wbT)
             if l > 0:
