@@ -161,7 +161,7 @@ int merlot_ln_bwd(const void* dy, int dy_f32, const void* x, int x_f32, const fl
 int merlot_attention_fwd(const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse, const uint8_t* valid,
                          const int32_t* seg, int B, int S, int heads, float scale, float* colsum_lo, float* colsum_hi,
                          int qsplit, int valid_q_only, float weight, merlot_stream_t stream);
-/* dqkv (bf16, same layout as qkv) from dout.  delta: f32 workspace [B*heads*S]. */
+/* dqkv (bf16, same layout as qkv) from dout.  delta: f32 workspace [B*heads*S] (written by the dQ kernel, read by the dK/dV kernel). */
 int merlot_attention_bwd(const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout, int64_t lddo,
                          const float* lse, const uint8_t* valid, const int32_t* seg, void* dqkv, int64_t lddqkv,
                          float* delta, int B, int S, int heads, float scale, merlot_stream_t stream);

@@ -511,33 +511,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const AttnArgs p, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward preprocess: delta[b,h,s] = sum_d dO * O
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs p, float* delta) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t nrows = (int64_t)p.B * p.S;
-    if (row >= nrows) return;
-    const int b = (int)(row / p.S), s = (int)(row - (int64_t)b * p.S);
-    // each lane handles 8 contiguous features, 8 lanes per head, 64 lanes = 8 heads per pass
-    for (int h0 = 0; h0 < p.heads; h0 += 8) {
-        const int h = h0 + (lane >> 3);
-        float acc = 0.f;
-        if (h < p.heads) {
-            const int col = h * 64 + (lane & 7) * 8;
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(p.out + row * p.ldo + col);
-            const bf16x8 d = *reinterpret_cast<const bf16x8*>(p.dout + row * p.lddo + col);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc += (float)a[e] * (float)d[e];
-        }
-        acc += __shfl_xor(acc, 1, 64);
-        acc += __shfl_xor(acc, 2, 64);
-        acc += __shfl_xor(acc, 4, 64);
-        if (h < p.heads && (lane & 7) == 0) delta[((int64_t)b * p.heads + h) * p.S + s] = acc;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // backward dQ: one wave per 32 query rows, loop over key tiles (same lane<->query layout and bias vectors as forward)
 // ------------------------------------------------------------------------------------------------
 template <bool MASKED>
@@ -573,7 +546,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
     }
     const int64_t stat = ((int64_t)b * p.heads + h) * S + q;
     const float lse2 = p.lse[stat] * LOG2E;
-    const float dl = p.delta[stat];
+    // delta_q = sum_d dO[q][d] * O[q][d], computed HERE from the dO fragments this lane holds anyway (+ one read of its O
+    // rows) instead of by a separate pass over O and dO; lanes l and l ^ 32 hold the two halves of a row.  Published for the
+    // dK / dV kernel, which runs after this one on the same stream.
+    float dl = 0.f;
+    {
+        const bf16* orow = p.out + ((int64_t)b * S + q) * p.ldo + h * 64;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const bf16x8 of = *reinterpret_cast<const bf16x8*>(orow + kk * 16 + hi * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dl += (float)of[e] * (float)dof[kk][e];
+        }
+        dl += __shfl_xor(dl, 32, 64);
+        if (hi == 0 && qw0 + (lane & 31) < S) const_cast<float*>(p.delta)[stat] = dl;
+    }
     const float sc = qv ? p.scale * LOG2E : 0.f;
     const float dsc = qv ? p.scale : 0.f;             // masked pairs have p == 0 exactly; padded query rows get ds = 0
     const float* bias = (qv ? biasA : biasB) + 4 * hi;
@@ -963,7 +950,6 @@ extern "C" int merlot_attention_bwd(const void* qkv, int64_t ld, const void* out
     a.lse = (float*)lse; a.delta = delta; a.valid = valid; a.seg = seg; a.dqkv = (bf16*)dqkv; a.lddqkv = lddqkv;
     a.B = B; a.S = S; a.heads = heads; a.scale = scale;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv((int64_t)B * S, 4)), dim3(256), 0, s, a, delta);
     if (valid) {
         hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);
         hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);
