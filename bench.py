@@ -180,7 +180,7 @@ def main():
     ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--examples', type=int, default=None, help='examples (x16 segments) per GPU per step (default 128 = 2048 segments: the throughput plateau of the batch sweep, '
-                         '~220 GB of the 288; round 1 and most of round 2 were quoted at 32; config 5: 12)')
+                         '~220 GB of the 288; round 1 and most of round 2 were quoted at 32; config 5: 48 = 768 segments of 384^2, ~210 GB)')
     ap.add_argument('--config', type=int, default=2, choices=(2, 5),
                     help='BASELINE.json configs[]: 2 = the headline 4-segment 224^2 bf16 workload (configs[1]; DP over --gpus); '
                          '5 = NOT the headline: the 16-segment 384^2 long-video variant with fp8 forward GEMMs (configs[4])')
@@ -205,7 +205,7 @@ def main():
     from merlot_amd.train import Trainer, synthetic_batch
 
     if args.examples is None:
-        args.examples = 12 if args.config == 5 else 128
+        args.examples = 48 if args.config == 5 else 128
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
