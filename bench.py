@@ -133,6 +133,29 @@ def cpu_baseline():
     return {'value': None, 'unit': 'segments/s', 'cores': usable_cores(), 'kind': 'port', 'sample': why}
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(('127.0.0.1', 0))
+        return so.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N ...` started without torchrun (no RANK / WORLD_SIZE): run the same command line as
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`
+    and hand its stdout / stderr / exit status through unchanged."""
+    import subprocess
+    port = os.environ.get('MASTER_PORT') or str(free_port())
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', '1')
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        raise SystemExit(rc)
+
+
 GEMM_SOURCES = ('gemm.hip', 'gemm_p8.inc', 'gemm_ring.h', 'common.h')
 
 
@@ -197,6 +220,10 @@ def main():
     if args.cpu_baseline_worker:
         cpu_baseline_worker(args.cpu_baseline_worker)
         return
+    if args.gpus > 1 and 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: re-exec THIS command line under torch.distributed.run, one rank
+        # per GPU on this node (the contract's own launch line); rank 0's JSON line and the exit status pass through.
+        return self_launch(args.gpus)
 
     import torch
     import torch.distributed as dist

@@ -208,3 +208,23 @@ def test_bench_py_code_path_two_ranks_emulated(tmp_path):
     assert res['config']['parallelism'] == 'dp2' and res['config']['segments_per_gpu_per_step'] == 4
     assert abs(res['value'] - 2 * 4 * 2 / (res['ms_per_step'] * 2 / 1e3)) < 1e-6 * res['value']     # whole-job aggregate
     assert res['config']['final_loss'] == res['config']['final_loss'] and res['config']['final_loss'] < 30.0
+
+
+@pytest.mark.timeout(900)
+def test_bench_py_self_launches_when_started_without_torchrun(tmp_path):
+    """`python bench.py --gpus 2` with no RANK / WORLD_SIZE in the environment (the command shape of the
+    driver's 1-GPU record) must not die before the first collective: it re-executes itself under torch.distributed.run and
+    rank 0's JSON line comes through."""
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    env['OMP_NUM_THREADS'] = '4'
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--examples', '1',
+           '--cpu-emulate']
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=850, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['config']['parallelism'] == 'dp2'
