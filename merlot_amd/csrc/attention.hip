@@ -295,7 +295,7 @@ __device__ __forceinline__ long cvt8_e4m3(u32x4 raw, float s) {
     const bf16x8 v = __builtin_bit_cast(bf16x8, raw);
     float f[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) f[e] = __builtin_fminf(__builtin_fmaxf((float)v[e] * s, -448.f), 448.f);
+    for (int e = 0; e < 8; ++e) f[e] = clamp_e4m3((float)v[e] * s);
     int w0 = 0, w1 = 0;
     w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w0, false);
     w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);

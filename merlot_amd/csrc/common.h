@@ -145,4 +145,11 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// saturating clamp into e4m3's finite range that PROPAGATES NaN (fminf / fmaxf return the other operand for a NaN input and
+// would turn a diverged activation into +-448 silently; v_cvt_pk_fp8_f32 maps NaN to e4m3fn's NaN encoding)
+__device__ __forceinline__ float clamp_e4m3(float x) {
+    const float c = __builtin_fminf(__builtin_fmaxf(x, -448.f), 448.f);
+    return x != x ? x : c;
+}
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void quantize_e4m3_kernel(const bf16* __restri
         const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + r * ldx + (int64_t)c * 8);
         float f[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = __builtin_fminf(__builtin_fmaxf((float)v[e] * s, -E4M3_MAX), E4M3_MAX);
+        for (int e = 0; e < 8; ++e) f[e] = clamp_e4m3((float)v[e] * s);
         u32x2 o;
         int w = 0;
         w = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w, false);

@@ -1588,7 +1588,8 @@ int gemm_nt_dispatch(GemmNTArgs& a, int epilogue, int out_f32, hipStream_t s) {
     // fused column sums of C (bias gradient): in the ping-pong kernel's epilogue when its row-contiguous path applies,
     // otherwise the stand-alone column-sum kernel right behind the GEMM (same stream, same result up to summation order)
     float* const colsum = a.colsum;
-    const bool cs_fused = colsum && cfg == MERLOT_NT_KERNEL_P8 && !out_f32 && (a.N % 8 == 0) && (a.ldc % 8 == 0) &&
+    // (N % 64: the epilogue flushes its per-lane column accumulators per whole 64-column slab; a ragged last slab would be dropped)
+    const bool cs_fused = colsum && cfg == MERLOT_NT_KERNEL_P8 && !out_f32 && (a.N % 64 == 0) && (a.ldc % 8 == 0) &&
                           (a.ld_aux_in % 8 == 0) && (a.ld_aux_out % 8 == 0) && (((uintptr_t)a.C | (uintptr_t)colsum) & 15) == 0;
     if (!cs_fused) a.colsum = nullptr;
     if (colsum && !cs_fused) {

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
         for (int i = 0; i < NS; ++i) {
             float f[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) f[e] = __builtin_fminf(__builtin_fmaxf(v[i][e] * sq, -448.f), 448.f);
+            for (int e = 0; e < 4; ++e) f[e] = clamp_e4m3(v[i][e] * sq);
             int w = 0;
             w = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w, false);
             w = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w, true);

@@ -6,9 +6,10 @@ decoder.  `entropy_decode` returns None for files outside the supported subset (
 the caller decodes those with the host library, as before."""
 import numpy as np
 
-from .lib import LIB, MerlotHipError
+from .lib import LIB
 
 JPEG_MALFORMED, JPEG_UNSUPPORTED, JPEG_CAPACITY = -20, -21, -22
+MAX_IMAGE_PIXELS = 89478485           # PIL.Image.MAX_IMAGE_PIXELS: the host decoder's own decompression-bomb threshold
 
 # mirrors merlot_jpeg_info_t (include/merlot_hip.h), C layout
 INFO_DTYPE = np.dtype([('width', np.int32), ('height', np.int32), ('subsampling', np.int32), ('blocks_w', np.int32, (3,)),
@@ -20,7 +21,8 @@ assert INFO_DTYPE.itemsize == 480
 
 def entropy_decode(data):
     """bytes of one JPEG file -> (coef int16 [coef_count], info INFO_DTYPE scalar array of shape (1,)), or None when the file is
-    not baseline 8-bit YCbCr 4:4:4 / 4:2:0 (decode it with the host library).  Raises on a malformed file."""
+    not baseline 8-bit YCbCr 4:4:4 / 4:2:0, is larger than MAX_IMAGE_PIXELS, or is malformed / truncated -- the caller then
+    decodes it with the host library (PIL), which keeps its own error behaviour for such files."""
     buf = np.frombuffer(bytes(data), np.uint8)
     info = np.zeros(1, INFO_DTYPE)
     dll = LIB.load()
@@ -28,13 +30,15 @@ def entropy_decode(data):
     if rc == JPEG_UNSUPPORTED:
         return None
     if rc != 0:
-        raise MerlotHipError(f"merlot_jpeg_entropy_decode: malformed JPEG ({rc})")
+        return None                                       # malformed / truncated: the host library decides (it may still cope)
+    # decompression-bomb guard BEFORE the coefficient buffer is sized from the header (a crafted 65535 x 65535 SOF would ask
+    # for ~13 GB inside a loader thread): above PIL's own limit the frame goes to the host decoder, which refuses it
+    if int(info['width'][0]) * int(info['height'][0]) > MAX_IMAGE_PIXELS:
+        return None
     coef = np.empty(int(info['coef_count'][0]), np.int16)
     rc = dll.merlot_jpeg_entropy_decode(buf.ctypes.data, buf.size, info.ctypes.data, coef.ctypes.data, coef.size)
-    if rc == JPEG_UNSUPPORTED:
+    if rc != 0:                                           # unsupported or malformed scan data: host decoder
         return None
-    if rc != 0:
-        raise MerlotHipError(f"merlot_jpeg_entropy_decode: malformed JPEG ({rc})")
     return coef, info
 
 

@@ -132,6 +132,7 @@ class TransformerStackFn(torch.autograd.Function):
         y, _, meanf, rstdf = ops.ln_fwd(h, stack.ln_final.gamma, stack.ln_final.beta)
         ctx.stack, ctx.B, ctx.S, ctx.valid, ctx.heads, ctx.p, ctx.seed, ctx.nl = stack, B, S, valid, heads, p, seed, nl
         ctx.seg = seg
+        ctx.fp8_attn = fp8_attn
         ctx.saved = saved
         ctx.final = (h, meanf, rstdf)
         return y
@@ -165,9 +166,12 @@ class TransformerStackFn(torch.autograd.Function):
             #      GEMM that produces it;  K: identically 0 (adding a constant to every key shifts each query's scores by a
             #      constant: softmax does not move);  Q: the column sums of the first third of dQKV only.
             D = heads * 64
-            dctx = ops.gemm_nt(db1, w.proj.wbT, colsum_out=w.qkv.gb[2 * D:3 * D])
+            #   (fp8 attention forward: the saved log-sum-exp comes from e4m3 scores while the backward recomputes P from bf16
+            #   ones, so the rows of P no longer sum to exactly 1 and the shortcut does not hold: all three thirds are summed)
+            exact_rows = not ctx.fp8_attn
+            dctx = ops.gemm_nt(db1, w.proj.wbT, colsum_out=w.qkv.gb[2 * D:3 * D] if exact_rows else None)
             dqkv = ops.attention_bwd(qkv, ctx_, dctx, lse, B, S, heads, valid, seg=ctx.seg)
-            ops.colsum_bf16(dqkv[:, :D], w.qkv.gb[:D])
+            ops.colsum_bf16(dqkv[:, :D] if exact_rows else dqkv, w.qkv.gb[:D] if exact_rows else w.qkv.gb)
             ops.gemm_tn(dqkv, x1, w.qkv.gw)
             dx1 = ops.gemm_nt(dqkv, w.qkv.wbT)
             if l > 0:

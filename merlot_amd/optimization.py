@@ -75,6 +75,7 @@ class AdamOptimizer(object):
         # launch driven by a per-64-element flag table; otherwise one launch per run.
         rest = {k[1:] for _, _, k in runs}
         self.single_launch = len(rest) == 1 and next(iter(rest))[0] != 0.0
+        self.single_key = next(iter(rest)) if len(rest) == 1 else None      # (lr, beta1, beta2, eps) of that one launch
         if self.single_launch:
             flags = torch.zeros(store.numel // 64, dtype=torch.uint8)
             wds = {k[0] for _, _, k in runs if k[0] > 0}
@@ -113,8 +114,9 @@ class AdamOptimizer(object):
     def step(self):
         st = self.store
         if self.single_launch:
-            ops.adamw_step(st.master, st.grad, self.m, self.v, self.lr * self._lr_mult(self.b1, self.b2), self.b1, self.b2,
-                           self.eps, self._wd, self.grad_scale, wd_flags=self._wd_flags)
+            lr, b1, b2, eps = self.single_key                        # the ONE (lr, beta1, beta2, eps) every run shares: a
+            ops.adamw_step(st.master, st.grad, self.m, self.v, lr * self._lr_mult(b1, b2), b1, b2,   # uniform param_override included
+                           eps, self._wd, self.grad_scale, wd_flags=self._wd_flags)
             self.step_count += 1
             st.master_version += 1
             return

@@ -92,8 +92,9 @@ class Trainer(object):
             return self.model_fn(features, None, 'train', {'store': self.store, 'dist': self.dist, 'seed': self.step_seed()})
 
     def check_inputs(self, wait=True):
-        """raise if an earlier step embedded a token id outside [0, vocab) (utils/model_utils.py:256-258's in-graph assertion).
-        The flag was copied to pinned host memory asynchronously; by the time the next step has been enqueued it is there."""
+        """raise if the step embedded a token id outside [0, vocab) (utils/model_utils.py:256-258's in-graph assertion).
+        The flag is copied to pinned host memory asynchronously behind the forward pass; `Trainer.step` reads it after the
+        backward has been enqueued and before the optimizer update."""
         if self._pending_check is None:
             return
         host, ev, step = self._pending_check
@@ -125,13 +126,16 @@ class Trainer(object):
     def step(self, features):
         self.store.zero_grad()
         out = self.model_fn(features, None, 'train', {'store': self.store, 'dist': self.dist, 'seed': self.step_seed()})
-        self.check_inputs()                                  # the PREVIOUS step's flag (long since on the host)
-        self._defer_check(out.get('token_id_out_of_range'))
+        self._defer_check(out.get('token_id_out_of_range'))  # async copy of the flag, recorded right behind the forward
         out['loss'].backward()
         if self.opt.clip_norm > 0.0:                         # clip the local gradients, then sum across replicas
             out['grad_norm'] = self.opt.clip_local_gradients()
         if self.reducer is not None:
             self.reducer.finish()
+        # THIS step's flag, before its update is applied (the reference fails the step in-graph, utils/model_utils.py:256-258):
+        # the host waits for the forward's embedding lookups only -- the whole backward is already queued behind them, so
+        # the GPU never idles -- and a bad batch neither reaches the weights nor a checkpoint.
+        self.check_inputs(wait=True)
         self.opt.step()
         self.step_idx += 1
         return out

@@ -158,7 +158,8 @@ def test_persist_dyn_back_to_back_launches_reuse_counter_slots(ops):
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(101376, 3072, 768, 'dgelu'), (42084, 3072, 768, 'dgelu'), (42084, 2304, 768, 'none'),
-                                        (300, 768, 768, 'dgelu')])
+                                        (300, 768, 768, 'dgelu'),
+                                        (65536, 200, 768, 'none')])   # N % 64 != 0: a ragged last 64-column slab
 def test_fused_column_sums_bias_gradient(ops, M, N, K, epi):
     """colsum_out: the column sums of the stored bf16 output from the GEMM's own epilogue (ping-pong kernel: interior AND
     ragged tiles; small problems: the stand-alone kernel behind the GEMM) == merlot_colsum_bf16 of that output; the output

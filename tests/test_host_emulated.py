@@ -304,6 +304,32 @@ def test_optimizer_hyperparameter_semantics_follow_the_reference(emu):
         assert torch.allclose(st.p(n).double(), want, rtol=2e-5, atol=1e-9), n
 
 
+def test_uniform_param_override_reaches_the_single_launch_update(emu):
+    """an override that matches EVERY variable (here beta_2 / epsilon for '.*') collapses to one (lr, b1, b2, eps)
+    key, so the whole arena updates in one launch -- which must use the overridden values, not the constructor defaults."""
+    from merlot_amd import ParamStore
+    from merlot_amd.optimization import AdamOptimizer, learning_rate_scale
+    cfg = tiny_config()
+    st = ParamStore(cfg, 'cpu', seed=0)
+    opt = AdamOptimizer(st, 1e-3, 100, 10, weight_decay_rate=0.1, clip_norm=0.0,
+                        param_overrides=[[['LayerNorm', 'bias'], {'weight_decay_rate': 0}], [['.*'], {'beta_2': 0.95, 'epsilon': 1e-4}]])
+    assert opt.single_launch and opt.single_key == (1e-3, 0.9, 0.95, 1e-4)
+    g = torch.Generator().manual_seed(2)
+    st.grad.copy_(torch.randn(st.grad.shape, generator=g) * 1e-3)
+    before = st.master.clone()
+    opt.step_count = 5
+    grads = {n: st.g(n).clone() for n in ('encoder/layer00/output/kernel', 'encoder/layer00/output/bias')}
+    opt.step()
+    scale = learning_rate_scale(5, 100, 10)
+    for n, wd in (('encoder/layer00/output/kernel', 0.1), ('encoder/layer00/output/bias', 0.0)):
+        p0, gr = st.view(before, n).double(), grads[n].double()
+        b1, b2, eps, t = 0.9, 0.95, 1e-4, 6.0
+        lr = 1e-3 * scale * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+        nm, nv = (1 - b1) * gr, (1 - b2) * (gr * gr + 1e-30)
+        want = p0 - lr * (nm / (nv.sqrt() + eps) + wd * p0)
+        assert torch.allclose(st.p(n).double(), want, rtol=2e-5, atol=1e-9), n
+
+
 @pytest.mark.parametrize('name', ['unshared', 'langonly_groups', 'block_mask', 'img_mask'])
 def test_config_variants_match_reference_program(emu, name):
     """the host wiring of `share_params: False` (own `langonly_encoder` weights, its own depth) and
@@ -341,8 +367,9 @@ def test_config_variants_match_reference_program(emu, name):
 
 def test_token_id_range_assertion_is_deferred_not_dropped(emu, oracle_run):
     """utils/model_utils.py:256-258 asserts 0 <= id < vocab inside the graph.  Here the flag is computed on the device (no
-    host round trip in the middle of the step), the lookup is clamped (memory-safe), and the error is raised by
-    `check_token_ids()` / by the trainer one step late -- and at once in inference mode."""
+    host round trip in the middle of the forward), the lookup is clamped (memory-safe), and the error is raised by
+    `check_token_ids()` / by the trainer after the backward is queued and before the optimizer update -- the bad batch never
+    reaches the weights or a checkpoint."""
     from merlot_amd import MerlotModel, ParamStore, model_fn_builder
     from merlot_amd.config import NeatConfig
     from merlot_amd.train import Trainer
@@ -359,13 +386,14 @@ def test_token_id_range_assertion_is_deferred_not_dropped(emu, oracle_run):
     assert bool(bad.token_id_flag())
     with pytest.raises(ValueError, match='out of range'):
         bad.check_token_ids()
-    # the trainer: the step that embedded the bad id completes, the next call raises and names it
+    # the trainer: the step that embedded the bad id raises, names itself and leaves the weights untouched
     config = NeatConfig.from_dict({'model': dict(cfg), 'data': {'num_chunks': 4, 'chunk_text_len': 32},
                                    'device': {'use_tpu': False, 'output_dir': '/tmp/unused'},
                                    'optimizer': {'type': 'adam_optimizer', 'learning_rate': 1e-4, 'num_train_steps': 10, 'num_warmup_steps': 0}})
     tr = Trainer(config, 'cpu', None, seed=0)
     feats = {'images': b['image'], 'input_ids': ids, 'shuffled_idx_img': torch.from_numpy(b['shuffled_idx_img']),
              'video_src_ids': torch.from_numpy(b['video_src_ids']), 'noise': {k: torch.from_numpy(v) for k, v in b['noise'].items()}}
-    tr.step(feats)
+    before = tr.store.master.clone()
     with pytest.raises(ValueError, match='training step 0'):
-        tr.check_inputs()
+        tr.step(feats)                                    # raised by the step itself, BEFORE its update is applied
+    assert torch.equal(tr.store.master, before) and tr.step_idx == 0
