@@ -50,6 +50,27 @@ def test_config5_geometry_384px_16_segments():
     assert abs(float(l1 + l2 + l3) - float(ref)) < 3e-2
 
 
+def test_config5_geometry_gradients_against_the_oracle():
+    """the BACKWARD at the config-#5 geometry (joint S = 2832, ViT S = 578) against the fp32 oracle's
+    autograd -- not against another HIP path.  1 example x 16 segments at 384^2, 2 + 2 layers."""
+    cfg = tiny_config(image_size=[384, 384], num_chunks_in_group=16, max_position_embeddings=1024)
+    b = synth_batch(cfg, E=1, num_chunks=16, seed=5)
+    w, m, st, pm = _both(cfg, b, grads=True)
+    loss, info = m.total_loss(b['shuffled_idx_img'], b['video_src_ids'])
+    loss.backward()
+    st.zero_grad()
+    l = pm.mask_loss()[0] + pm.contrastive_loss()[0] + pm.temporal_loss(
+        torch.from_numpy(b['shuffled_idx_img']).cuda(), torch.from_numpy(b['video_src_ids']).cuda())[0]
+    assert abs(float(l) - float(loss)) < 3e-2
+    l.backward()
+    torch.cuda.synchronize()
+    gt = st.export_tf_grads()
+    rels = {k: rel_l2(gt[k], v.grad) for k, v in w.items() if v.grad is not None and not k.endswith('key_layer/bias')}
+    bad = {k: r for k, r in rels.items() if r > (0.2 if k.startswith('contrastive/') else 0.12)}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
+    assert np.median(list(rels.values())) < 3e-2
+
+
 def test_ragged_batch_odd_sizes_forward_backward():
     """3 examples x 4 chunks (12 frames: 216 ViT tokens, 3 x 148 joint tokens -- no multiple of 32/64/128/256), one
     caption without padding, one that is START only."""

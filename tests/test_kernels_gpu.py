@@ -246,6 +246,14 @@ def test_attention_fwd_bwd_long_sequences_tiled_kernels(ops, B, S, heads, pad):
     test_attention_fwd_bwd(ops, B, S, heads, pad)
 
 
+@pytest.mark.parametrize("B,S,heads,pad", [(2, 410, 12, True), (2, 410, 12, False), (1, 2832, 2, True), (1, 2832, 3, False)])
+def test_attention_fwd_bwd_at_the_baseline_config_lengths(ops, B, S, heads, pad):
+    """the joint sequence of BASELINE config #4 (5 segments at 224^2: S = 5 * 82 = 410) and of
+    config #5 (16 segments at 384^2: S = 16 * 177 = 2832), forward AND backward of the bf16 kernels against the fp32
+    torch restatement (not against another HIP path)."""
+    test_attention_fwd_bwd(ops, B, S, heads, pad)
+
+
 def test_attention_padded_query_rows_uniform(ops):
     """utils/transformer.py:109-112: a fully masked query row attends uniformly over ALL keys (-1e10, not -inf)."""
     B, S, heads = 1, 70, 12
