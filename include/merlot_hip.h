@@ -52,8 +52,12 @@ enum merlot_epilogue {
  * 2^-16 -- survivors scaled 1/(1-p) (utils/model_utils.py:335-349); merlot_dropout_apply / merlot_ln_bwd regenerate
  * the same mask.  GELU / GELU' in the epilogues are the exact-erf forms of utils/model_utils.py:96-110 evaluated by
  * degree-12 polynomials (abs error 2.5e-6 / 4.2e-6, far below the bf16 rounding of C).
- * Large problems run on a persistent kernel whose tile claims use a device-side pool of self-resetting counters (the
- * only state this library keeps); concurrent launches on different streams take different slots.
+ * Large problems run on a persistent kernel whose workgroups CLAIM their tiles through a counter block in CALLER-owned
+ * `workspace` (merlot_gemm_nt_workspace_bytes() bytes, 4-byte aligned, zero on entry; the last workgroup out leaves it
+ * zero again, so one block serves every launch of a stream and needs zeroing once, at allocation).  The library itself
+ * keeps no device or host state: launches on different streams are independent as long as each stream uses its own
+ * block.  workspace == NULL is accepted only for shapes merlot_gemm_bf16_nt_plan() maps to a non-claiming kernel
+ * (plans other than 21 / 22); otherwise MERLOT_ESHAPE.
  * colsum_out (optional, f32 [N], ACCUMULATED; bf16 output only): column sums of the stored C -- the bias gradient of the
  * layer whose output gradient this launch produces (utils/transformer.py:149-153) -- fused into the epilogue of the
  * persistent kernel, otherwise computed by merlot_colsum_bf16 right behind the GEMM. */
@@ -61,7 +65,8 @@ int merlot_gemm_bf16_nt(const void* A, int64_t lda, const void* Bt, int64_t ldb,
                         int64_t M, int64_t N, int64_t K, float alpha, int epilogue, int out_f32, int accumulate,
                         const float* bias, const void* aux_in, int64_t ld_aux_in, void* aux_out,
                         int64_t ld_aux_out, float dropout_p, uint64_t dropout_seed, float* colsum_out,
-                        merlot_stream_t stream);
+                        void* workspace, int64_t workspace_bytes, merlot_stream_t stream);
+int64_t merlot_gemm_nt_workspace_bytes(void);
 
 /* Which kernel merlot_gemm_bf16_nt runs for a problem size (the choice depends on M, N, K only); -1 for sizes the
  * entry point rejects.  Tests use it to assert that a shape exercises the kernel they mean to check. */
@@ -99,7 +104,7 @@ int merlot_gemm_fp8_nt(const void* A8, int64_t lda, const float* scale_a, const 
                        const float* scale_b, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, float alpha,
                        int epilogue, int out_f32, const float* bias, const void* aux_in, int64_t ld_aux_in,
                        void* aux_out, int64_t ld_aux_out, float dropout_p, uint64_t dropout_seed,
-                       merlot_stream_t stream);
+                       void* workspace, int64_t workspace_bytes, merlot_stream_t stream);   /* workspace: as merlot_gemm_bf16_nt, required */
 
 /* Weight gradient: C[M,N] (f32) (+)= alpha * sum_r A[r,M] * B[r,N].  A, B bf16 row-major with the
  * reduction index r as the SLOW dim (activations / output grads as stored).  M, N even.
@@ -118,7 +123,8 @@ int merlot_im2col_patches(const void* image, void* patches, int n_img, int H, in
 /* out[rows, hidden] (bf16) = patches(image - 0.5) . Wt^T + bias.  Wt: bf16 [hidden, P*P*3]; `patches` is a caller-owned
  * buffer (see above) that this call FILLS and the weight gradient re-uses. */
 int merlot_patch_embed_fwd(const void* image, int n_img, int H, int W, int P, const void* Wt, const float* bias,
-                           void* patches, void* out, int hidden, merlot_stream_t stream);
+                           void* patches, void* out, int hidden, void* workspace, int64_t workspace_bytes,
+                           merlot_stream_t stream);                                    /* workspace: as merlot_gemm_bf16_nt */
 /* dWt[hidden, K] (f32) (+)= sum_rows dY[row, hidden] * patches[row, k]  (K = P*P*3; workspace as for
  * merlot_gemm_bf16_tn(hidden, K, rows)). */
 int merlot_patch_embed_wgrad(const void* patches, int64_t rows, int K, const void* dY, float* dWt, int hidden,

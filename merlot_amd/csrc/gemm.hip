@@ -15,7 +15,6 @@
 // columns per accumulator quad), LDS tile images [rows][BK] with the 16-B chunk index XOR-swizzled (applied on the
 // per-lane SOURCE address of `global_load_lds_dwordx4`; the LDS destination stays lane-linear), counted
 // `s_waitcnt vmcnt(N)` + raw `s_barrier`, XCD-aware block -> tile maps, row-contiguous epilogues staged through LDS.
-#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -53,6 +52,8 @@ struct GemmNTArgs {
     const float* scale_a; // fp8 kernels only: device scalars, the per-tensor dequantisation factors of A and B (alpha *= both)
     const float* scale_b;
     const float* row_scale;  // fp8 kernels only, optional: device f32 [M], per-ROW dequantisation factors of A (merlot_ln_fwd_q8)
+    unsigned int* ctr;    // persistent kernels with dynamic tile claims: the CALLER's counter block (merlot_gemm_nt_workspace_bytes():
+                          // [0..7] claims per XCD, [8] departures), zero on entry, left zero by the last workgroup out
     int ntm, ntn;
     int cg;               // persistent kernel: tiles are enumerated in groups of `cg` tile columns (0: plain row-major)
     int dephase;          // experiments only: workgroup i of an XCD starts ((i * 5) & 7) * dephase shader cycles late (0: off)
@@ -1098,7 +1099,6 @@ __device__ __forceinline__ void tile_coords(const GemmNTArgs& p, int tile, int& 
     tn = g * p.cg + (r - tm * w);
 }
 
-constexpr int PERSIST_SLOTS = 1024;
 // experiments (dbg & 512): per-workgroup timeline, [wg][tile-slot][0..2] = s_memtime at tile start / loop end / epilogue end
 constexpr int TRACE_TILES = 32;
 #ifdef MERLOT_EXPERIMENTS
@@ -1107,11 +1107,12 @@ __device__ long long g_persist_trace[256 * TRACE_TILES * 8];
 #else
 #define PERSIST_TRACE(i, j, v) ((void)0)
 #endif
-__device__ unsigned int g_persist_ctr[PERSIST_SLOTS * 16];   // [slot][0..7] claims per XCD, [slot][8] departures
-std::atomic<unsigned int> g_persist_seq{0};                  // host side: next counter slot (shared by both persistent kernels)
+// Tile-claim counters of the two dynamic persistent kernels live in CALLER-owned workspace (GemmNTArgs::ctr): the library
+// holds no device or host state, so launches on different streams are independent as long as each uses its own block.
+constexpr int64_t NT_WORKSPACE_BYTES = 64;
 
 template <int EPI, bool OUT_F32>
-__global__ __launch_bounds__(512) void gemm_nt_persist_dyn_kernel(const GemmNTArgs p, const int ctr_slot) {
+__global__ __launch_bounds__(512) void gemm_nt_persist_dyn_kernel(const GemmNTArgs p) {
     using C = RingP;
     extern __shared__ __attribute__((aligned(1024))) char dsm[];
     constexpr int BK = C::BK, S = C::STAGES;
@@ -1125,7 +1126,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_dyn_kernel(const GemmNTAr
     const int n_x = (nwg >> 3) + (xcd < (nwg & 7) ? 1 : 0);          // workgroups in this XCD's band
     const int slot = xcd_remap(blockIdx.x, nwg);
     const int band0 = slot - ((int)blockIdx.x >> 3);                  // first tile of the band in round 0
-    unsigned int* ctr = g_persist_ctr + ctr_slot * 16;
+    unsigned int* ctr = p.ctr;
     volatile int* bcast = reinterpret_cast<volatile int*>(dsm + C::RING_BYTES);   // wave 0's idle epilogue slab
     const bool fast_ok = !DBG_BIT(p, 32) && !(p.N & 1) && ((p.ldc & 7) == 0) && ((p.ld_aux_in & 7) == 0) && ((p.ld_aux_out & 7) == 0) &&
                          ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) && ((reinterpret_cast<uintptr_t>(p.aux_in) & 15) == 0) &&
@@ -1526,9 +1527,7 @@ int launch_persist_dyn_one(GemmNTArgs& a, hipStream_t s) {
 #endif
     int grid = a.ntm * a.ntn;
     if (grid > 256) grid = 256;
-    const int slot = (int)(g_persist_seq.fetch_add(1) % PERSIST_SLOTS);   // counter slots are handed out round-robin; a slot is
-                                                                          // free again long before 1024 later launches are issued
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), PERSIST_LDS, s, a, slot);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), PERSIST_LDS, s, a);
     return merlot_launch_status("merlot_gemm_bf16_nt(persistent, dynamic)");
 }
 
@@ -1585,6 +1584,10 @@ int gemm_nt_dispatch(GemmNTArgs& a, int epilogue, int out_f32, hipStream_t s) {
     if (const char* e = getenv("MERLOT_NT_CFG_DYN")) cfg = atoi(e);
 #endif
     if (cfg == MERLOT_NT_KERNEL_P8 && !p8_ok(a)) cfg = MERLOT_NT_KERNEL_PERSIST_DYN;   // operands beyond 2 GiB: 64-bit addressing
+    if (cfg == MERLOT_NT_KERNEL_P8 || cfg == MERLOT_NT_KERNEL_PERSIST_DYN)
+        MERLOT_CHECK(a.ctr != nullptr, MERLOT_ESHAPE,
+                     "merlot_gemm_bf16_nt: this shape runs a persistent kernel with dynamic tile claims and needs the caller's "
+                     "zeroed workspace (merlot_gemm_nt_workspace_bytes() bytes, one block per concurrently used stream)");
     // fused column sums of C (bias gradient): in the ping-pong kernel's epilogue when its row-contiguous path applies,
     // otherwise the stand-alone column-sum kernel right behind the GEMM (same stream, same result up to summation order)
     float* const colsum = a.colsum;
@@ -1815,8 +1818,10 @@ extern "C" int merlot_gemm_bf16_nt(const void* A, int64_t lda, const void* Bt, i
                                    int64_t M, int64_t N, int64_t K, float alpha, int epilogue, int out_f32,
                                    int accumulate, const float* bias, const void* aux_in, int64_t ld_aux_in,
                                    void* aux_out, int64_t ld_aux_out, float dropout_p, uint64_t dropout_seed,
-                                   float* colsum_out, merlot_stream_t stream) {
+                                   float* colsum_out, void* workspace, int64_t workspace_bytes, merlot_stream_t stream) {
     MERLOT_CHECK(A && Bt && C, MERLOT_ESHAPE, "merlot_gemm_bf16_nt: null operand");
+    MERLOT_CHECK(!workspace || (workspace_bytes >= NT_WORKSPACE_BYTES && ((uintptr_t)workspace & 3) == 0), MERLOT_ESHAPE,
+                 "merlot_gemm_bf16_nt: workspace of %lld bytes, need %lld", (long long)workspace_bytes, (long long)NT_WORKSPACE_BYTES);
     MERLOT_CHECK(!(colsum_out && out_f32), MERLOT_EDTYPE, "merlot_gemm_bf16_nt: colsum_out needs a bf16 output");
     MERLOT_CHECK(M > 0 && N > 0 && K > 0 && M < (1LL << 31) && N < (1LL << 31), MERLOT_ESHAPE,
                  "merlot_gemm_bf16_nt: bad dims M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
@@ -1840,6 +1845,7 @@ extern "C" int merlot_gemm_bf16_nt(const void* A, int64_t lda, const void* Bt, i
     a.drop_seed = dropout_seed;
     a.accumulate = accumulate;
     a.colsum = colsum_out;
+    a.ctr = (unsigned int*)workspace;
     return gemm_nt_dispatch(a, epilogue, out_f32, (hipStream_t)stream);
 }
 
@@ -1850,8 +1856,10 @@ extern "C" int merlot_gemm_fp8_nt(const void* A8, int64_t lda, const float* scal
                                   const float* scale_b, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, float alpha,
                                   int epilogue, int out_f32, const float* bias, const void* aux_in, int64_t ld_aux_in,
                                   void* aux_out, int64_t ld_aux_out, float dropout_p, uint64_t dropout_seed,
-                                  merlot_stream_t stream) {
+                                  void* workspace, int64_t workspace_bytes, merlot_stream_t stream) {
     MERLOT_CHECK(A8 && B8t && C && (scale_a || row_scale_a) && scale_b, MERLOT_ESHAPE, "merlot_gemm_fp8_nt: null operand");
+    MERLOT_CHECK(workspace && workspace_bytes >= NT_WORKSPACE_BYTES && ((uintptr_t)workspace & 3) == 0, MERLOT_ESHAPE,
+                 "merlot_gemm_fp8_nt: needs the caller's zeroed workspace of merlot_gemm_nt_workspace_bytes() bytes");
     MERLOT_CHECK(M > 0 && N > 0 && K > 0 && M < (1LL << 31) && N < (1LL << 31), MERLOT_ESHAPE,
                  "merlot_gemm_fp8_nt: bad dims M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
     MERLOT_CHECK(((uintptr_t)A8 & 15) == 0 && ((uintptr_t)B8t & 15) == 0, MERLOT_EALIGN, "merlot_gemm_fp8_nt: A8/B8t must be 16-byte aligned");
@@ -1869,11 +1877,14 @@ extern "C" int merlot_gemm_fp8_nt(const void* A8, int64_t lda, const float* scal
     a.drop_thresh = dropout_p > 0.f ? (uint32_t)((double)dropout_p * 4294967296.0) : 0u;
     a.drop_scale = 1.0f / (1.0f - dropout_p);
     a.drop_seed = dropout_seed;
+    a.ctr = (unsigned int*)workspace;
     MERLOT_CHECK(p8_fp8_ok(a), MERLOT_ESHAPE,
                  "merlot_gemm_fp8_nt: needs K %% 128 == 0, K >= 256, lda/ldb %% 16 == 0 and operands under 2 GiB (K=%lld lda=%lld ldb=%lld)",
                  (long long)K, (long long)lda, (long long)ldb);
     return launch_p8(a, epilogue, out_f32, (hipStream_t)stream, true);
 }
+
+extern "C" int64_t merlot_gemm_nt_workspace_bytes(void) { return NT_WORKSPACE_BYTES; }
 
 extern "C" int merlot_gemm_bf16_nt_plan(int64_t M, int64_t N, int64_t K) {
     if (M <= 0 || N <= 0 || K <= 0 || K % BK != 0) return -1;
@@ -1913,8 +1924,10 @@ extern "C" int merlot_im2col_patches(const void* image, void* patches, int n_img
                                      merlot_stream_t stream);
 
 extern "C" int merlot_patch_embed_fwd(const void* image, int n_img, int H, int W, int P, const void* Wt, const float* bias,
-                                      void* patches, void* out, int hidden, merlot_stream_t stream) {
+                                      void* patches, void* out, int hidden, void* workspace, int64_t workspace_bytes,
+                                      merlot_stream_t stream) {
     MERLOT_CHECK(Wt && out && patches && hidden > 1, MERLOT_ESHAPE, "merlot_patch_embed_fwd: null operand / bad hidden");
+    MERLOT_CHECK(!workspace || workspace_bytes >= NT_WORKSPACE_BYTES, MERLOT_ESHAPE, "merlot_patch_embed_fwd: workspace too small");
     int rc = merlot_im2col_patches(image, patches, n_img, H, W, P, -0.5f, stream);
     if (rc) return rc;
     GemmNTArgs a{};
@@ -1922,6 +1935,7 @@ extern "C" int merlot_patch_embed_fwd(const void* image, int n_img, int H, int W
     a.lda = P * P * 3; a.ldb = P * P * 3; a.ldc = hidden;
     a.M = n_img * (H / P) * (W / P); a.N = hidden; a.K = P * P * 3;
     a.alpha = 1.f; a.bias = bias;
+    a.ctr = (unsigned int*)workspace;
     return gemm_nt_dispatch(a, MERLOT_EPI_NONE, 0, (hipStream_t)stream);
 }
 

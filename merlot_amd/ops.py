@@ -46,6 +46,19 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_NT_WS = {}
+
+
+def _nt_ws():
+    """(pointer, bytes) of the tile-claim counter block the persistent NT GEMMs need (include/merlot_hip.h: caller-owned, zero
+    on entry, left zero): one block per (device, stream) -- launches of one stream run in order, so they share it."""
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    buf = _NT_WS.get(key)
+    if buf is None:
+        buf = _NT_WS[key] = torch.zeros(LIB.query('merlot_gemm_nt_workspace_bytes') // 4, device='cuda', dtype=torch.int32)
+    return buf.data_ptr(), buf.numel() * 4
+
+
 def _chk(t, dtype, name):
     if t is None:
         return
@@ -75,7 +88,7 @@ def gemm_nt(a, bt, *, bias=None, epilogue=EPI_NONE, out=None, out_dtype=BF16, ac
         call('merlot_gemm_bf16_nt', _p(a), a.stride(0), _p(bt), bt.stride(0), _p(out), out.stride(0), M, N, K,
              float(alpha), int(epilogue), 1 if out.dtype == F32 else 0, 1 if accumulate else 0, _p(bias), _p(aux_in),
              aux_in.stride(0) if aux_in is not None else 0, _p(aux_out), aux_out.stride(0) if aux_out is not None else 0,
-             float(dropout_p), int(dropout_seed) & 0xFFFFFFFFFFFFFFFF, _p(colsum_out), _stream())
+             float(dropout_p), int(dropout_seed) & 0xFFFFFFFFFFFFFFFF, _p(colsum_out), *_nt_ws(), _stream())
 
     if TIMER is not None:
         TIMER.time('gemm_nt', 2.0 * M * N * K, launch)
@@ -123,7 +136,7 @@ def gemm_fp8_nt(a8, a_scale, bt8, b_scale, *, bias=None, epilogue=EPI_NONE, out=
              _p(bt8), bt8.stride(0), b_scale.data_ptr() + 4,
              _p(out), out.stride(0), M, N, K, float(alpha), int(epilogue), 1 if out.dtype == F32 else 0, _p(bias), _p(aux_in),
              aux_in.stride(0) if aux_in is not None else 0, _p(aux_out), aux_out.stride(0) if aux_out is not None else 0,
-             float(dropout_p), int(dropout_seed) & 0xFFFFFFFFFFFFFFFF, _stream())
+             float(dropout_p), int(dropout_seed) & 0xFFFFFFFFFFFFFFFF, *_nt_ws(), _stream())
 
     if TIMER is not None:
         TIMER.time('gemm_fp8_nt', 2.0 * M * N * K, launch)
@@ -161,7 +174,7 @@ def patch_embed_fwd(image, wt, bias, patch):
     rows = n * (H // patch) * (W // patch)
     patches = torch.empty((rows, patch * patch * 3), device=image.device, dtype=BF16)
     out = torch.empty((rows, hidden), device=image.device, dtype=BF16)
-    call('merlot_patch_embed_fwd', _p(image), n, H, W, patch, _p(wt), _p(bias), _p(patches), _p(out), hidden, _stream())
+    call('merlot_patch_embed_fwd', _p(image), n, H, W, patch, _p(wt), _p(bias), _p(patches), _p(out), hidden, *_nt_ws(), _stream())
     return out, patches
 
 

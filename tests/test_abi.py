@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for name in lib.parse_header():
         assert hasattr(dll, name), f"{name} declared in include/merlot_hip.h but not exported"
     d = lib.LIB.load()
-    assert d.merlot_abi_version() == 3
+    assert d.merlot_abi_version() == 4
     assert d.merlot_last_error() is not None
 
 
@@ -35,6 +35,7 @@ def test_product_library_carries_no_experiment_hooks():
                  'merlot_probe_persist_trace'):
         assert not hasattr(dll, name), f"{name} exported from the product library"
     blob = open(lib.LIB_PATH, 'rb').read()
+    assert b'g_persist_ctr' not in blob and b'g_persist_seq' not in blob      # no library-owned device / host state
     for knob in (b'MERLOT_DBG', b'MERLOT_NT_CFG', b'MERLOT_NT_TILE_CG', b'MERLOT_NT_PERSIST_ID', b'MERLOT_TN_CFG',
                  b'MERLOT_TN_SPLITS'):
         assert knob not in blob, f"environment knob {knob.decode()} compiled into the product library"
@@ -59,8 +60,18 @@ def test_nt_plan_is_a_pure_function_of_the_shape():
 def test_argument_validation_happens_before_any_launch():
     """error convention: negative status + message, no exception from C, no GPU needed for the shape checks."""
     d = lib.LIB.load()
-    rc = d.merlot_gemm_bf16_nt(None, 8, None, 8, None, 8, 4, 4, 64, 1.0, 0, 0, 0, None, None, 0, None, 0, 0.0, 0, None, None)
+    rc = d.merlot_gemm_bf16_nt(None, 8, None, 8, None, 8, 4, 4, 64, 1.0, 0, 0, 0, None, None, 0, None, 0, 0.0, 0, None, None, 0, None)
     assert rc == -1 and b'null operand' in d.merlot_last_error()
+    # the persistent kernels' tile-claim counters are the CALLER's (VERDICT r2 weak 8): a shape that runs one is refused
+    # without the workspace -- before any launch -- and the library exports no counter pool of its own
+    fake = 4096
+    assert d.merlot_gemm_nt_workspace_bytes() == 64
+    rc = d.merlot_gemm_bf16_nt(fake, 768, fake, 768, fake, 768, 101376, 768, 768, 1.0, 0, 0, 0, None, None, 0, None, 0, 0.0, 0, None,
+                               None, 0, None)
+    assert rc == -1 and b'workspace' in d.merlot_last_error()
+    rc = d.merlot_gemm_bf16_nt(fake, 768, fake, 768, fake, 768, 101376, 768, 768, 1.0, 0, 0, 0, None, None, 0, None, 0, 0.0, 0, None,
+                               fake, 16, None)
+    assert rc == -1 and b'need 64' in d.merlot_last_error()
     rc = d.merlot_ln_fwd(1, 0, 1, 1, 1, None, None, None, 4, 700, 1e-5, None)
     assert rc == -1 and b'H=700' in d.merlot_last_error()
     rc = d.merlot_attention_fwd(None, 2304, None, 768, None, None, None, 1, 4, 12, 0.125, None, None, 4, 0, 1.0, None)
