@@ -148,8 +148,16 @@ def test_five_segment_sort_story_inference_at_224px_joint_410():
         logits = pm.allpairs_temporal_logits(h_lang, h_viz, 'lang_viz_temporal')
         probs = torch.softmax(logits, -1)[:, 1:].reshape(bs, dup, n, n, 3).mean(1).cpu()
     assert float((probs - ref['lang_viz_probs']).abs().max()) < 2e-2
+    # at random initialisation the 120 orders score within bf16 noise of each other, so the arg-max itself may flip between
+    # the fp32 oracle and the bf16 path; what must hold is that the oracle's best order is (all but) the best here too:
+    # its log-score under the HIP probabilities is within the probabilities' own tolerance of the HIP maximum
     for s in range(bs):
-        assert ix.best_permutation(probs[s].numpy())[0] == ix.best_permutation(ref['lang_viz_probs'][s].numpy())[0]
+        best_hip, score_hip = ix.best_permutation(probs[s].numpy())
+        best_ref, _ = ix.best_permutation(ref['lang_viz_probs'][s].numpy())
+        m, gsc = ix.score_permutation(probs[s].numpy(), np.arange(n), best_ref)
+        # each of the n*n = 25 log-terms of either score moves by at most maxdiff / p_min
+        maxdiff = float((probs - ref['lang_viz_probs']).abs().max())
+        assert score_hip - (np.log(m).sum() + np.log(gsc).sum()) <= 2 * n * n * maxdiff / float(min(probs.min(), ref['lang_viz_probs'].min()))
 
 
 def test_dropout_training_step_is_finite_and_seeded():
