@@ -1761,25 +1761,30 @@ int tn_p8_launch(GemmTNArgs& a, int accumulate, float* ws, int64_t ws_bytes, hip
         MERLOT_CHECK(ws != nullptr && ws_bytes >= need, MERLOT_ESHAPE,
                      "merlot_gemm_bf16_tn: workspace too small (%lld < %lld bytes)", (long long)ws_bytes, (long long)need);
     }
-    // two phases per K-tile (round 3, profiles/r03_a_ph2.txt: 20-25 % faster than four on every weight-gradient shape of the
-    // step -- the 24-instruction transposing read segment of the four-phase schedule never fitted under 8 MFMAs); the four-phase
-    // body remains in the experiments build (MERLOT_TN_PH2=0)
+    // ONE phase per K-tile (gemm_tn_p1_kernel, round 3).  profiles/r03_a_ph2.txt: four -> two phases +20-25 % on every
+    // weight-gradient shape of the step, two -> one another +3-5 % (1 230 TFLOP/s = 0.49 of peak on dW1 / dW2); the two- and
+    // four-phase bodies of gemm_tn_p8_kernel remain in the experiments build (MERLOT_TN_PH2 = 1 / 0).
+    int ph = 1;
+    static bool attr1 = false;
+    if (!attr1) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_p1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+        MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        attr1 = true;
+    }
+#ifdef MERLOT_EXPERIMENTS
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_p8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
         MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-#ifdef MERLOT_EXPERIMENTS
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_p8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
         MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-#endif
         attr_set = true;
     }
-    bool ph2 = true;
-#ifdef MERLOT_EXPERIMENTS
-    if (const char* e = getenv("MERLOT_TN_PH2")) ph2 = atoi(e) != 0;
-    if (!ph2) hipLaunchKernelGGL(gemm_tn_p8_kernel<false>, dim3(pl.ntm * pl.ntn * pl.splits), dim3(512), P8_LDS, s, a, ws);
+    if (const char* e = getenv("MERLOT_TN_PH2")) ph = atoi(e) == 0 ? 4 : atoi(e) == 1 ? 2 : 1;
+    if (ph == 4) hipLaunchKernelGGL(gemm_tn_p8_kernel<false>, dim3(pl.ntm * pl.ntn * pl.splits), dim3(512), P8_LDS, s, a, ws);
+    if (ph == 2) hipLaunchKernelGGL(gemm_tn_p8_kernel<true>, dim3(pl.ntm * pl.ntn * pl.splits), dim3(512), P8_LDS, s, a, ws);
 #endif
-    if (ph2) hipLaunchKernelGGL(gemm_tn_p8_kernel<true>, dim3(pl.ntm * pl.ntn * pl.splits), dim3(512), P8_LDS, s, a, ws);
+    if (ph == 1) hipLaunchKernelGGL(gemm_tn_p1_kernel, dim3(pl.ntm * pl.ntn * pl.splits), dim3(512), P8_LDS, s, a, ws);
     if (pl.splits > 1) {
         int64_t total = (int64_t)a.M * (a.N / 4);
         int grid = (int)((total + 255) / 256);

@@ -12,8 +12,9 @@ dev = 'cuda'
 T = int(os.environ.get('T', 101376))
 torch.manual_seed(0)
 os.environ['MERLOT_NT_CFG_DYN'] = '22'
-for name, N, K, epi in [('qkv', 2304, 768, 'none'), ('proj', 768, 768, 'residual'), ('fc1', 3072, 768, 'gelu'), ('fc2', 768, 3072, 'residual'),
-                        ('dgrad_fc1', 768, 3072, 'none'), ('dgrad_fc2', 3072, 768, 'dgelu'), ('dgrad_qkv', 768, 2304, 'none')]:
+NT_SHAPES = [] if os.environ.get('SKIP_NT') else [('qkv', 2304, 768, 'none'), ('proj', 768, 768, 'residual'), ('fc1', 3072, 768, 'gelu'), ('fc2', 768, 3072, 'residual'),
+                        ('dgrad_fc1', 768, 3072, 'none'), ('dgrad_fc2', 3072, 768, 'dgelu'), ('dgrad_qkv', 768, 2304, 'none')]
+for name, N, K, epi in NT_SHAPES:
     a = torch.randn(T, K, device=dev).bfloat16()
     b = (torch.randn(N, K, device=dev) * 0.02).bfloat16()
     bias = torch.randn(N, device=dev) * 0.1
@@ -47,12 +48,12 @@ for (M, N, name) in [(768, 768, 'dWproj'), (3072, 768, 'dW1'), (768, 3072, 'dW2'
     out = torch.zeros((M, N), device=dev)
     bench(lambda: fn(out), 20)
     row, ref = [], None
-    for ph in ('0', '1', '1', '0'):
+    for ph in os.environ.get('TN_MODES', '0,1,3,3,1,0').split(','):
         os.environ['MERLOT_TN_PH2'] = ph
         o = torch.zeros((M, N), device=dev)
         fn(o)
         ref = o.clone() if ref is None else ref
         same = torch.equal(o, ref)
         t = bench(lambda: fn(out), 20)
-        row.append(f'ph{4 if ph == "0" else 2}: {t:7.1f} us {2.0 * T * M * N / t / 1e6:5.0f} TF{"" if same else " MISMATCH"}')
+        row.append(f'ph{ {"0": 4, "1": 2, "3": 1}[ph] }: {t:7.1f} us {2.0 * T * M * N / t / 1e6:5.0f} TF{"" if same else " MISMATCH"}')
     print(f'T={T} {name:6s} [{M} x {N}]  ' + ' | '.join(row), flush=True)
