@@ -17,6 +17,8 @@
 // rows the kernels use the score 0 for every key instead of -1e10: the softmax is the same uniform 1/S, but the
 // saved log-sum-exp is log(S) -- representable -- whereas -1e10 + log(S) rounds to -1e10 in fp32 and would make
 // the recomputed probabilities of the backward / column-sum kernels 1 instead of 1/S.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -876,6 +878,9 @@ __global__ __launch_bounds__(64) void attn_colsum_kernel(const AttnArgs p) {
 }
 
 #include "attention_res.inc"
+#ifdef MERLOT_EXPERIMENTS
+#include "attention_ps.inc"
+#endif
 
 int check_attn(const void* qkv, int64_t ld, int B, int S, int heads) {
     MERLOT_CHECK(qkv != nullptr, MERLOT_ESHAPE, "attention: null qkv");
@@ -907,6 +912,16 @@ extern "C" int merlot_attention_fwd(const void* qkv, int64_t ld, void* out, int6
         rc = res_fwd(a, (hipStream_t)stream);            // come from the same launch
         return rc ? rc : merlot_launch_status("merlot_attention_fwd");
     }
+#ifdef MERLOT_EXPERIMENTS
+    // the persistent streaming forward (attention_ps.inc, experiments build only): measured level with the one-shot kernel at
+    // every shape of the step (profiles/r03_c_attention_ps.txt) -- the forward is bound by its per-tile VALU work, not by data movement
+    if (const char* e = getenv("MERLOT_ATTN_PS")) {
+        if (atoi(e) != 0 && !want_cs && ps_ok(a)) {
+            rc = ps_fwd(a, (hipStream_t)stream, atoi(e) == 2 ? 2 : 3);
+            return rc ? rc : merlot_launch_status("merlot_attention_fwd");
+        }
+    }
+#endif
     if (valid)
         hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, (hipStream_t)stream, a);
     else
