@@ -49,6 +49,7 @@ struct AttnArgs {
     int qsplit;
     int valid_q_only;
     float weight;
+    int dbg;             // experiments build only (MERLOT_ATTN_DBG): 1 = the streaming kernels move the data but skip the tile arithmetic
 };
 
 __device__ __forceinline__ int h2_off(int R, int row, int chunk) {
@@ -915,9 +916,10 @@ extern "C" int merlot_attention_fwd(const void* qkv, int64_t ld, void* out, int6
 #ifdef MERLOT_EXPERIMENTS
     // the persistent streaming forward (attention_ps.inc, experiments build only): measured level with the one-shot kernel at
     // every shape of the step (profiles/r03_c_attention_ps.txt) -- the forward is bound by its per-tile VALU work, not by data movement
+    if (const char* e = getenv("MERLOT_ATTN_DBG")) a.dbg = atoi(e);
     if (const char* e = getenv("MERLOT_ATTN_PS")) {
         if (atoi(e) != 0 && !want_cs && ps_ok(a)) {
-            rc = ps_fwd(a, (hipStream_t)stream, atoi(e) == 2 ? 2 : 3);
+            rc = ps_fwd(a, (hipStream_t)stream, atoi(e));
             return rc ? rc : merlot_launch_status("merlot_attention_fwd");
         }
     }
@@ -965,11 +967,20 @@ extern "C" int merlot_attention_bwd(const void* qkv, int64_t ld, const void* out
     a.lse = (float*)lse; a.delta = delta; a.valid = valid; a.seg = seg; a.dqkv = (bf16*)dqkv; a.lddqkv = lddqkv;
     a.B = B; a.S = S; a.heads = heads; a.scale = scale;
     hipStream_t s = (hipStream_t)stream;
+    int ps_mode = 0;                                     // bit 0: persistent streaming dQ kernel, bit 1: dK / dV
+#ifdef MERLOT_EXPERIMENTS
+    if (const char* e = getenv("MERLOT_ATTN_DBG")) a.dbg = atoi(e);
+    if (const char* e = getenv("MERLOT_ATTN_PS_BWD")) ps_mode = ps_ok(a) ? atoi(e) : 0;
+    if (ps_mode & 1) {
+        rc = ps_bwd_dq(a, s);
+        if (rc) return rc;
+    }
+#endif
     if (valid) {
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);
+        if (!(ps_mode & 1)) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);
         hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);
     } else {
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);
+        if (!(ps_mode & 1)) hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);
         hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);
     }
     return merlot_launch_status("merlot_attention_bwd");
