@@ -879,9 +879,7 @@ __global__ __launch_bounds__(64) void attn_colsum_kernel(const AttnArgs p) {
 }
 
 #include "attention_res.inc"
-#ifdef MERLOT_EXPERIMENTS
 #include "attention_ps.inc"
-#endif
 
 int check_attn(const void* qkv, int64_t ld, int B, int S, int heads) {
     MERLOT_CHECK(qkv != nullptr, MERLOT_ESHAPE, "attention: null qkv");
@@ -967,15 +965,17 @@ extern "C" int merlot_attention_bwd(const void* qkv, int64_t ld, const void* out
     a.lse = (float*)lse; a.delta = delta; a.valid = valid; a.seg = seg; a.dqkv = (bf16*)dqkv; a.lddqkv = lddqkv;
     a.B = B; a.S = S; a.heads = heads; a.scale = scale;
     hipStream_t s = (hipStream_t)stream;
-    int ps_mode = 0;                                     // bit 0: persistent streaming dQ kernel, bit 1: dK / dV
+    // dQ (+ delta): the persistent streaming kernel (attention_ps.inc) wherever it applies -- bit-identical to the one-shot
+    // kernel and 14-16 % faster at the step's shapes (profiles/r03_c_attention_ps.txt); dK / dV: one-shot
+    int ps_mode = ps_ok(a) ? 1 : 0;
 #ifdef MERLOT_EXPERIMENTS
     if (const char* e = getenv("MERLOT_ATTN_DBG")) a.dbg = atoi(e);
     if (const char* e = getenv("MERLOT_ATTN_PS_BWD")) ps_mode = ps_ok(a) ? atoi(e) : 0;
+#endif
     if (ps_mode & 1) {
         rc = ps_bwd_dq(a, s);
         if (rc) return rc;
     }
-#endif
     if (valid) {
         if (!(ps_mode & 1)) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);
         hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);

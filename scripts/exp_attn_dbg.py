@@ -16,10 +16,10 @@ for B, S, masked in ((512 * SC, 198, False), (128 * SC, 328, True)):
     o, lse = ops.attention_fwd(qkv, B, S, 12, valid)
     do = torch.randn_like(o)
     row = []
-    for ps in ('1', '3'):
+    for ps in ('1', '2'):
         for dbg in ('0', '1'):
             os.environ['MERLOT_ATTN_PS'], os.environ['MERLOT_ATTN_DBG'] = ps, dbg
-            row.append(f'fwd {"H2 (64-B requests)" if ps == "1" else "L128 (128-B requests)"} {"data only" if dbg == "1" else "full"} {timeit(lambda: ops.attention_fwd(qkv, B, S, 12, valid)):7.1f}')
+            row.append(f'fwd {"128-row items" if ps == "1" else "256-row items"} {"data only" if dbg == "1" else "full"} {timeit(lambda: ops.attention_fwd(qkv, B, S, 12, valid)):7.1f}')
     os.environ['MERLOT_ATTN_PS'] = '0'
     for dbg in ('0', '1'):
         os.environ['MERLOT_ATTN_PS_BWD'], os.environ['MERLOT_ATTN_DBG'] = '1', dbg
