@@ -228,6 +228,20 @@ int merlot_softmax_ce(const float* logits, int64_t ld, const int32_t* labels, fl
                       const float* rowscale, void* dlogits, int dl_bf16, int64_t ld_dl, int64_t rows, int C,
                       merlot_stream_t stream);
 
+/* MLM head tail as ONE call (model/modeling.py:217-223 logits = h . E^T + output_bias, :539-545 cross-entropy; SURVEY 8(b)
+ * `merlot_vocab_ce`): logits GEMM (bf16 operands, fp32 accumulate, fp32 logits) + merlot_softmax_ce through the caller's `scratch`
+ * (fp32 logits, rows x ceil64(V) floats).  merlot_vocab_ce_scratch_bytes(T, V) = room for all T rows (one GEMM + one softmax launch,
+ * the fastest form: 3.7 ms at 12 800 x 50 370); with less scratch (>= 256 rows) the rows are processed in chunks -- cache-sized
+ * chunks were measured and are slower (profiles/r03_f_vocab_ce.txt), they exist for memory-constrained callers.
+ * h: bf16 [T, K]; table: bf16 [>= V rows, K] (the tied word-embedding table); out_bias f32 [V] or NULL; targets int32 [T];
+ * rowscale f32 [T] or NULL; outputs loss f32 [T], argmax int32 [T] (or NULL), dlogits bf16 [T, ld_dl] (= rowscale * (softmax -
+ * onehot), columns V..ld_dl zero-filled; or NULL).  nt_workspace: as merlot_gemm_bf16_nt. */
+int64_t merlot_vocab_ce_scratch_bytes(int64_t T, int64_t V);
+int merlot_vocab_ce_fwd(const void* h, int64_t ldh, const void* table, int64_t ldt, const float* out_bias, const int32_t* targets,
+                        const float* rowscale, float* loss, int32_t* argmax, void* dlogits, int64_t ld_dl, int64_t T, int64_t V,
+                        int64_t K, void* scratch, int64_t scratch_bytes, void* nt_workspace, int64_t nt_workspace_bytes,
+                        merlot_stream_t stream);
+
 /* x * rsqrt(max(sum x^2, 1e-12))  (tf.math.l2_normalize, model/modeling.py:43) ; f32 [rows, H] */
 int merlot_l2norm_fwd(const float* x, float* y, float* inv_norm, int64_t rows, int H, merlot_stream_t stream);
 int merlot_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, float* dx, int64_t rows, int H,

@@ -1903,6 +1903,42 @@ extern "C" int merlot_gemm_fp8_nt(const void* A8, int64_t lda, const float* scal
 
 extern "C" int64_t merlot_gemm_nt_workspace_bytes(void) { return NT_WORKSPACE_BYTES; }
 
+extern "C" int merlot_softmax_ce(const float* logits, int64_t ld, const int32_t* labels, float* loss, int32_t* argmax,
+                                 const float* rowscale, void* dlogits, int dl_bf16, int64_t ld_dl, int64_t rows, int C,
+                                 merlot_stream_t stream);
+
+// scripts/exp_vocab_ce.py (profiles/r03_f_vocab_ce.txt): row chunks sized for the 256 MiB Infinity Cache LOSE -- 12 800 x 50 370:
+// 3.72 ms in one chunk, 5.25 ms in 160 MiB chunks (831 rows = 3.2 rounds of tiles per GEMM launch, 16 launch pairs), 6.9 ms at 96 MiB.
+// The recommended scratch is therefore the whole logits matrix; smaller scratch still works (memory-constrained callers).
+extern "C" int64_t merlot_vocab_ce_scratch_bytes(int64_t T, int64_t V) {
+    if (T <= 0 || V <= 0) return 0;
+    return T * ((V + 63) / 64 * 64) * 4;
+}
+
+extern "C" int merlot_vocab_ce_fwd(const void* h, int64_t ldh, const void* table, int64_t ldt, const float* out_bias,
+                                   const int32_t* targets, const float* rowscale, float* loss, int32_t* argmax, void* dlogits,
+                                   int64_t ld_dl, int64_t T, int64_t V, int64_t K, void* scratch, int64_t scratch_bytes,
+                                   void* nt_workspace, int64_t nt_workspace_bytes, merlot_stream_t stream) {
+    MERLOT_CHECK(h && table && targets && loss && scratch, MERLOT_ESHAPE, "merlot_vocab_ce_fwd: null operand");
+    MERLOT_CHECK(T > 0 && V > 1 && K > 0 && K % BK == 0 && V < (1LL << 31), MERLOT_ESHAPE, "merlot_vocab_ce_fwd: bad dims");
+    const int64_t ldl = (V + 63) / 64 * 64;
+    MERLOT_CHECK(!dlogits || ld_dl >= V, MERLOT_ESHAPE, "merlot_vocab_ce_fwd: ld_dl < V");
+    const int64_t chunk = scratch_bytes / (ldl * 4);
+    MERLOT_CHECK(chunk >= (T < 256 ? T : 256), MERLOT_ESHAPE, "merlot_vocab_ce_fwd: scratch of %lld bytes holds %lld rows; need >= %lld",
+                 (long long)scratch_bytes, (long long)chunk, (long long)(T < 256 ? T : 256));
+    for (int64_t r0 = 0; r0 < T; r0 += chunk) {
+        const int64_t rows = T - r0 < chunk ? T - r0 : chunk;
+        int rc = merlot_gemm_bf16_nt((const bf16*)h + r0 * ldh, ldh, table, ldt, scratch, ldl, rows, V, K, 1.0f, MERLOT_EPI_NONE, 1, 0,
+                                     out_bias, nullptr, 0, nullptr, 0, 0.f, 0, nullptr, nt_workspace, nt_workspace_bytes, stream);
+        if (rc) return rc;
+        rc = merlot_softmax_ce((const float*)scratch, ldl, targets + r0, loss + r0, argmax ? argmax + r0 : nullptr,
+                               rowscale ? rowscale + r0 : nullptr, dlogits ? (bf16*)dlogits + r0 * ld_dl : nullptr, 1, ld_dl, rows,
+                               (int)V, stream);
+        if (rc) return rc;
+    }
+    return MERLOT_OK;
+}
+
 extern "C" int merlot_gemm_bf16_nt_plan(int64_t M, int64_t N, int64_t K) {
     if (M <= 0 || N <= 0 || K <= 0 || K % BK != 0) return -1;
     return nt_plan(M, N, K);

@@ -596,10 +596,8 @@ class VocabCEFn(torch.autograd.Function):
     def forward(ctx, h, emb, out_bias, gout_bias, targets, rowweight, vocab):
         hb = ops.cast_bf16(h.contiguous())
         vpad = emb.wbT.shape[1]
-        logits = torch.empty((h.shape[0], vpad), device=h.device, dtype=F32)
-        ops.gemm_nt(hb, emb.wb, bias=out_bias, out=logits, n=vocab)
-        loss, am, dl = ops.softmax_ce(logits, targets, vocab, rowscale=rowweight, dlogits_dtype=BF16, ld_dl=vpad)
-        del logits
+        # logits GEMM + softmax cross-entropy as ONE C-ABI call (merlot_vocab_ce_fwd) over a caller-owned fp32 scratch
+        loss, am, dl = ops.vocab_ce(hb, emb.wb, out_bias, targets, rowweight, vocab, vpad)
         ctx.hb, ctx.emb, ctx.dl, ctx.gout_bias, ctx.vocab = hb, emb, dl, gout_bias, vocab
         ctx.mark_non_differentiable(loss, am)
         return (loss * rowweight).sum(), loss, am

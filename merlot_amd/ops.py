@@ -372,17 +372,47 @@ def cls_avgpool_bwd(dout, n_img, h1, w1, cls_skip, pool):
     return dx
 
 
-def softmax_ce(logits, labels, C, *, rowscale=None, dlogits_dtype=None, ld_dl=None, want_argmax=True):
+def softmax_ce(logits, labels, C, *, rowscale=None, dlogits_dtype=None, ld_dl=None, want_argmax=True, out=None):
+    """out: optional (loss, argmax, dlogits) views to fill (row chunks of caller-owned tensors) instead of fresh tensors."""
     _chk(logits, F32, 'logits'); _chk(labels, torch.int32, 'labels'); _chk(rowscale, F32, 'rowscale')
     rows = logits.shape[0]
-    loss = torch.empty(rows, device=logits.device, dtype=F32)
-    am = torch.empty(rows, device=logits.device, dtype=torch.int32) if want_argmax else None
-    dl = None
-    if dlogits_dtype is not None:
-        ld_dl = ld_dl or logits.shape[1]
-        dl = torch.empty((rows, ld_dl), device=logits.device, dtype=dlogits_dtype)
+    if out is not None:
+        loss, am, dl = out
+        _chk(loss, F32, 'loss'); _chk(am, torch.int32, 'argmax'); _chk(dl, dlogits_dtype, 'dlogits')
+        ld_dl = dl.stride(0)
+        if loss.shape[0] != rows or dl.shape[0] != rows:
+            raise ValueError("softmax_ce: out views must have one row per logits row")
+    else:
+        loss = torch.empty(rows, device=logits.device, dtype=F32)
+        am = torch.empty(rows, device=logits.device, dtype=torch.int32) if want_argmax else None
+        dl = None
+        if dlogits_dtype is not None:
+            ld_dl = ld_dl or logits.shape[1]
+            dl = torch.empty((rows, ld_dl), device=logits.device, dtype=dlogits_dtype)
     call('merlot_softmax_ce', _p(logits), logits.stride(0), _p(labels), _p(loss), _p(am), _p(rowscale), _p(dl),
          1 if dlogits_dtype == BF16 else 0, ld_dl or 0, rows, C, _stream())
+    return loss, am, dl
+
+
+_VOCAB_SCRATCH = {}
+
+
+def vocab_ce(hb, table, out_bias, targets, rowscale, vocab, ld_dl):
+    """MLM head tail in one C-ABI call (merlot_vocab_ce_fwd): logits GEMM + softmax cross-entropy through a per-stream fp32 scratch
+    -> (loss f32 [T], argmax int32 [T], dlogits bf16 [T, ld_dl])."""
+    _chk(hb, BF16, 'h'); _chk(table, BF16, 'table'); _chk(out_bias, F32, 'out_bias'); _chk(targets, torch.int32, 'targets')
+    _chk(rowscale, F32, 'rowscale')
+    T, K = hb.shape
+    need = LIB.query('merlot_vocab_ce_scratch_bytes', T, vocab)
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    scratch = _VOCAB_SCRATCH.get(key)
+    if scratch is None or scratch.numel() * 4 < need:
+        scratch = _VOCAB_SCRATCH[key] = torch.empty(need // 4, device=hb.device, dtype=F32)
+    loss = torch.empty(T, device=hb.device, dtype=F32)
+    am = torch.empty(T, device=hb.device, dtype=torch.int32)
+    dl = torch.empty((T, ld_dl), device=hb.device, dtype=BF16)
+    call('merlot_vocab_ce_fwd', _p(hb), hb.stride(0), _p(table), table.stride(0), _p(out_bias), _p(targets), _p(rowscale), _p(loss),
+         _p(am), _p(dl), ld_dl, T, vocab, K, _p(scratch), scratch.numel() * 4, *_nt_ws(), _stream())
     return loss, am, dl
 
 

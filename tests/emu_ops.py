@@ -240,7 +240,11 @@ def cls_avgpool_bwd(dout, n_img, h1, w1, cls_skip, pool):
     return dx.to(BF16)
 
 
-def softmax_ce(logits, labels, C, *, rowscale=None, dlogits_dtype=None, ld_dl=None, want_argmax=True):
+def softmax_ce(logits, labels, C, *, rowscale=None, dlogits_dtype=None, ld_dl=None, want_argmax=True, out=None):
+    if out is not None:
+        l, a, d = softmax_ce(logits, labels, C, rowscale=rowscale, dlogits_dtype=dlogits_dtype, ld_dl=out[2].shape[1], want_argmax=True)
+        out[0].copy_(l); out[1].copy_(a); out[2].copy_(d)
+        return out
     lg = logits[:, :C].float()
     lse = torch.logsumexp(lg, -1)
     lab = labels.long()
@@ -256,6 +260,11 @@ def softmax_ce(logits, labels, C, *, rowscale=None, dlogits_dtype=None, ld_dl=No
         dl = torch.zeros((lg.shape[0], ld_dl), dtype=dlogits_dtype)
         dl[:, :C] = g.to(dlogits_dtype)
     return loss, am, dl
+
+
+def vocab_ce(hb, table, out_bias, targets, rowscale, vocab, ld_dl):
+    logits = gemm_nt(hb, table, bias=out_bias, out_dtype=torch.float32, n=vocab)
+    return softmax_ce(logits, targets, vocab, rowscale=rowscale, dlogits_dtype=torch.bfloat16, ld_dl=ld_dl)
 
 
 def l2norm_fwd(x):
@@ -489,7 +498,7 @@ def weight_std_bwd(dkhat_t, khat, rstd, gk2d):
 
 _NAMES = ['weight_std_fwd', 'weight_std_bwd', 'gemm_nt', 'gemm_tn', 'patch_embed_fwd', 'patch_embed_wgrad', 'ln_fwd', 'ln_bwd', 'attention_fwd',
           'attention_bwd', 'attention_colsum', 'cast_bf16', 'cast_transpose_bf16', 'colsum_bf16', 'gather_add4',
-          'scatter_add_rows', 'dropout_apply', 'cls_avgpool_fwd', 'cls_avgpool_bwd', 'softmax_ce', 'l2norm_fwd',
+          'scatter_add_rows', 'dropout_apply', 'cls_avgpool_fwd', 'cls_avgpool_bwd', 'softmax_ce', 'vocab_ce', 'l2norm_fwd',
           'l2norm_bwd', 'gelu_fwd', 'gelu_bwd', 'mask_inputs', 'temporal_labels', 'shuffled_idx', 'im2col3x3', 'col2im3x3',
           'groupnorm_fwd', 'groupnorm_bwd', 'avgpool2_fwd', 'avgpool2_bwd', 'cast_transpose_batched', 'image_frames', 'adamw_step']
 

@@ -16,6 +16,53 @@ def test_header_declares_the_survey_export_list():
         assert n in protos, n
 
 
+# SURVEY.md 8(b), "Minimum export list", name by name -> the entry points of include/merlot_hip.h that provide it.  The survey wrote
+# its list before any kernel existed; where this ABI factors the work differently the row says how (INTEGRATION.md section B has the
+# same table with the reference lines).
+SURVEY_8B = {
+    'merlot_patch_embed_fwd': ['merlot_patch_embed_fwd', 'merlot_im2col_patches'],
+    'merlot_patch_embed_bwd': ['merlot_patch_embed_wgrad'],                 # the image is not differentiated: weight gradient only
+    'merlot_gemm_bf16_nt': ['merlot_gemm_bf16_nt', 'merlot_gemm_nt_workspace_bytes', 'merlot_gemm_bf16_nt_plan'],
+    'merlot_gemm_bf16_tn': ['merlot_gemm_bf16_tn', 'merlot_gemm_bf16_tn_workspace_bytes'],
+    # dgrad dX = dY . W reads W through its transposed bf16 working copy (refreshed once per step with the cast): NT + the transposes
+    'merlot_gemm_bf16_nn': ['merlot_gemm_bf16_nt', 'merlot_cast_transpose_f32_bf16', 'merlot_cast_transpose_batched'],
+    # epilogue enum {none, bias, bias_gelu, bias_residual, bias_dropout_residual} = merlot_epilogue + bias / dropout_p arguments
+    'merlot_ln_residual_fwd': ['merlot_ln_fwd', 'merlot_gemm_bf16_nt'],     # the residual add lives in the producing GEMM's epilogue
+    'merlot_ln_residual_bwd': ['merlot_ln_bwd'],                            # dres / branch gradient / bias column sums fused
+    'merlot_qkv_attention_fwd': ['merlot_attention_fwd'],                   # colsum_out / blocksum_out = colsum_lo / colsum_hi
+    'merlot_qkv_attention_bwd': ['merlot_attention_bwd'],
+    'merlot_bias_gelu_fwd': ['merlot_gelu_fwd'],
+    'merlot_bias_gelu_bwd': ['merlot_gelu_bwd'],
+    'merlot_gather_rows_fwd': ['merlot_gather_add4'],
+    'merlot_gather_rows_bwd': ['merlot_scatter_add_rows'],
+    'merlot_vocab_ce_fwd': ['merlot_vocab_ce_fwd', 'merlot_vocab_ce_scratch_bytes'],
+    'merlot_vocab_ce_bwd': ['merlot_gemm_bf16_nt', 'merlot_gemm_bf16_tn', 'merlot_colsum_bf16'],   # dlogits come out of the forward
+    'merlot_contrastive_logits_ce_fwd': ['merlot_l2norm_fwd', 'merlot_gemm_bf16_nt', 'merlot_softmax_ce'],
+    'merlot_contrastive_logits_ce_bwd': ['merlot_gemm_bf16_nt', 'merlot_l2norm_bwd'],
+    'merlot_avgpool_posemb_ln_fwd': ['merlot_cls_avgpool_fwd', 'merlot_gather_add4', 'merlot_ln_fwd'],
+    'merlot_avgpool_posemb_ln_bwd': ['merlot_ln_bwd', 'merlot_cls_avgpool_bwd'],
+    'merlot_adamw_bf16state_step': ['merlot_adamw_step'],                   # state_bf16 = 1
+}
+
+
+def test_survey_8b_export_list_is_covered():
+    """every name of SURVEY 8(b)'s own minimum export list is provided by exported entry points."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    survey = open(os.path.join(root, 'SURVEY.md')).read()
+    line = [l for l in survey.splitlines() if l.startswith('`merlot_patch_embed_{fwd,bwd}`')][0]
+    names = []
+    for stem, alts in re.findall(r'`(merlot_[a-z0-9_]+?)(?:_\{([a-z,]+)\})?`', line):
+        names += [f'{stem}_{a}' for a in alts.split(',')] if alts else [stem]
+    assert len(names) >= 20
+    assert sorted(set(names)) == sorted(SURVEY_8B), sorted(set(names) ^ set(SURVEY_8B))
+    protos = lib.parse_header()
+    dll = ctypes.CDLL(lib.LIB_PATH)
+    for want, have in SURVEY_8B.items():
+        for h in have:
+            assert h in protos and hasattr(dll, h), (want, h)
+
+
 def test_library_exports_every_declared_symbol():
     assert os.path.exists(lib.LIB_PATH), "build the extension first: python -c 'import __graft_entry__ as g; g.build()'"
     dll = ctypes.CDLL(lib.LIB_PATH)

@@ -204,3 +204,23 @@ def test_operands_between_2_and_4_gib_stay_on_the_ping_pong_kernels():
     for r0 in range(0, M, 50000):
         want += a[r0:r0 + 50000].double().t() @ bb[r0:r0 + 50000].double()
     assert rel_l2(dw, want.float()) < 2e-3
+
+
+def test_two_k_tiles_per_tile_many_tiles_per_workgroup(ops):
+    """K = 128 (two K-tiles per tile) with a dozen tiles per workgroup: the shape of the ResNet-stem 1x1 convolutions.  On the
+    two-phase schedule the LDS-DMA stream wraps into the next tile in that tile's FIRST read segment, right behind the publication
+    of the claimed tile index: without a barrier in between a wave could read a stale word (memory fault / wrong tiles, one run in
+    two -- profiles/r03_e_ph2_claim_race.txt).  Repeated, against an fp32 matmul on sampled rows."""
+    from merlot_amd.lib import LIB
+    M, N, K = 802816, 256, 128
+    assert LIB.query('merlot_gemm_bf16_nt_plan', M, N, K) == 22
+    a, bt = dev_rand((M, K), 41), dev_rand((N, K), 42, 0.05)
+    rows = torch.cat([torch.arange(0, 512), torch.arange(M // 2 - 256, M // 2 + 256), torch.arange(M - 512, M)]).cuda()
+    ref = a[rows].float() @ bt.float().t()
+    first = None
+    for _ in range(12):
+        out = ops.gemm_nt(a, bt)
+        torch.cuda.synchronize()
+        assert rel_l2(out[rows].float(), ref) < 6e-3
+        first = out if first is None else first
+        assert torch.equal(out, first)
