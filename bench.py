@@ -170,31 +170,31 @@ def gemm_source_hash():
 
 def measured_traffic():
     """HBM-side bytes per launch of the representative dominant launch (M=101376 N=3072 K=768, bias epilogue), from the
-    TCC counters collected in separate rocprofv3 --pmc passes over THIS kernel (profiles/r02_traffic.txt, written by
+    TCC counters collected in separate rocprofv3 --pmc passes over THIS kernel (profiles/r03_traffic.txt, written by
     scripts/gpu_traffic.sh): 2 * FETCH_SIZE (gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE, in bytes.  The
     file records the hash of the GEMM sources it was measured on; if the sources changed since, the figure is STALE and
     is not reported (traffic: null, with the reason)."""
-    path = os.path.join(ROOT, 'profiles', 'r02_traffic.txt')
+    path = os.path.join(ROOT, 'profiles', 'r03_traffic.txt')
     if not os.path.exists(path):
-        return {'bytes_per_launch': None, 'why': 'profiles/r02_traffic.txt absent'}
+        return {'bytes_per_launch': None, 'why': 'profiles/r03_traffic.txt absent'}
     fetch = write = src = None
     for line in open(path):
         if line.startswith('gemm_source_hash'):
             src = line.split()[-1]
-        if 'gemm_nt_p8_kernel<0, false, false>' in line and line.split(' | ')[0] in ('FETCH_SIZE', 'WRITE_SIZE'):
+        if 'gemm_nt_p8_kernel<0, false, false, true>' in line and line.split(' | ')[0] in ('FETCH_SIZE', 'WRITE_SIZE'):
             kb = float(line.split()[-1])                      # '<counter> | <kernel> | launches n | KB_per_launch v'
             if line.startswith('FETCH_SIZE'):
                 fetch = kb
             else:
                 write = kb
     if fetch is None or write is None:
-        return {'bytes_per_launch': None, 'why': 'profiles/r02_traffic.txt holds no gemm_nt_p8_kernel<0, false, false> rows'}
+        return {'bytes_per_launch': None, 'why': 'profiles/r03_traffic.txt holds no gemm_nt_p8_kernel<0, false, false, true> rows'}
     if src != gemm_source_hash():
-        return {'bytes_per_launch': None, 'why': f'profiles/r02_traffic.txt was measured on GEMM sources {src}, the tree has '
+        return {'bytes_per_launch': None, 'why': f'profiles/r03_traffic.txt was measured on GEMM sources {src}, the tree has '
                                                  f'{gemm_source_hash()}: stale, re-run scripts/gpu_traffic.sh'}
     return {'bytes_per_launch': (2.0 * fetch + write) * 1024.0, 'algorithmic_bytes_per_launch': 3119.0e6,
-            'launch': 'forward Linear M=405504 (= 128 examples x 16 frames x 198 tokens) N=3072 K=768, bias epilogue, bf16 out (gemm_nt_p8_kernel<0,false,false>)',
-            'source': 'profiles/r02_traffic.txt', 'gemm_source_hash': src}
+            'launch': 'forward Linear M=405504 (= 128 examples x 16 frames x 198 tokens) N=3072 K=768, bias epilogue, bf16 out (gemm_nt_p8_kernel<0,false,false,true>)',
+            'source': 'profiles/r03_traffic.txt', 'gemm_source_hash': src}
 
 
 def main():
@@ -356,7 +356,7 @@ def main():
             f, t, n = summ.get('gemm_nt', (0.0, 1.0, 0))
             traffic = measured_traffic()                     # PMC bytes of the representative launch, or None
             res['roofline'] = {'bound': 'mfma',
-                               'kernel': 'merlot_gemm_bf16_nt = gemm_nt_p8_kernel<EPI,OUT> (persistent ping-pong 256x256) + gemm_nt_ring_kernel<Cfg<2,4,2,2,32,3>,EPI,OUT> '
+                               'kernel': 'merlot_gemm_bf16_nt = gemm_nt_p8_kernel<EPI,OUT,FP8,PH2> (persistent ping-pong 256x256, two phases per K-tile) + gemm_nt_ring_kernel<Cfg<2,4,2,2,32,3>,EPI,OUT> '
                                          '(bf16 MFMA 32x32x16, all epilogues; the dominant kernel family of the step)',
                                'achieved': f / t / 1e12, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                                'frac': f / t / 1e12 / PEAK_BF16_TFLOPS, 'traffic': (traffic or {}).get('bytes_per_launch'),
@@ -372,7 +372,7 @@ def main():
                                        'share_of_step_time': t8 / timed_steps / (elapsed / args.steps)}
             if 'gemm_tn' in summ:
                 f2, t2, n2 = summ['gemm_tn']
-                res['roofline_wgrad'] = {'kernel': 'merlot_gemm_bf16_tn = gemm_tn_p8_kernel (+ gemm_tn_ring_kernel for small shapes) + tn_reduce_kernel', 'achieved': f2 / t2 / 1e12, 'unit': 'TFLOP/s',
+                res['roofline_wgrad'] = {'kernel': 'merlot_gemm_bf16_tn = gemm_tn_p1_kernel (one phase per K-tile; + gemm_tn_ring_kernel for small shapes) + tn_reduce_kernel', 'achieved': f2 / t2 / 1e12, 'unit': 'TFLOP/s',
                                          'frac': f2 / t2 / 1e12 / PEAK_BF16_TFLOPS, 'launches': n2,
                                          'share_of_step_time': t2 / timed_steps / (elapsed / args.steps)}
         if world == 1 and not args.no_cpu_baseline and not args.resnet_stem and not args.cpu_emulate and args.config == 2:

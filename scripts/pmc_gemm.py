@@ -14,7 +14,7 @@ T = 405504                                    # ViT rows of one bench step (128 
 a, w = rnd(T, 768), rnd(3072, 768)
 bias = torch.zeros(3072, device='cuda')
 for _ in range(3):
-    ops.gemm_nt(a, w, bias=bias)              # gemm_nt_p8_kernel<0, false, false>: the launch bench.py's roofline.traffic quotes
+    ops.gemm_nt(a, w, bias=bias)              # gemm_nt_p8_kernel<0, false, false, true>: the launch bench.py's roofline.traffic quotes
 u = torch.empty(T, 3072, device='cuda', dtype=BF16)
 for _ in range(3):
     ops.gemm_nt(a, w, bias=bias, epilogue=ops.EPI_GELU, aux_out=u)          # <1, false, false>: fc1
@@ -25,7 +25,7 @@ for _ in range(3):
 dy, x = rnd(T, 3072), rnd(T, 768)
 gw = torch.zeros((3072, 768), device='cuda')
 for _ in range(3):
-    ops.gemm_tn(dy, x, gw)                                                  # gemm_tn_p8_kernel + tn_reduce_kernel
+    ops.gemm_tn(dy, x, gw)                                                  # gemm_tn_p1_kernel + tn_reduce_kernel
 qkv = rnd(2048 * 198, 2304)
 for _ in range(2):
     o, lse = ops.attention_fwd(qkv, 2048, 198, 12)
