@@ -880,6 +880,7 @@ __global__ __launch_bounds__(64) void attn_colsum_kernel(const AttnArgs p) {
 
 #include "attention_res.inc"
 #include "attention_ps.inc"
+#include "attention_fb.inc"
 
 int check_attn(const void* qkv, int64_t ld, int B, int S, int heads) {
     MERLOT_CHECK(qkv != nullptr, MERLOT_ESHAPE, "attention: null qkv");
@@ -968,6 +969,16 @@ extern "C" int merlot_attention_bwd(const void* qkv, int64_t ld, const void* out
     // dQ (+ delta): the persistent streaming kernel (attention_ps.inc) wherever it applies -- bit-identical to the one-shot
     // kernel and 14-16 % faster at the step's shapes (profiles/r03_c_attention_ps.txt); dK / dV: one-shot (a streaming dK / dV
     // kernel gained 6 % unmasked and nothing masked, same file)
+    // short unmasked sequences (the ViT pass): ONE launch, K | V and then Q | dO resident in LDS (attention_fb.inc) -- 10 instead
+    // of 16 [S, 64] tensors through the CU's memory pipe per (batch, head), bit-identical results
+    int fb_mode = fb_ok(a) ? 1 : 0;
+#ifdef MERLOT_EXPERIMENTS
+    if (const char* e = getenv("MERLOT_ATTN_FB")) fb_mode = fb_ok(a) ? atoi(e) : 0;
+#endif
+    if (fb_mode) {
+        rc = fb_bwd(a, s);
+        return rc ? rc : merlot_launch_status("merlot_attention_bwd");
+    }
     int ps_mode = ps_ok(a) ? 1 : 0;
 #ifdef MERLOT_EXPERIMENTS
     if (const char* e = getenv("MERLOT_ATTN_DBG")) a.dbg = atoi(e);

@@ -1,0 +1,45 @@
+"""Round 3: the fused short-sequence attention backward (attention_fb.inc, MERLOT_ATTN_FB=1, experiments build) against the
+dQ + dK/dV kernel pair (=0): outputs compared bit for bit (dqkv and the published delta), then timing in mirrored order."""
+import _exp_lib  # noqa: F401
+import os
+import torch
+from merlot_amd import ops
+from merlot_amd.lib import call
+from exp_attn_time import timeit
+
+_p = ops._p
+
+
+def bwd(qkv, o, do, lse, B, S):
+    dqkv = torch.full_like(qkv, float('nan'))
+    delta = torch.full((B, 12, S), float('nan'), device='cuda')
+    call('merlot_attention_bwd', _p(qkv), qkv.stride(0), _p(o), o.stride(0), _p(do), do.stride(0), _p(lse), None, None, _p(dqkv),
+         dqkv.stride(0), _p(delta), B, S, 12, 0.125, ops._stream())
+    return dqkv, delta
+
+
+SC = int(os.environ.get('SCALE', 4))
+for B, S in ((64, 65), (64, 96), (64, 100), (64, 130), (64, 160), (64, 198), (64, 224), (64, 225), (64, 256), (512 * SC, 198)):
+    qkv = (torch.randn(B * S, 2304, device='cuda') * 0.7).bfloat16()
+    os.environ['MERLOT_ATTN_FB'] = '0'
+    o, lse = ops.attention_fwd(qkv, B, S, 12)
+    do = torch.randn_like(o)
+    outs = {}
+    for k in ('0', '1'):
+        os.environ['MERLOT_ATTN_FB'] = k
+        outs[k] = bwd(qkv, o, do, lse, B, S)
+    torch.cuda.synchronize()
+    same = torch.equal(outs['0'][0].view(torch.int16), outs['1'][0].view(torch.int16))
+    same_d = torch.equal(outs['0'][1].view(torch.int32), outs['1'][1].view(torch.int32))
+    nan = bool(torch.isnan(outs['1'][0].float()).any())
+    err = []
+    if not same:
+        for name, sl in (('dq', slice(0, 768)), ('dk', slice(768, 1536)), ('dv', slice(1536, 2304))):
+            a, r = outs['1'][0][:, sl].float(), outs['0'][0][:, sl].float()
+            err.append(f'{name} {float((a - r).norm() / r.norm()):.1e}')
+    row = []
+    for k in ('0', '1', '1', '0'):
+        os.environ['MERLOT_ATTN_FB'] = k
+        t = timeit(lambda: ops.attention_bwd(qkv, o, do, lse, B, S, 12))
+        row.append(f'{ {"0": "dQ + dK/dV", "1": "fused"}[k] } {t:7.1f} us')
+    print(f'bwd B {B:5d} S {S:4d}: dqkv bit-identical {same} delta bit-identical {same_d} nan {nan} {" ".join(err)} | ' + ' | '.join(row), flush=True)

@@ -254,6 +254,27 @@ def test_attention_fwd_bwd_at_the_baseline_config_lengths(ops, B, S, heads, pad)
     test_attention_fwd_bwd(ops, B, S, heads, pad)
 
 
+@pytest.mark.parametrize("B,S,heads", [(2, 65, 12), (2, 96, 3), (3, 100, 12), (2, 130, 2), (2, 160, 12), (2, 197, 12), (2, 224, 4),
+                                       (2, 225, 12), (1, 256, 12)])
+def test_attention_bwd_fused_short_unmasked(ops, B, S, heads):
+    """Unmasked sequences of 65..256 tokens (the ViT pass: 198) take the ONE-launch backward of csrc/attention_fb.inc (K | V, then
+    Q | dO resident in LDS): every block / chunk raggedness of that range against the fp32 torch restatement, and the published
+    delta against sum(dO * O)."""
+    test_attention_fwd_bwd(ops, B, S, heads, False)
+    from merlot_amd.lib import call
+    qkv, _, g = _attn_inputs(B, S, heads, 7 + S, False)
+    qkv = qkv.cuda()
+    o, lse = ops.attention_fwd(qkv, B, S, heads)
+    do = rnd((B * S, heads * 64), g).cuda()
+    dqkv = torch.full_like(qkv, float('nan'))
+    delta = torch.full((B, heads, S), float('nan'), device='cuda')
+    call('merlot_attention_bwd', qkv.data_ptr(), qkv.stride(0), o.data_ptr(), o.stride(0), do.data_ptr(), do.stride(0), lse.data_ptr(),
+         None, None, dqkv.data_ptr(), dqkv.stride(0), delta.data_ptr(), B, S, heads, 0.125, torch.cuda.current_stream().cuda_stream)
+    assert not bool(torch.isnan(dqkv.float()).any())
+    want = (do.float() * o.float()).view(B, S, heads, 64).sum(-1).permute(0, 2, 1)
+    assert float((delta - want).abs().max()) < 1e-3 * (1 + float(want.abs().max()))
+
+
 def test_attention_padded_query_rows_uniform(ops):
     """utils/transformer.py:109-112: a fully masked query row attends uniformly over ALL keys (-1e10, not -inf)."""
     B, S, heads = 1, 70, 12
