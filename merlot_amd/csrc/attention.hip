@@ -18,6 +18,7 @@
 // saved log-sum-exp is log(S) -- representable -- whereas -1e10 + log(S) rounds to -1e10 in fp32 and would make
 // the recomputed probabilities of the backward / column-sum kernels 1 instead of 1/S.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -973,6 +974,7 @@ extern "C" int merlot_attention_bwd(const void* qkv, int64_t ld, const void* out
     // of 16 [S, 64] tensors through the CU's memory pipe per (batch, head), bit-identical results
     int fb_mode = fb_ok(a) ? 1 : 0;
 #ifdef MERLOT_EXPERIMENTS
+    if (const char* e = getenv("MERLOT_ATTN_DBG")) a.dbg = atoi(e);
     if (const char* e = getenv("MERLOT_ATTN_FB")) fb_mode = fb_ok(a) ? atoi(e) : 0;
 #endif
     if (fb_mode) {

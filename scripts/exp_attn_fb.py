@@ -43,3 +43,15 @@ for B, S in ((64, 65), (64, 96), (64, 100), (64, 130), (64, 160), (64, 198), (64
         t = timeit(lambda: ops.attention_bwd(qkv, o, do, lse, B, S, 12))
         row.append(f'{ {"0": "dQ + dK/dV", "1": "fused"}[k] } {t:7.1f} us')
     print(f'bwd B {B:5d} S {S:4d}: dqkv bit-identical {same} delta bit-identical {same_d} nan {nan} {" ".join(err)} | ' + ' | '.join(row), flush=True)
+
+# ---- where the time goes (MERLOT_ATTN_DBG: bit 0 = no tile arithmetic, bit 2 = no Q | dO refill)
+B, S = 512 * SC, 198
+qkv = (torch.randn(B * S, 2304, device='cuda') * 0.7).bfloat16()
+o, lse = ops.attention_fwd(qkv, B, S, 12)
+do = torch.randn_like(o)
+os.environ['MERLOT_ATTN_FB'] = '1'
+for dbg in ('0', '1', '4', '5', '0'):
+    os.environ['MERLOT_ATTN_DBG'] = dbg
+    t = timeit(lambda: ops.attention_bwd(qkv, o, do, lse, B, S, 12))
+    print(f'fused B {B} S {S} dbg {dbg}: {t:7.1f} us', flush=True)
+os.environ['MERLOT_ATTN_DBG'] = '0'
