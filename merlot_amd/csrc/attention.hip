@@ -970,8 +970,8 @@ extern "C" int merlot_attention_bwd(const void* qkv, int64_t ld, const void* out
     // dQ (+ delta): the persistent streaming kernel (attention_ps.inc) wherever it applies -- bit-identical to the one-shot
     // kernel and 14-16 % faster at the step's shapes (profiles/r03_c_attention_ps.txt); dK / dV: one-shot (a streaming dK / dV
     // kernel gained 6 % unmasked and nothing masked, same file)
-    // short unmasked sequences (the ViT pass): ONE launch, K | V and then Q | dO resident in LDS (attention_fb.inc) -- 10 instead
-    // of 16 [S, 64] tensors through the CU's memory pipe per (batch, head), bit-identical results
+    // S <= 512 without a segment mask (every pass of the 224^2 step): ONE launch, K | V and then Q | dO resident in LDS
+    // (attention_fb.inc) -- 10 instead of 16 .. 24 [S, 64] tensors through the CU's memory pipe per (batch, head), same results
     int fb_mode = fb_ok(a) ? 1 : 0;
 #ifdef MERLOT_EXPERIMENTS
     if (const char* e = getenv("MERLOT_ATTN_DBG")) a.dbg = atoi(e);
