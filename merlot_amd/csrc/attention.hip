@@ -909,11 +909,20 @@ extern "C" int merlot_attention_fwd(const void* qkv, int64_t ld, void* out, int6
     a.qkv = (const bf16*)qkv; a.ld = ld; a.out = (bf16*)out; a.ldo = ldo; a.lse = lse; a.valid = valid; a.seg = seg;
     a.B = B; a.S = S; a.heads = heads; a.scale = scale;
     a.colsum_lo = colsum_lo; a.colsum_hi = colsum_hi; a.qsplit = qsplit; a.valid_q_only = valid_q_only; a.weight = weight;
-    if (want_cs && S <= RES_MAX_S) {                     // K and V of one (batch, head) resident in LDS: the column sums
-        rc = res_fwd(a, (hipStream_t)stream);            // come from the same launch
+    // K and V of one (batch, head) resident in LDS (attention_res.inc): with side outputs (they come from the same launch), and
+    // for the plain forward of short unmasked sequences (the ViT pass: K | V through the CU's memory pipe once instead of once
+    // per 128-row block, 685 vs 780 us at the bench shape, profiles/r03_j_attention_res.txt; masked sequences: level -> tiled)
+    if (S <= RES_MAX_S && (want_cs || (!valid && S > 64 && S <= 256))) {
+        rc = res_fwd(a, (hipStream_t)stream);
         return rc ? rc : merlot_launch_status("merlot_attention_fwd");
     }
 #ifdef MERLOT_EXPERIMENTS
+    if (const char* e = getenv("MERLOT_ATTN_RES")) {     // the resident forward for calls WITHOUT side outputs
+        if (atoi(e) != 0 && S <= RES_MAX_S) {
+            rc = res_fwd(a, (hipStream_t)stream);
+            return rc ? rc : merlot_launch_status("merlot_attention_fwd");
+        }
+    }
     // the persistent streaming forward (attention_ps.inc, experiments build only): measured level with the one-shot kernel at
     // every shape of the step (profiles/r03_c_attention_ps.txt) -- the forward is bound by its per-tile VALU work, not by data movement
     if (const char* e = getenv("MERLOT_ATTN_DBG")) a.dbg = atoi(e);
