@@ -912,7 +912,11 @@ extern "C" int merlot_attention_fwd(const void* qkv, int64_t ld, void* out, int6
     // K and V of one (batch, head) resident in LDS (attention_res.inc): with side outputs (they come from the same launch), and
     // for the plain forward of short unmasked sequences (the ViT pass: K | V through the CU's memory pipe once instead of once
     // per 128-row block, 685 vs 780 us at the bench shape, profiles/r03_j_attention_res.txt; masked sequences: level -> tiled)
-    if (S <= RES_MAX_S && (want_cs || (!valid && S > 64 && S <= 256))) {
+    bool res_plain = !valid && S > 64 && S <= 256;
+#ifdef MERLOT_EXPERIMENTS
+    if (const char* e = getenv("MERLOT_ATTN_RESFWD")) res_plain = res_plain && atoi(e) != 0;
+#endif
+    if (S <= RES_MAX_S && (want_cs || res_plain)) {
         rc = res_fwd(a, (hipStream_t)stream);
         return rc ? rc : merlot_launch_status("merlot_attention_fwd");
     }
