@@ -914,6 +914,7 @@ extern "C" int merlot_attention_fwd(const void* qkv, int64_t ld, void* out, int6
     // per 128-row block, 685 vs 780 us at the bench shape, profiles/r03_j_attention_res.txt; masked sequences: level -> tiled)
     bool res_plain = !valid && S > 64 && S <= 256;
 #ifdef MERLOT_EXPERIMENTS
+    if (const char* e = getenv("MERLOT_ATTN_DBG")) a.dbg = atoi(e);
     if (const char* e = getenv("MERLOT_ATTN_RESFWD")) res_plain = res_plain && atoi(e) != 0;
 #endif
     if (S <= RES_MAX_S && (want_cs || res_plain)) {

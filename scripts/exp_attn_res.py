@@ -40,3 +40,21 @@ for B, S, joint in ((128 * SC, 328, True), (32 * SC, 512, False)):
         f = lambda: ops.attention_fwd(qkv, B, S, 12, valid, colsum_lo=lo, valid_q_only=False, weight=1.0 / 12)
     t = timeit(f)
     print(f'fwd + side outputs B {B:5d} S {S:4d}: {t:7.1f} us', flush=True)
+
+# (c) where the side-output launches spend their time (MERLOT_ATTN_DBG: 8 = no side-output pass, 16 = no main pass, 24 = neither)
+for B, S, joint in ((128 * SC, 328, True), (32 * SC, 512, False)):
+    qkv = (torch.randn(B * S, 2304, device='cuda') * 0.7).bfloat16()
+    valid = (torch.rand(B, S, device='cuda') > 0.1).to(torch.uint8)
+    valid[:, 0] = 1
+    lo = torch.zeros(B, S, device='cuda')
+    hi = torch.zeros(B, S, device='cuda')
+    if joint:
+        f = lambda: ops.attention_fwd(qkv, B, S, 12, valid, colsum_lo=lo, colsum_hi=hi, qsplit=200, valid_q_only=True, weight=1.0 / 12)
+    else:
+        f = lambda: ops.attention_fwd(qkv, B, S, 12, valid, colsum_lo=lo, valid_q_only=False, weight=1.0 / 12)
+    row = []
+    for dbg in ('0', '8', '16', '24', '0'):
+        os.environ['MERLOT_ATTN_DBG'] = dbg
+        row.append(f'dbg {dbg}: {timeit(f):7.1f} us')
+    os.environ['MERLOT_ATTN_DBG'] = '0'
+    print(f'side-output forward B {B:5d} S {S:4d}: ' + ' | '.join(row), flush=True)
