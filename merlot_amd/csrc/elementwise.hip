@@ -309,6 +309,92 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
     }
 }
 
+// Wide rows (the vocabulary: C = 50 370 fp32 logits = 197 KB): one 1024-thread workgroup per row keeps the WHOLE row in registers
+// (up to 16 x 16 B per thread: C <= 65 536) -- the logits are read from memory once instead of three times; 16-B loads, 8 / 16-B
+// stores.  Same arithmetic per element as softmax_ce_kernel (first maximum wins the argmax; exp(x - max) summed; gradient from
+// exp(x - lse)); the sum runs in a different order, so loss and gradient agree with it to fp32 rounding, not bit for bit.
+template <typename TDL>
+__global__ __launch_bounds__(1024) void softmax_ce_wide_kernel(const float* __restrict__ logits, int64_t ld,
+                                                               const int32_t* __restrict__ labels, float* __restrict__ loss,
+                                                               int32_t* __restrict__ argmax, const float* __restrict__ rowscale,
+                                                               TDL* __restrict__ dl, int64_t ld_dl, int C) {
+    constexpr int MAXV = 16;
+    __shared__ float sval[16];
+    __shared__ int sidx[16];
+    __shared__ float ssum[16];
+    const int64_t row = blockIdx.x;
+    const float* lr = logits + row * ld;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nv = (C + 3) >> 2;                          // 4-column groups that hold logits
+    f32x4 v[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int g = i * 1024 + tid;
+        if (g < nv) {
+            v[i] = *reinterpret_cast<const f32x4*>(lr + 4 * (int64_t)g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * g + e >= C) v[i][e] = -INFINITY;
+        } else {
+            v[i] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        }
+    }
+    float mx = -INFINITY;
+    int mi = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (v[i][e] > mx) { mx = v[i][e]; mi = 4 * (i * 1024 + tid) + e; }     // ascending per thread => first max per thread
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(mx, o, 64);
+        const int oi = __shfl_xor(mi, o, 64);
+        if (ov > mx || (ov == mx && oi < mi)) { mx = ov; mi = oi; }
+    }
+    if (lane == 0) { sval[wave] = mx; sidx[wave] = mi; }
+    __syncthreads();
+    mx = sval[0]; mi = sidx[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w)
+        if (sval[w] > mx || (sval[w] == mx && sidx[w] < mi)) { mx = sval[w]; mi = sidx[w]; }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sum += __expf(v[i][e] - mx);          // exp(-inf) = 0 beyond C
+    sum = wave_sum(sum);
+    if (lane == 0) ssum[wave] = sum;
+    __syncthreads();
+    sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) sum += ssum[w];
+    const float lse = mx + __logf(sum);
+    const int lab = labels[row];
+    if (tid == 0) {
+        loss[row] = lse - lr[lab];
+        if (argmax) argmax[row] = mi;
+    }
+    if (dl) {
+        const float rs = rowscale ? rowscale[row] : 1.0f;
+        TDL* dr = dl + row * ld_dl;
+        const int no = (int)(ld_dl >> 2);                 // 4-column groups of the output row (columns C .. ld_dl: zeros)
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int g = i * 1024 + tid;
+            if (g < no) {
+                TDL o4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = 4 * g + e;
+                    o4[e] = (TDL)(c < C ? rs * (__expf(v[i][e] - lse) - (c == lab ? 1.0f : 0.0f)) : 0.f);
+                }
+                *reinterpret_cast<decltype(o4)*>(dr + 4 * (int64_t)g) = o4;
+            }
+        }
+    }
+}
+
 // ---- l2 normalise ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                          float* __restrict__ inv_norm, int64_t rows, int H) {
@@ -502,6 +588,19 @@ extern "C" int merlot_softmax_ce(const float* logits, int64_t ld, const int32_t*
                                  merlot_stream_t stream) {
     MERLOT_CHECK(logits && labels && loss && rows > 0 && C > 0 && ld >= C, MERLOT_ESHAPE, "merlot_softmax_ce: bad args");
     MERLOT_CHECK(!dlogits || ld_dl >= C, MERLOT_ESHAPE, "merlot_softmax_ce: ld_dl < C");
+    // wide rows: the row-in-registers kernel (its vector accesses need 16-B aligned rows; columns C .. ld_dl of the gradient are
+    // zero-filled by both kernels)
+    const bool wide = C > 4096 && C <= 65536 && ld % 4 == 0 && (uintptr_t)logits % 16 == 0 &&
+                      (!dlogits || (ld_dl % 4 == 0 && ld_dl <= 65536 && (uintptr_t)dlogits % 16 == 0));
+    if (wide) {
+        if (dl_bf16)
+            hipLaunchKernelGGL((softmax_ce_wide_kernel<bf16>), dim3((unsigned)rows), dim3(1024), 0, STREAM, logits, ld, labels, loss,
+                               argmax, rowscale, (bf16*)dlogits, ld_dl, C);
+        else
+            hipLaunchKernelGGL((softmax_ce_wide_kernel<float>), dim3((unsigned)rows), dim3(1024), 0, STREAM, logits, ld, labels, loss,
+                               argmax, rowscale, (float*)dlogits, ld_dl, C);
+        return merlot_launch_status("merlot_softmax_ce");
+    }
     if (dl_bf16)
         hipLaunchKernelGGL((softmax_ce_kernel<bf16>), dim3((unsigned)rows), dim3(256), 0, STREAM, logits, ld, labels, loss,
                            argmax, rowscale, (bf16*)dlogits, ld_dl, C);

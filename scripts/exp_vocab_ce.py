@@ -20,7 +20,7 @@ loss = torch.empty(T, device='cuda')
 am = torch.empty(T, device='cuda', dtype=torch.int32)
 dl = torch.empty(T, VP, device='cuda', dtype=torch.bfloat16)
 ref = None
-for mb in (2600, 160, 96, 48, 24, 160, 2600):
+for mb in (2600, 160, 96, 160, 2600):
     scratch = torch.empty((mb << 20) // 4, device='cuda')
 
     def fn():

@@ -399,7 +399,7 @@ def test_gather_scatter_pool(ops):
     assert rel_l2(ops.cls_avgpool_bwd(dout.cuda(), 6, 14, 14, 2, 2), E.cls_avgpool_bwd(dout, 6, 14, 14, 2, 2).float()) < 4e-3
 
 
-@pytest.mark.parametrize("rows,C,ld", [(40, 4, 4), (64, 128, 128), (25, 50370, 50432)])
+@pytest.mark.parametrize("rows,C,ld", [(40, 4, 4), (64, 128, 128), (25, 50370, 50432), (9, 4097, 4100), (5, 65536, 65536), (3, 7001, 7001)])
 def test_softmax_ce(ops, rows, C, ld):
     g = torch.Generator().manual_seed(C)
     logits = torch.randn((rows, ld), generator=g) * 3
