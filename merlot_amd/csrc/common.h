@@ -27,6 +27,7 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 #endif
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+typedef __attribute__((address_space(3))) int lds_int_t;
 #define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
 // ---- error plumbing (host) -----------------------------------------------------------------

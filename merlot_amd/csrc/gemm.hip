@@ -1127,7 +1127,9 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_dyn_kernel(const GemmNTAr
     const int slot = xcd_remap(blockIdx.x, nwg);
     const int band0 = slot - ((int)blockIdx.x >> 3);                  // first tile of the band in round 0
     unsigned int* ctr = p.ctr;
-    volatile int* bcast = reinterpret_cast<volatile int*>(dsm + C::RING_BYTES);   // wave 0's idle epilogue slab
+    // an LDS-address-space pointer: through a generic `volatile int*` the read compiled to flat_load + s_waitcnt vmcnt(0), which
+    // drains the whole LDS-DMA stream once per tile (profiles/r03_m_p8_ktile.txt)
+    volatile lds_int_t* bcast = (volatile lds_int_t*)LDS_PTR(dsm + C::RING_BYTES);   // wave 0's idle epilogue slab
     const bool fast_ok = !DBG_BIT(p, 32) && !(p.N & 1) && ((p.ldc & 7) == 0) && ((p.ld_aux_in & 7) == 0) && ((p.ld_aux_out & 7) == 0) &&
                          ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) && ((reinterpret_cast<uintptr_t>(p.aux_in) & 15) == 0) &&
                          ((reinterpret_cast<uintptr_t>(p.aux_out) & 15) == 0) && ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0) &&
