@@ -275,6 +275,45 @@ def test_attention_bwd_fused_short_unmasked(ops, B, S, heads):
     assert float((delta - want).abs().max()) < 1e-3 * (1 + float(want.abs().max()))
 
 
+@pytest.mark.parametrize("B,S,heads,pad,pads", [(3, 198, 12, False, (64, 8, 16, 8)), (2, 130, 5, True, (8, 24, 8, 16)),
+                                                 (2, 328, 3, True, (128, 8, 8, 8)), (1, 512, 2, True, (8, 8, 8, 8)),
+                                                 (5, 77, 7, False, (16, 40, 8, 24))])
+def test_attention_nondefault_leading_dims(ops, B, S, heads, pad, pads):
+    """The resident forward and the fused backward build their LDS-DMA source addresses from the leading dimensions: operands with
+    padded rows (ld > 3 * heads * 64, ldo / lddo > heads * 64), odd head counts; the padding columns of the outputs stay untouched."""
+    from merlot_amd.lib import call
+    D = heads * 64
+    ld, ldo, lddo, lddq = 3 * D + pads[0], D + pads[1], D + pads[2], 3 * D + pads[3]
+    qkv, valid, g = _attn_inputs(B, S, heads, 31 + S, pad)
+    qkv_full = torch.zeros((B * S, ld), dtype=BF16)
+    qkv_full[:, :3 * D] = qkv
+    qkv_full = qkv_full.cuda()
+    vp = valid.cuda() if valid is not None else None
+    o_full = torch.full((B * S, ldo), float('nan'), device='cuda', dtype=BF16)
+    lse = torch.empty(B, heads, S, device='cuda')
+    stream = torch.cuda.current_stream().cuda_stream
+    call('merlot_attention_fwd', qkv_full.data_ptr(), ld, o_full.data_ptr(), ldo, lse.data_ptr(), vp.data_ptr() if pad else None, None, B, S,
+         heads, 0.125, None, None, S, 0, 1.0, stream)
+    o_ref, lse_ref = E.attention_fwd(qkv, B, S, heads, valid)
+    assert rel_l2(o_full[:, :D], o_ref) < 8e-3 and float((lse.cpu() - lse_ref).abs().max()) < 2e-2
+    assert bool(torch.isnan(o_full[:, D:].float()).all())
+    do = rnd((B * S, D), g)
+    if valid is not None:
+        do = do * valid.reshape(B * S, 1).to(BF16)
+    do_full = torch.zeros((B * S, lddo), dtype=BF16)
+    do_full[:, :D] = do
+    do_full = do_full.cuda()
+    dqkv = torch.full((B * S, lddq), float('nan'), device='cuda', dtype=BF16)
+    delta = torch.empty((B, heads, S), device='cuda')
+    call('merlot_attention_bwd', qkv_full.data_ptr(), ld, o_full.data_ptr(), ldo, do_full.data_ptr(), lddo, lse.data_ptr(),
+         vp.data_ptr() if pad else None, None, dqkv.data_ptr(), lddq, delta.data_ptr(), B, S, heads, 0.125, stream)
+    dq_ref = E.attention_bwd(qkv, o_ref, do, lse_ref, B, S, heads, valid).float()
+    got = dqkv[:, :3 * D].float().cpu()
+    for name, sl in [('dq', slice(0, D)), ('dk', slice(D, 2 * D)), ('dv', slice(2 * D, 3 * D))]:
+        assert rel_l2(got[:, sl], dq_ref[:, sl]) < 1.5e-2, name
+    assert bool(torch.isnan(dqkv[:, 3 * D:].float()).all())
+
+
 def test_attention_padded_query_rows_uniform(ops):
     """utils/transformer.py:109-112: a fully masked query row attends uniformly over ALL keys (-1e10, not -inf)."""
     B, S, heads = 1, 70, 12
