@@ -31,6 +31,10 @@ extern "C" {
 
 typedef void* merlot_stream_t;
 
+/* Bumped whenever a signature of this header changes.  merlot_abi_version() returns the value the library was built with;
+ * a binding must compare the two before its first call (merlot_amd/lib.py does, and refuses a mismatching library). */
+#define MERLOT_ABI_VERSION 5
+
 const char* merlot_last_error(void);
 int merlot_abi_version(void);
 

@@ -880,7 +880,6 @@ __global__ __launch_bounds__(64) void attn_colsum_kernel(const AttnArgs p) {
 }
 
 #include "attention_res.inc"
-#include "attention_ps.inc"
 #include "attention_fb.inc"
 
 int check_attn(const void* qkv, int64_t ld, int B, int S, int heads) {
@@ -928,15 +927,6 @@ extern "C" int merlot_attention_fwd(const void* qkv, int64_t ld, void* out, int6
             return rc ? rc : merlot_launch_status("merlot_attention_fwd");
         }
     }
-    // the persistent streaming forward (attention_ps.inc, experiments build only): measured level with the one-shot kernel at
-    // every shape of the step (profiles/r03_c_attention_ps.txt) -- the forward is bound by its per-tile VALU work, not by data movement
-    if (const char* e = getenv("MERLOT_ATTN_DBG")) a.dbg = atoi(e);
-    if (const char* e = getenv("MERLOT_ATTN_PS")) {
-        if (atoi(e) != 0 && !want_cs && ps_ok(a)) {
-            rc = ps_fwd(a, (hipStream_t)stream, atoi(e));
-            return rc ? rc : merlot_launch_status("merlot_attention_fwd");
-        }
-    }
 #endif
     if (valid)
         hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, (hipStream_t)stream, a);
@@ -981,9 +971,6 @@ extern "C" int merlot_attention_bwd(const void* qkv, int64_t ld, const void* out
     a.lse = (float*)lse; a.delta = delta; a.valid = valid; a.seg = seg; a.dqkv = (bf16*)dqkv; a.lddqkv = lddqkv;
     a.B = B; a.S = S; a.heads = heads; a.scale = scale;
     hipStream_t s = (hipStream_t)stream;
-    // dQ (+ delta): the persistent streaming kernel (attention_ps.inc) wherever it applies -- bit-identical to the one-shot
-    // kernel and 14-16 % faster at the step's shapes (profiles/r03_c_attention_ps.txt); dK / dV: one-shot (a streaming dK / dV
-    // kernel gained 6 % unmasked and nothing masked, same file)
     // S <= 512 without a segment mask (every pass of the 224^2 step): ONE launch, K | V and then Q | dO resident in LDS
     // (attention_fb.inc) -- 10 instead of 16 .. 24 [S, 64] tensors through the CU's memory pipe per (batch, head), same results
     int fb_mode = fb_ok(a) ? 1 : 0;
@@ -995,20 +982,14 @@ extern "C" int merlot_attention_bwd(const void* qkv, int64_t ld, const void* out
         rc = fb_bwd(a, s);
         return rc ? rc : merlot_launch_status("merlot_attention_bwd");
     }
-    int ps_mode = ps_ok(a) ? 1 : 0;
-#ifdef MERLOT_EXPERIMENTS
-    if (const char* e = getenv("MERLOT_ATTN_DBG")) a.dbg = atoi(e);
-    if (const char* e = getenv("MERLOT_ATTN_PS_BWD")) ps_mode = ps_ok(a) ? atoi(e) : 0;
-#endif
-    if (ps_mode & 1) {
-        rc = ps_bwd_dq(a, s);
-        if (rc) return rc;
-    }
+    // everything else (longer sequences -- BASELINE config #5's S = 578 / 2832 --, segment masks, S <= 64, unaligned outputs):
+    // the tiled pair, dQ (+ delta) then dK / dV, each recomputing S and dP.  (Round 3's persistent streaming dQ kernel sat between
+    // the two; since the fused kernel took every sequence <= 512 it was reachable only for misaligned outputs and was retired.)
     if (valid) {
-        if (!(ps_mode & 1)) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);
         hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);
     } else {
-        if (!(ps_mode & 1)) hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);
         hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);
     }
     return merlot_launch_status("merlot_attention_bwd");

@@ -14,4 +14,4 @@ void merlot_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* merlot_last_error(void) { return g_err; }
-extern "C" int merlot_abi_version(void) { return 4; }
+extern "C" int merlot_abi_version(void) { return MERLOT_ABI_VERSION; }

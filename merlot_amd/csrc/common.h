@@ -40,6 +40,34 @@ void merlot_set_error(const char* fmt, ...);
         }                                         \
     } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is an attribute of a kernel ON ONE DEVICE: a process that drives several GPUs has
+// to set it on each of them.  `LdsAttrOnce` remembers, per device, the largest size already granted to one kernel (a cache of an
+// idempotent driver attribute, not library state: losing it only costs one more hipFuncSetAttribute); host threads may race.
+struct LdsAttrOnce {
+    int granted[64];                                     // zero-initialised (static storage); index = device ordinal & 63
+};
+static inline int merlot_ensure_lds(LdsAttrOnce& st, const void* kern, int bytes, const char* what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    int* slot = &st.granted[dev & 63];
+    if (__atomic_load_n(slot, __ATOMIC_ACQUIRE) >= bytes) return MERLOT_OK;
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        merlot_set_error("%s: hipFuncSetAttribute(LDS=%d) failed on device %d: %s", what, bytes, dev, hipGetErrorString(e));
+        return MERLOT_ELAUNCH;
+    }
+    int cur = __atomic_load_n(slot, __ATOMIC_RELAXED);   // published only AFTER the attribute is in place
+    while (cur < bytes && !__atomic_compare_exchange_n(slot, &cur, bytes, true, __ATOMIC_RELEASE, __ATOMIC_RELAXED)) {
+    }
+    return MERLOT_OK;
+}
+#define MERLOT_ENSURE_LDS(kern, bytes, what)                                                         \
+    do {                                                                                              \
+        static LdsAttrOnce lds_once_;                                                                 \
+        const int rc_ = merlot_ensure_lds(lds_once_, reinterpret_cast<const void*>(kern), bytes, what); \
+        if (rc_ != MERLOT_OK) return rc_;                                                             \
+    } while (0)
+
 static inline int merlot_launch_status(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -1463,14 +1463,7 @@ int launch_nt(const GemmNTArgs& a, int out_f32, hipStream_t s) {
 template <typename C, int EPI, bool OUT_F32>
 int launch_ring_one(GemmNTArgs& a, hipStream_t s) {
     auto kern = gemm_nt_ring_kernel<C, EPI, OUT_F32>;
-    static bool attr_set = false;                    // per instantiation
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           C::LDS_BYTES);
-        MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipFuncSetAttribute(LDS=%d) failed: %s", C::LDS_BYTES,
-                     hipGetErrorString(e));
-        attr_set = true;
-    }
+    MERLOT_ENSURE_LDS(kern, C::LDS_BYTES, "merlot_gemm_bf16_nt(ring)");
     a.ntm = cdiv(a.M, C::BM);
     a.ntn = cdiv(a.N, C::BN);
     hipLaunchKernelGGL(kern, dim3(a.ntm * a.ntn), dim3(C::NT), C::LDS_BYTES, s, a);
@@ -1496,13 +1489,7 @@ int launch_ring(GemmNTArgs& a, int epilogue, int out_f32, hipStream_t s) {
 template <int EPI, bool OUT_F32>
 int launch_persist_one(GemmNTArgs& a, hipStream_t s) {
     auto kern = gemm_nt_persist_kernel<EPI, OUT_F32>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           PERSIST_LDS);
-        MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipFuncSetAttribute(LDS=%d) failed: %s", PERSIST_LDS, hipGetErrorString(e));
-        attr_set = true;
-    }
+    MERLOT_ENSURE_LDS(kern, PERSIST_LDS, "merlot_gemm_bf16_nt(persistent)");
     a.ntm = cdiv(a.M, RingP::BM);
     a.ntn = cdiv(a.N, RingP::BN);
     int grid = a.ntm * a.ntn;
@@ -1514,13 +1501,7 @@ int launch_persist_one(GemmNTArgs& a, hipStream_t s) {
 template <int EPI, bool OUT_F32>
 int launch_persist_dyn_one(GemmNTArgs& a, hipStream_t s) {
     auto kern = gemm_nt_persist_dyn_kernel<EPI, OUT_F32>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           PERSIST_LDS);
-        MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipFuncSetAttribute(LDS=%d) failed: %s", PERSIST_LDS, hipGetErrorString(e));
-        attr_set = true;
-    }
+    MERLOT_ENSURE_LDS(kern, PERSIST_LDS, "merlot_gemm_bf16_nt(persistent)");
     a.ntm = cdiv(a.M, RingP::BM);
     a.ntn = cdiv(a.N, RingP::BN);
     a.cg = 0;                                            // row-major tile enumeration (profiles/r01_i_gemm_ceiling.txt section 5)
@@ -1693,13 +1674,7 @@ TnPlan tn_plan(int64_t M, int64_t N, int64_t R) {
 template <typename C>
 int tn_ring_launch_cfg(GemmTNArgs& a, const TnPlan& pl, float* ws, hipStream_t s) {
     auto kern = gemm_tn_ring_kernel<C>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           C::LDS_BYTES);
-        MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    MERLOT_ENSURE_LDS(kern, C::LDS_BYTES, "merlot_gemm_bf16_tn(ring)");
     hipLaunchKernelGGL(kern, dim3(pl.ntm * pl.ntn * pl.splits), dim3(C::NT), C::LDS_BYTES, s, a, ws);
     return MERLOT_OK;
 }
@@ -1767,21 +1742,10 @@ int tn_p8_launch(GemmTNArgs& a, int accumulate, float* ws, int64_t ws_bytes, hip
     // weight-gradient shape of the step, two -> one another +3-5 % (1 230 TFLOP/s = 0.49 of peak on dW1 / dW2); the two- and
     // four-phase bodies of gemm_tn_p8_kernel remain in the experiments build (MERLOT_TN_PH2 = 1 / 0).
     int ph = 1;
-    static bool attr1 = false;
-    if (!attr1) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_p1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
-        MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-        attr1 = true;
-    }
+    MERLOT_ENSURE_LDS(gemm_tn_p1_kernel, P8_LDS, "merlot_gemm_bf16_tn(p1)");
 #ifdef MERLOT_EXPERIMENTS
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_p8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
-        MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_p8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
-        MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    MERLOT_ENSURE_LDS(gemm_tn_p8_kernel<true>, P8_LDS, "merlot_gemm_bf16_tn(p8)");
+    MERLOT_ENSURE_LDS(gemm_tn_p8_kernel<false>, P8_LDS, "merlot_gemm_bf16_tn(p8)");
     if (const char* e = getenv("MERLOT_TN_PH2")) ph = atoi(e) == 0 ? 4 : atoi(e) == 1 ? 2 : 1;
     if (ph == 4) hipLaunchKernelGGL(gemm_tn_p8_kernel<false>, dim3(pl.ntm * pl.ntn * pl.splits), dim3(512), P8_LDS, s, a, ws);
     if (ph == 2) hipLaunchKernelGGL(gemm_tn_p8_kernel<true>, dim3(pl.ntm * pl.ntn * pl.splits), dim3(512), P8_LDS, s, a, ws);

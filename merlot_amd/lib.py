@@ -53,6 +53,7 @@ class _Lib(object):
     def __init__(self, header=HEADER, path=None):
         self._dll = None
         self.path = path
+        self.header = header
         self.protos = parse_header(header)
 
     def load(self):
@@ -68,6 +69,15 @@ class _Lib(object):
             fn = getattr(dll, name)
             fn.restype = {'int': ctypes.c_int, 'int64_t': ctypes.c_int64}.get(ret, ctypes.c_char_p)
             fn.argtypes = [_CTYPES[t] for t, _ in args]
+        if 'merlot_abi_version' in self.protos:
+            # a stale library of another ABI version would take shifted arguments (v4 inserted workspace pointers in front of
+            # `stream`) without any error: refuse it here, before the first call
+            m = re.search(r'#define\s+MERLOT_ABI_VERSION\s+(\d+)', open(self.header).read())
+            want = int(m.group(1)) if m else None
+            got = int(dll.merlot_abi_version())
+            if want is not None and got != want:
+                raise MerlotHipError(f"{path} implements ABI v{got}, {self.header} declares v{want}: rebuild the library "
+                                     f"(merlot_amd/csrc/build.sh)")
         self._dll = dll
         return dll
 

@@ -394,20 +394,15 @@ def softmax_ce(logits, labels, C, *, rowscale=None, dlogits_dtype=None, ld_dl=No
     return loss, am, dl
 
 
-_VOCAB_SCRATCH = {}
-
-
 def vocab_ce(hb, table, out_bias, targets, rowscale, vocab, ld_dl):
-    """MLM head tail in one C-ABI call (merlot_vocab_ce_fwd): logits GEMM + softmax cross-entropy through a per-stream fp32 scratch
+    """MLM head tail in one C-ABI call (merlot_vocab_ce_fwd): logits GEMM + softmax cross-entropy through an fp32 scratch that
+    lives for this call only (a caching-allocator hit: the 2.6 GB block is free for the backward's tensors afterwards)
     -> (loss f32 [T], argmax int32 [T], dlogits bf16 [T, ld_dl])."""
     _chk(hb, BF16, 'h'); _chk(table, BF16, 'table'); _chk(out_bias, F32, 'out_bias'); _chk(targets, torch.int32, 'targets')
     _chk(rowscale, F32, 'rowscale')
     T, K = hb.shape
     need = LIB.query('merlot_vocab_ce_scratch_bytes', T, vocab)
-    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
-    scratch = _VOCAB_SCRATCH.get(key)
-    if scratch is None or scratch.numel() * 4 < need:
-        scratch = _VOCAB_SCRATCH[key] = torch.empty(need // 4, device=hb.device, dtype=F32)
+    scratch = torch.empty((need + 3) // 4, device=hb.device, dtype=F32)
     loss = torch.empty(T, device=hb.device, dtype=F32)
     am = torch.empty(T, device=hb.device, dtype=torch.int32)
     dl = torch.empty((T, ld_dl), device=hb.device, dtype=BF16)

@@ -108,6 +108,15 @@ class Trainer(object):
     def _defer_check(self, flag):
         if flag is None:
             return
+        from .parallel import FORCE
+        if self.dist is not None and (self.dist.world_size > 1 or FORCE):
+            # the reference's in-graph assertion fails the whole job: every rank has to see ANY rank's bad batch, or the
+            # good ranks would apply an update that already contains the bad rank's gradients and then hang at the next
+            # collective.  One 4-byte MAX all-reduce, queued right behind the forward like the copy below.
+            import torch.distributed as dist
+            flag = flag.to(torch.int32).reshape(1)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.dist.group)
+            flag = flag.reshape(()) != 0
         if flag.is_cuda:
             host = torch.empty((), dtype=torch.bool, pin_memory=True)
             host.copy_(flag, non_blocking=True)
@@ -134,7 +143,8 @@ class Trainer(object):
             self.reducer.finish()
         # THIS step's flag, before its update is applied (the reference fails the step in-graph, utils/model_utils.py:256-258):
         # the host waits for the forward's embedding lookups only -- the whole backward is already queued behind them, so
-        # the GPU never idles -- and a bad batch neither reaches the weights nor a checkpoint.
+        # the GPU never idles -- and a bad batch neither reaches the weights nor a checkpoint (on ANY rank: the flag is
+        # MAX-reduced across the replicas in _defer_check, so all of them raise together).
         self.check_inputs(wait=True)
         self.opt.step()
         self.step_idx += 1
