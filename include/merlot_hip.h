@@ -33,7 +33,7 @@ typedef void* merlot_stream_t;
 
 /* Bumped whenever a signature of this header changes.  merlot_abi_version() returns the value the library was built with;
  * a binding must compare the two before its first call (merlot_amd/lib.py does, and refuses a mismatching library). */
-#define MERLOT_ABI_VERSION 5
+#define MERLOT_ABI_VERSION 4
 
 const char* merlot_last_error(void);
 int merlot_abi_version(void);
@@ -55,7 +55,7 @@ enum merlot_epilogue {
  * keep-mask is a counter-based hash of (dropout_seed, m*N+n) -- one 32-bit hash per pair of elements, p resolved to
  * 2^-16 -- survivors scaled 1/(1-p) (utils/model_utils.py:335-349); merlot_dropout_apply / merlot_ln_bwd regenerate
  * the same mask.  GELU / GELU' in the epilogues are the exact-erf forms of utils/model_utils.py:96-110 evaluated by
- * degree-12 polynomials (abs error 2.5e-6 / 4.2e-6, far below the bf16 rounding of C).
+ * degree-10 polynomials (abs error 1.6e-5 / 1.1e-4 over the whole line, below the bf16 rounding of C; scripts/fit_gelu_poly.py).
  * Large problems run on a persistent kernel whose workgroups CLAIM their tiles through a counter block in CALLER-owned
  * `workspace` (merlot_gemm_nt_workspace_bytes() bytes, 4-byte aligned, zero on entry; the last workgroup out leaves it
  * zero again, so one block serves every launch of a stream and needs zeroing once, at allocation).  The library itself

@@ -21,13 +21,16 @@ build_lib() {  # build_lib <objdir> <out> <extra flags>
   local dir=$1 out=$2 extra=$3
   mkdir -p $dir
   local pids=()
+  : > $dir/BUILD_MANIFEST                      # one line per object: "compiled <obj>" or "reused <obj>" (what build() really did)
   for f in $SRCS; do
-    if newer $dir/$f.o $f.hip $HDRS; then ( $HIPCC $FLAGS $extra -c $f.hip -o $dir/$f.o ) & pids+=($!); fi
+    if newer $dir/$f.o $f.hip $HDRS; then ( $HIPCC $FLAGS $extra -c $f.hip -o $dir/$f.o ) & pids+=($!); echo "compiled $f.o" >> $dir/BUILD_MANIFEST
+    else echo "reused $f.o" >> $dir/BUILD_MANIFEST; fi
   done
   for f in capi hostio jpeg_host; do
-    if newer $dir/$f.o $f.cpp ../../include/merlot_hip.h; then ( g++ -O2 -fPIC -std=c++17 $extra -c $f.cpp -o $dir/$f.o ) & pids+=($!); fi
+    if newer $dir/$f.o $f.cpp ../../include/merlot_hip.h; then ( g++ -O2 -fPIC -std=c++17 $extra -c $f.cpp -o $dir/$f.o ) & pids+=($!); echo "compiled $f.o" >> $dir/BUILD_MANIFEST
+    else echo "reused $f.o" >> $dir/BUILD_MANIFEST; fi
   done
-  for p in "${pids[@]}"; do wait $p; done
+  for p in "${pids[@]}"; do wait $p || { echo "build.sh: a compile job failed" >&2; exit 1; }; done
   local objs=""
   for f in $SRCS capi hostio jpeg_host; do objs="$objs $dir/$f.o"; done
   $HIPCC --offload-arch=gfx950 -shared -fPIC -o $out $objs

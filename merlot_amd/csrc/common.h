@@ -93,19 +93,23 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 // 2 quarter-rate transcendentals (profiles/r01_f_epilogue_decomposition.txt).  Here, with a = min(|x|, 4.5),
 //   gelu(x)  = max(x, 0) - r(a),            r(a) = a * Phi(-a)            (smooth hump, -> 0)
 //   gelu'(x) = x >= 0 ? 1 - d(a) : d(a),    d(a) = Phi(-a) - a * phi(a)   (smooth, -> 0)
-// and r, d are degree-12 polynomials in t = a * 2/4.5 - 1 (Chebyshev fit, fp32 Horner): max abs error 2.5e-6 / 4.2e-6
-// (1.5e-5 / 7e-5 beyond |x| = 4.5) -- three orders below the bf16 rounding of the result -- no transcendental, and
-// evaluated two elements per instruction with v_pk_fma_f32.  Coefficients: scripts/fit_gelu_poly.py.
-__device__ constexpr float GELU_R[13] = {2.750501223e-02f, -1.331440359e-01f, 2.460481972e-01f, -1.450011879e-01f, -1.969143003e-01f, 4.218034446e-01f, -2.295046449e-01f, -1.455463320e-01f, 2.215920240e-01f, -9.922845289e-03f, -8.095980436e-02f, 1.182068978e-02f, 1.224126294e-02f};
-__device__ constexpr float GELU_D[13] = {-5.918708444e-02f, 2.187175453e-01f, -1.923305541e-01f, -3.502573371e-01f, 9.239494205e-01f, -6.108126044e-01f, -3.885312378e-01f, 7.847974896e-01f, -1.774333119e-01f, -3.563932776e-01f, 1.924710423e-01f, 6.391551346e-02f, -4.897490889e-02f};
+// and r, d are degree-10 polynomials in t = a * 2/4.5 - 1 (Chebyshev fit, fp32 Horner): max abs error 1.6e-5 / 1.1e-4 over the
+// whole line -- what the clamp at 4.5 leaves anyway (r(4.5) = 1.5e-5, d(4.5) = -6.9e-5: the degree-12 fits of rounds 1-3 were
+// 2.5e-6 / 4.2e-6 inside the interval and no better than that outside), below half a bf16 ulp of every gelu output with
+// |y| >= 0.008 -- no transcendental, evaluated two elements per instruction with v_pk_fma_f32.  The GELU epilogues are VALU-bound
+// (profiles/r02_f_epilogue_timeline.txt: the polynomial was ~10 k of the fc1 tile's 23 k epilogue cycles), so every FMA counts.
+// Coefficients: scripts/fit_gelu_poly.py.
+__device__ constexpr float GELU_R[11] = {2.749903500e-02f, -1.330170631e-01f, 2.464785576e-01f, -1.475407928e-01f, -2.019351274e-01f, 4.360252321e-01f, -2.080824375e-01f, -1.780532300e-01f, 1.802777648e-01f, 2.258405089e-02f, -4.423601553e-02f};
+__device__ constexpr float GELU_D[11] = {-5.916317180e-02f, 2.194041312e-01f, -1.940523237e-01f, -3.639891744e-01f, 9.440367818e-01f, -5.339142084e-01f, -4.742373228e-01f, 6.090298295e-01f, -1.214299630e-02f, -1.806256324e-01f, 4.554631189e-02f};
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 gelu_poly_pk(f32x2 a, const float (&c)[13]) {
+constexpr int GELU_DEG = 10;
+__device__ __forceinline__ f32x2 gelu_poly_pk(f32x2 a, const float (&c)[GELU_DEG + 1]) {
     const f32x2 lim = {4.5f, 4.5f}, sc = {2.0f / 4.5f, 2.0f / 4.5f}, m1 = {-1.0f, -1.0f};
     a = __builtin_elementwise_min(a, lim);
     const f32x2 t = __builtin_elementwise_fma(a, sc, m1);
-    f32x2 acc = {c[12], c[12]};
+    f32x2 acc = {c[GELU_DEG], c[GELU_DEG]};
 #pragma unroll
-    for (int k = 11; k >= 0; --k) {
+    for (int k = GELU_DEG - 1; k >= 0; --k) {
         const f32x2 ck = {c[k], c[k]};
         acc = __builtin_elementwise_fma(acc, t, ck);
     }
@@ -124,6 +128,10 @@ __device__ __forceinline__ void gelu_grad_fast2(float u0, float u1, float& g0, f
     g0 = u0 >= 0.f ? 1.0f - d[0] : d[0];
     g1 = u1 >= 0.f ? 1.0f - d[1] : d[1];
 }
+// (Round 4 measured the alternative the ISA suggested -- hipcc separates the dependent v_pk_fma_f32 of a chain by s_nop and
+// evaluates pair after pair --: eight independent scalar chains of v_fmaak_f32 interleaved step by step.  Same-box A/B: fc1 622 ->
+// 632 us, GELU' level, step +0.5 %: the packed form stays.  The epilogue is bound by VALU throughput (2 cycles per FMA and element
+// either way), not by the chain's latency; profiles/r04_b_gelu_scalar_ab.txt.)
 __device__ __forceinline__ float gelu_fast(float x) {
     float y0 = x, y1 = x;
     gelu_fast2(y0, y1);

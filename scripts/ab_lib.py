@@ -7,6 +7,7 @@ sys.path.insert(0, ROOT)
 from merlot_amd import lib  # noqa: E402
 if os.environ.get('AB_LIB'):
     lib.LIB.path = os.path.abspath(os.environ['AB_LIB'])
+    lib.LIB.check_abi = False             # an older build: only entry points whose signature did not change are called here
 import torch  # noqa: E402
 from merlot_amd import ops  # noqa: E402
 

@@ -8,5 +8,6 @@ sys.path.insert(0, ROOT)
 from merlot_amd import lib  # noqa: E402
 if os.environ.get('AB_LIB'):
     lib.LIB.path = os.path.abspath(os.environ['AB_LIB'])
+    lib.LIB.check_abi = False
 sys.argv[0] = os.path.join(ROOT, 'bench.py')
 runpy.run_path(sys.argv[0], run_name='__main__')
