@@ -37,7 +37,10 @@ def problem(which):
         cfg = tiny_config()
         return cfg, synth_batch(cfg)
     if which == 'config2x8':                                # config #2's geometry (224^2, groups of 4, 16 chunks), 8 examples, 2 + 2 + 2 layers
-        cfg = tiny_config(image_size=[224, 224])
+        # masking_use_attn off: with 32 groups a near-tie between the 25th and 26th attention sum of SOME group flips between the
+        # bf16 and the fp32 run, and a different mask is a different problem (the attention-guided choice is compared where it is
+        # stable: config #1, config #2 at one example, the reference-run fixtures); the masks here come from the explicit noise only
+        cfg = tiny_config(image_size=[224, 224], masking_use_attn=False)
         return cfg, synth_batch(cfg, E=8, num_chunks=16, seed=5)
     raise ValueError(which)
 
@@ -58,7 +61,7 @@ def _run_product(cfg, w, b, device):
     if device != 'cpu':
         torch.cuda.synchronize()
     g = {k: v.detach().float().cpu() for k, v in st.export_tf_grads().items()}
-    return g, float(l1 + l2 + l3), pm.lang_mask_info['masked_idx'].cpu().numpy()
+    return g, float((l1 + l2 + l3).detach()), pm.lang_mask_info['masked_idx'].cpu().numpy()
 
 
 def run_all(which, verbose=False):

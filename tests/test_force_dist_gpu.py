@@ -1,0 +1,83 @@
+"""GPU: one `Trainer.step` with every collective of the data-parallel path issued on REAL RCCL kernels -- a world-size-1 `nccl` group
+under MERLOT_FORCE_DIST: the fused all-gather of the contrastive embeddings and its reduce-scatter backward
+(model/modeling.py:504-510, utils/model_utils.py:673-707), the per-layer gradient buckets launched from inside the backward and the
+tail in `finish()` (utils/optimization.py:241-245), the MAX-reduced token-id flag -- against the same step without a process group.
+At world size 1 every collective is the identity, so the two steps have to agree to the last bit wherever the kernels are
+deterministic; bias / LayerNorm gradients are summed with fp32 atomics (arrival order), so the comparison allows what two plain steps
+differ by and not more.  (No multi-GPU node is available to this build: this is the collectives' only run on hardware.)"""
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(('127.0.0.1', 0))
+        return so.getsockname()[1]
+
+
+def _step(config, dist_ctx, batch, payload=None):
+    from merlot_amd.train import Trainer
+    if payload:
+        config.optimizer['grad_reduce_dtype'] = payload
+    tr = Trainer(config, 'cuda', dist_ctx, seed=0)
+    out = tr.step(batch)
+    torch.cuda.synchronize()
+    return float(out['loss'].detach()), tr.store.grad.clone(), tr.store.master.clone() if hasattr(tr.store, 'master') else None, tr
+
+
+def test_trainer_step_under_forced_rccl_collectives_matches_the_plain_step(monkeypatch):
+    import copy
+
+    import torch.distributed as dist
+
+    import merlot_amd.parallel as par
+    from merlot_amd import NeatConfig
+    from merlot_amd.train import synthetic_batch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    config = NeatConfig.from_yaml(os.path.join(root, 'merlot_amd', 'configs', 'pretrain_4seg_224.yaml'))
+    config.model.update(image_size=[64, 64], num_hidden_layers=2, num_vision_transformer_hidden_layers=2, num_lang_transformer_hidden_layers=2)
+    config.data['num_chunks'] = 4
+    batch = synthetic_batch(config, 4, 'cuda', seed=77)
+    # two plain steps: what the atomics' arrival order alone moves
+    l0, g0, _, _ = _step(copy.deepcopy(config), None, batch)
+    l1, g1, _, _ = _step(copy.deepcopy(config), None, batch)
+    noise = float((g0 - g1).abs().max())
+    scale = float(g0.abs().max())
+    assert noise <= 1e-5 * scale
+    # the same step with the collectives on
+    monkeypatch.setenv('HSA_ENABLE_IPC_MODE_LEGACY', os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{_free_port()}', rank=0, world_size=1,
+                            device_id=torch.device('cuda', torch.cuda.current_device()))
+    try:
+        monkeypatch.setattr(par, 'FORCE', True)
+        ctx = par.DistContext()
+        launched = []
+        real = par.GradReducer._launch
+
+        def spy(self, s, e):
+            launched.append((s, e))
+            return real(self, s, e)
+        monkeypatch.setattr(par.GradReducer, '_launch', spy)
+        lf, gf, _, tr = _step(copy.deepcopy(config), ctx, batch)
+        assert tr.reducer is not None
+        # buckets: the per-layer ranges launched from inside the backward + the tail, together exactly one cover of the arena
+        assert len(launched) >= 6
+        cover = sorted(launched)
+        assert cover[0][0] == 0 and cover[-1][1] == tr.store.numel
+        assert all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+        assert abs(lf - l0) <= 1e-6 * max(1.0, abs(l0))
+        d = float((gf - g0).abs().max())
+        assert d <= max(2.0 * noise, 1e-7 * scale), (d, noise, scale)
+        # bf16 bucket payload (optimizer.grad_reduce_dtype: bfloat16): each gradient element is rounded to bf16 once
+        launched.clear()
+        lb, gb, _, _ = _step(copy.deepcopy(config), ctx, batch, payload='bfloat16')
+        rel = float((gb - g0).norm() / g0.norm())
+        assert rel < 4e-3, rel
+        assert torch.equal(gb, gb.to(torch.bfloat16).float())
+    finally:
+        dist.destroy_process_group()

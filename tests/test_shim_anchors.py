@@ -200,3 +200,83 @@ def test_conv2d_and_avg_pool_layout_conventions_on_a_hand_computed_case(tf):
             for c in range(3):
                 want = sum(float(xp[0, 2 * y + dy, 2 * xx + dx, c]) for dy in range(2) for dx in range(2)) / 4.0
                 assert abs(float(pooled[0, y, xx, c]) - want) < 1e-6
+
+
+# ---- round 4 (VERDICT r3 weak 1a / next #5c): GroupNorm moments layout, tf.image crop / pad corner cases -------------------------
+def test_sufficient_statistics_and_normalize_moments_against_torch(tf):
+    """`tf.nn.sufficient_statistics` / `tf.nn.normalize_moments` (what utils/model_utils.py:196-201 builds GroupNorm's one-pass
+    moments from): count, sum x, sum x^2 over the given axes; mean = sum / count, variance = sum x^2 / count - mean^2 (population
+    variance, TF's documented definition) -- against torch.mean / torch.var(unbiased=False) in float64."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 5, 7, 4, 6, generator=g) * 2.0 + 0.7
+    cnt, m_ss, v_ss, shift = tf.nn.sufficient_statistics(x, [1, 2, 4], keep_dims=True)
+    assert shift is None and float(cnt) == 5 * 7 * 6
+    mean, var = tf.nn.normalize_moments(cnt, m_ss, v_ss, shift=None)
+    xd = x.double()
+    assert tuple(mean.shape) == (3, 1, 1, 4, 1)
+    assert torch.allclose(mean.double(), xd.mean(dim=(1, 2, 4), keepdim=True), atol=1e-6)
+    assert torch.allclose(var.double(), xd.var(dim=(1, 2, 4), unbiased=False, keepdim=True), atol=2e-5)
+
+
+_GN_SCRIPT = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from oracle import tf_shim
+tf_shim.install()
+sys.path.insert(1, '/root/reference')
+from utils import model_utils as ref
+import tensorflow as tf
+out = {}
+for name, (n, h, w, c) in {'c64': (2, 6, 5, 64), 'c256': (1, 4, 4, 256)}.items():
+    g = torch.Generator().manual_seed(c)
+    x = torch.randn(n, h, w, c, generator=g) * 1.5 + 0.3
+    with tf.variable_scope('anchor_' + name):
+        y = ref.group_norm(tf.constant(x), epsilon=1e-4, name='t')
+    out[name + '_x'] = x.numpy(); out[name + '_y'] = np.asarray(y.detach() if hasattr(y, 'detach') else y)
+np.savez(sys.argv[2], **out)
+'''
+
+
+@pytest.mark.skipif(not __import__('os').path.isdir('/root/reference/utils'), reason="reference sources only exist in the build container")
+def test_reference_group_norm_under_the_shim_against_torch_group_norm(tmp_path):
+    """The reference's OWN `group_norm` (utils/model_utils.py:133-222: reshape [N,H,W,C] -> [N,H,W,32,C/32], moments over
+    H, W and the within-group channel axis, eps inside the rsqrt, gamma 1 / beta 0 at creation) executed under the shim, against
+    `torch.nn.functional.group_norm` on the NCHW view -- an implementation by somebody else with the same documented conventions
+    (contiguous channel groups, population variance).  This anchors the moments LAYOUT the ResNet-stem fixtures rest on."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / 'gn.npz')
+    r = subprocess.run([sys.executable, '-c', _GN_SCRIPT, root, out], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = np.load(out)
+    for name in ('c64', 'c256'):
+        x, y = torch.from_numpy(d[name + '_x']), torch.from_numpy(d[name + '_y'])
+        ref = F.group_norm(x.permute(0, 3, 1, 2).double(), 32, eps=1e-4).permute(0, 2, 3, 1)
+        assert float((y.double() - ref).abs().max()) < 1e-5, name
+
+
+def test_pad_to_bounding_box_and_slice_corner_cases(tf):
+    """`image[oy:oy+H, ox:ox+W]` + `tf.image.pad_to_bounding_box(image, 0, 0, H, W)` (utils/model_utils.py:923-924) on the corner
+    cases of resize_and_pad: the scaled frame smaller than the target in one or both dimensions (zeros appended BELOW / to the RIGHT
+    only, content anchored at the top-left), equal to it (unchanged), larger (cropped at the offset first; the slice clamps at the
+    border like a Python slice), a 1-pixel frame -- against explicit per-pixel loops over the documented contract."""
+    rng = np.random.RandomState(0)
+    for (h, w, H, W, oy, ox) in [(5, 7, 8, 9, 0, 0), (8, 9, 8, 9, 0, 0), (12, 7, 8, 9, 3, 0), (12, 15, 8, 9, 4, 6), (1, 1, 4, 4, 0, 0),
+                                 (9, 9, 8, 9, 1, 0), (8, 20, 8, 9, 0, 11)]:
+        img = rng.uniform(size=(h, w, 3)).astype(np.float32)
+        cropped = torch.from_numpy(img)[oy:oy + H, ox:ox + W, :]
+        got = np.asarray(tf.image.pad_to_bounding_box(cropped, 0, 0, H, W))
+        want = np.zeros((H, W, 3), np.float32)
+        for y in range(H):
+            for x in range(W):
+                if oy + y < h and ox + x < w:
+                    want[y, x] = img[oy + y, ox + x]
+        assert got.shape == (H, W, 3) and np.array_equal(got, want), (h, w, H, W, oy, ox)
+    # a non-zero offset places the content there (the documented contract; resize_and_pad only uses 0, 0)
+    img = rng.uniform(size=(2, 3, 3)).astype(np.float32)
+    got = np.asarray(tf.image.pad_to_bounding_box(torch.from_numpy(img), 1, 2, 5, 6))
+    want = np.zeros((5, 6, 3), np.float32)
+    want[1:3, 2:5] = img
+    assert np.array_equal(got, want)
