@@ -959,6 +959,7 @@ extern "C" int merlot_attention_fwd_fp8(const void* qkv, int64_t ld, void* out, 
 extern "C" int merlot_attention_bwd(const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout,
                                     int64_t lddo, const float* lse, const uint8_t* valid, const int32_t* seg, void* dqkv,
                                     int64_t lddqkv, float* delta, int B, int S, int heads, float scale,
+                                    float* log_lo, float* log_hi, int log_qsplit, float log_weight,
                                     merlot_stream_t stream) {
     int rc = check_attn(qkv, ld, B, S, heads);
     if (rc) return rc;
@@ -970,6 +971,10 @@ extern "C" int merlot_attention_bwd(const void* qkv, int64_t ld, const void* out
     MERLOT_CHECK(!seg || valid, MERLOT_ESHAPE, "attention: a segment mask needs the validity mask too");
     a.lse = (float*)lse; a.delta = delta; a.valid = valid; a.seg = seg; a.dqkv = (bf16*)dqkv; a.lddqkv = lddqkv;
     a.B = B; a.S = S; a.heads = heads; a.scale = scale;
+    // the attention LOG side output (valid pairs only), taken from the backward instead of the forward: in the fused kernel it is
+    // two lane accumulators of the dK / dV pass; on every other path the tiled column-sum kernel recomputes P (as the forward would)
+    const bool want_log = log_lo != nullptr || log_hi != nullptr;
+    a.colsum_lo = log_lo; a.colsum_hi = log_hi; a.qsplit = log_qsplit; a.valid_q_only = 1; a.weight = log_weight;
     hipStream_t s = (hipStream_t)stream;
     // S <= 512 without a segment mask (every pass of the 224^2 step): ONE launch, K | V and then Q | dO resident in LDS
     // (attention_fb.inc) -- 10 instead of 16 .. 24 [S, 64] tensors through the CU's memory pipe per (batch, head), same results
@@ -979,9 +984,11 @@ extern "C" int merlot_attention_bwd(const void* qkv, int64_t ld, const void* out
     if (const char* e = getenv("MERLOT_ATTN_FB")) fb_mode = fb_ok(a) ? atoi(e) : 0;
 #endif
     if (fb_mode) {
+        if (want_log && !fb_log_ok(a)) hipLaunchKernelGGL(attn_colsum_kernel, dim3(cdiv(S, 32), heads, B), dim3(64), 0, s, a);
         rc = fb_bwd(a, s);
         return rc ? rc : merlot_launch_status("merlot_attention_bwd");
     }
+    if (want_log) hipLaunchKernelGGL(attn_colsum_kernel, dim3(cdiv(S, 32), heads, B), dim3(64), 0, s, a);
     // everything else (longer sequences -- BASELINE config #5's S = 578 / 2832 --, segment masks, S <= 64, unaligned outputs):
     // the tiled pair, dQ (+ delta) then dK / dV, each recomputing S and dP.  (Round 3's persistent streaming dQ kernel sat between
     // the two; since the fused kernel took every sequence <= 512 it was reachable only for misaligned outputs and was retired.)

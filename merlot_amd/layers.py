@@ -66,6 +66,9 @@ class TransformerStackFn(torch.autograd.Function):
     opts: dict(heads, dropout_p, seed, fp8 (True: QKV / fc1 / fc2 forward GEMMs on e4m3 operands; 'ln': only the two fed by a
                LayerNorm, whose e4m3 copy costs no extra pass; 'all': True + the attention forward's two contractions), colsum (f32 [B,S] accumulated over layers, all query rows, weight 1/heads),
                log_lo / log_hi (f32 [B,S], valid pairs only, queries < / >= log_split), num_layers,
+               log_in_backward (True: when a backward will run, log_lo / log_hi are filled by the attention BACKWARD -- its dK / dV
+               pass forms P anyway -- instead of a second Q K^T walk in every forward launch; `log_done` (callable) is invoked once
+               the last layer's backward has been queued.  Metrics only: nothing in the forward reads them),
                seg (int32 [S]: the disable_pairwise_lang_attn block mask, model/modeling.py:160-168))
     """
 
@@ -82,6 +85,10 @@ class TransformerStackFn(torch.autograd.Function):
         fp8_fc2 = fp8 and opts.get('fp8') != 'ln'
         fp8_attn = opts.get('fp8') == 'all'              # + Q K^T and P V of the forward on the e4m3 MFMA
         need_bwd = ctx.needs_input_grad[0]
+        log_bwd = bool(opts.get('log_in_backward', False)) and need_bwd and log_lo is not None and not fp8_attn
+        ctx.log = (log_lo, log_hi, opts.get('log_split'), opts.get('log_done')) if log_bwd else None
+        if log_bwd:
+            log_lo = log_hi = None                        # the forward launches carry no log side output
         saved = []
         h = h.contiguous()
         for l in range(nl):
@@ -170,7 +177,11 @@ class TransformerStackFn(torch.autograd.Function):
             #   ones, so the rows of P no longer sum to exactly 1 and the shortcut does not hold: all three thirds are summed)
             exact_rows = not ctx.fp8_attn
             dctx = ops.gemm_nt(db1, w.proj.wbT, colsum_out=w.qkv.gb[2 * D:3 * D] if exact_rows else None)
-            dqkv = ops.attention_bwd(qkv, ctx_, dctx, lse, B, S, heads, valid, seg=ctx.seg)
+            if ctx.log is not None:
+                dqkv = ops.attention_bwd(qkv, ctx_, dctx, lse, B, S, heads, valid, seg=ctx.seg, log_lo=ctx.log[0], log_hi=ctx.log[1],
+                                         log_split=ctx.log[2], log_weight=1.0 / heads)
+            else:
+                dqkv = ops.attention_bwd(qkv, ctx_, dctx, lse, B, S, heads, valid, seg=ctx.seg)
             ops.colsum_bf16(dqkv[:, :D] if exact_rows else dqkv, w.qkv.gb[:D] if exact_rows else w.qkv.gb)
             ops.gemm_tn(dqkv, x1, w.qkv.gw)
             dx1 = ops.gemm_nt(dqkv, w.qkv.wbT)
@@ -182,6 +193,8 @@ class TransformerStackFn(torch.autograd.Function):
                 dh = ops.ln_bwd(dx1, h, mean1, rstd1, w.ln1.gamma, w.ln1.ggamma, w.ln1.gbeta, dres=dh_mid)
             store.notify_ready(w.name)
         store.notify_ready(stack.scope + '/LayerNorm_ln_final')
+        if ctx.log is not None and ctx.log[3] is not None:
+            ctx.log[3]()                                 # every layer's log sums are queued: the owner finalises its metrics
         ctx.saved = None
         ctx.final = None
         return dh, None, None, None, None, None

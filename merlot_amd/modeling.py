@@ -225,7 +225,19 @@ class MerlotModel(object):
         if log_attention_probs:
             log_lo = torch.zeros((self.B, Sj), device=dev, dtype=F32)
             log_hi = torch.zeros((self.B, Sj), device=dev, dtype=F32)
-            opts.update(log_lo=log_lo, log_hi=log_hi, log_split=self.P)
+            log_vals = torch.zeros(4, device=dev, dtype=F32)
+
+            def finish_log():                                                     # :186-203 from the fused block sums
+                tot = log_lo.sum() + log_hi.sum()
+                P_ = self.P
+                log_vals.copy_(torch.stack([log_hi[:, P_:].sum(), log_lo[:, P_:].sum(), log_hi[:, :P_].sum(), log_lo[:, :P_].sum()]) / tot)
+            # `attention_log_in_backward` (an extension key, default off): in a TRAINING step the block sums come out of the
+            # attention backward (its dK / dV pass forms P anyway) instead of a second Q K^T walk in each of the joint encoder's
+            # forward launches; `attention_log` then holds its values once `loss.backward()` has run (zeros before) -- the
+            # reference reads these metrics at the end of the train step too (model/modeling.py:709).  Without a backward
+            # (inference, forward-only timing) and by default they are complete right after construction.
+            opts.update(log_lo=log_lo, log_hi=log_hi, log_split=self.P, log_done=finish_log,
+                        log_in_backward=bool(cfg.get('attention_log_in_backward', False)) and is_training and torch.is_grad_enabled())
         enc = L.transformer_stack(encoder_input.reshape(self.B * Sj, H), self._enc, self.B, Sj,
                                   is_valid.to(torch.uint8).contiguous(), opts)
         enc3 = enc.view(self.B, Sj, H)
@@ -238,12 +250,11 @@ class MerlotModel(object):
             cur = p['end']
             self.encoder_hidden_states[p['name']] = enc3[:, p['start']:p['end']].float()     # :184
 
-        if log_attention_probs:                                                   # :186-203 from the fused block sums
-            tot = log_lo.sum() + log_hi.sum()
-            P_ = self.P
-            attns = {'viz2viz': log_lo[:, :P_].sum() / tot, 'lang2viz': log_lo[:, P_:].sum() / tot,
-                     'viz2lang': log_hi[:, :P_].sum() / tot, 'lang2lang': log_hi[:, P_:].sum() / tot}
-            self.attention_log = {f'encoder/{k}': v for k, v in sorted(attns.items())}
+        if log_attention_probs:
+            if not (opts['log_in_backward'] and encoder_input.requires_grad):
+                finish_log()
+            # sorted keys: lang2lang, lang2viz, viz2lang, viz2viz  (queries -> keys: log_lo = viz queries, log_hi = lang queries)
+            self.attention_log = {f'encoder/{k}': log_vals[i] for i, k in enumerate(('lang2lang', 'lang2viz', 'viz2lang', 'viz2viz'))}
 
     # ------------------------------------------------------------------------------------------------
     # index helpers (host side, cached per shape)

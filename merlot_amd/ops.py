@@ -277,12 +277,15 @@ def attention_fwd_fp8(qkv, B, S, heads, valid=None, scale=None, seg=None, amax3=
     return out, lse
 
 
-def attention_bwd(qkv, out, dout, lse, B, S, heads, valid=None, seg=None):
-    _chk(dout, BF16, 'dout'); _chk(seg, torch.int32, 'seg')
+def attention_bwd(qkv, out, dout, lse, B, S, heads, valid=None, seg=None, log_lo=None, log_hi=None, log_split=None, log_weight=1.0):
+    """log_lo / log_hi (f32 [B, S], accumulated): the attention LOG side output (valid pairs only, queries below / from log_split),
+    taken from the backward's own P instead of a second Q K^T walk in the forward (merlot_hip.h, merlot_attention_bwd)."""
+    _chk(dout, BF16, 'dout'); _chk(seg, torch.int32, 'seg'); _chk(log_lo, F32, 'log_lo'); _chk(log_hi, F32, 'log_hi')
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, heads, S), device=qkv.device, dtype=F32)
     call('merlot_attention_bwd', _p(qkv), qkv.stride(0), _p(out), out.stride(0), _p(dout), dout.stride(0), _p(lse),
-         _p(valid), _p(seg), _p(dqkv), dqkv.stride(0), _p(delta), B, S, heads, 0.125, _stream())
+         _p(valid), _p(seg), _p(dqkv), dqkv.stride(0), _p(delta), B, S, heads, 0.125, _p(log_lo), _p(log_hi),
+         S if log_split is None else int(log_split), float(log_weight), _stream())
     return dqkv
 
 

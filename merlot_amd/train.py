@@ -48,6 +48,10 @@ class Trainer(object):
         self.store = ParamStore(config.model, self.device, seed=seed)
         world = dist_ctx.world_size if dist_ctx is not None else 1
         self.opt = build_optimizer_from_config(self.store, config.optimizer, world_size=world, grad_reduce=grad_reduce)
+        # a training step always runs the backward: let the attention LOG metrics (model/modeling.py:186-203, :709) come out of the
+        # attention backward instead of a second Q K^T walk in every joint-encoder forward launch (they are read at the END of the
+        # step, as in the reference's train op); `attention_log_in_backward: False` in the YAML restores forward-time values
+        config.model.setdefault('attention_log_in_backward', True)
         self.model_fn = model_fn_builder(config)
         self.reducer = None
         from .parallel import FORCE

@@ -44,7 +44,7 @@ for B, S, heads, masked, pads in ((3, 198, 12, False, (64, 8, 16, 8)), (2, 130, 
         dqkv = torch.full((B * S, lddq), float('nan'), device='cuda', dtype=torch.bfloat16)
         delta = torch.full((B, heads, S), float('nan'), device='cuda')
         call('merlot_attention_bwd', qkv_full.data_ptr(), ld, o_full.data_ptr(), ldo, do_full.data_ptr(), lddo, lse.data_ptr(), vp, None,
-             dqkv.data_ptr(), lddq, delta.data_ptr(), B, S, heads, 0.125, ops._stream())
+             dqkv.data_ptr(), lddq, delta.data_ptr(), B, S, heads, 0.125, None, None, S, 1.0, ops._stream())
         res_b[k] = (dqkv, delta)
     torch.cuda.synchronize()
     same = torch.equal(res_b['0'][0][:, :3 * D].view(torch.int16), res_b['1'][0][:, :3 * D].view(torch.int16))

@@ -144,7 +144,10 @@ def attention_fwd(qkv, B, S, heads, valid=None, need_lse=True, seg=None, colsum_
     return o.to(BF16), (lse if need_lse else None)
 
 
-def attention_bwd(qkv, out, dout, lse, B, S, heads, valid=None, seg=None):
+def attention_bwd(qkv, out, dout, lse, B, S, heads, valid=None, seg=None, log_lo=None, log_hi=None, log_split=None, log_weight=1.0):
+    if log_lo is not None or log_hi is not None:            # the attention LOG taken from the backward (valid pairs only)
+        attention_colsum(qkv, lse, B, S, heads, log_lo, log_hi, qsplit=log_split, valid=valid, valid_q_only=True,
+                         weight=log_weight, seg=seg)
     qkv_f = qkv.float().detach().requires_grad_(True)
     with torch.enable_grad():
         q, k, v, s = _attn_probs(qkv_f, B, S, heads, valid, seg)

@@ -397,3 +397,39 @@ def test_token_id_range_assertion_is_deferred_not_dropped(emu, oracle_run):
     with pytest.raises(ValueError, match='training step 0'):
         tr.step(feats)                                    # raised by the step itself, BEFORE its update is applied
     assert torch.equal(tr.store.master, before) and tr.step_idx == 0
+
+
+def test_attention_log_taken_from_the_backward_equals_the_forward_values(emu, oracle_run):
+    """`attention_log_in_backward` (merlot_amd/modeling.py; the Trainer's default): the four viz / lang block fractions of
+    model/modeling.py:186-203 are zeros until `backward()` has run and equal the forward-time values afterwards; without a backward
+    (no_grad) they are complete at construction."""
+    from merlot_amd import MerlotModel, ParamStore
+    cfg, w, b, m, loss, info = oracle_run
+    outs = {}
+    for mode in (False, True):
+        c = dict(cfg, attention_log_in_backward=mode)
+        st = ParamStore(c, 'cpu', seed=0)
+        st.load_tf_weights({k: v.detach() for k, v in w.items()})
+        pm = MerlotModel(c, True, False, b['image'], b['input_ids'], mask_input=True,
+                         shuffled_idx_img=torch.from_numpy(b['shuffled_idx_img']), params=st,
+                         noise={k: torch.from_numpy(v) for k, v in b['noise'].items()})
+        before = {k: float(v) for k, v in pm.attention_log.items()}
+        l1, _ = pm.mask_loss()
+        st.zero_grad()
+        l1.backward()
+        outs[mode] = (before, {k: float(v) for k, v in pm.attention_log.items()})
+    assert all(v == 0.0 for v in outs[True][0].values())                 # deferred: nothing before the backward
+    assert outs[False][0] == outs[False][1]                               # immediate: untouched by the backward
+    for k, v in outs[False][1].items():
+        assert abs(outs[True][1][k] - v) < 1e-6, k
+        assert abs(v - float(m.attention_log[k])) < 1e-3
+    assert abs(sum(outs[True][1].values()) - 1.0) < 1e-5
+    with torch.no_grad():                                                 # no backward will come: complete at construction
+        c = dict(cfg, attention_log_in_backward=True)
+        st = ParamStore(c, 'cpu', seed=0)
+        st.load_tf_weights({k: v.detach() for k, v in w.items()})
+        pm = MerlotModel(c, True, False, b['image'], b['input_ids'], mask_input=True,
+                         shuffled_idx_img=torch.from_numpy(b['shuffled_idx_img']), params=st,
+                         noise={k: torch.from_numpy(v) for k, v in b['noise'].items()})
+        for k, v in outs[False][1].items():
+            assert abs(float(pm.attention_log[k]) - v) < 1e-6

@@ -269,7 +269,7 @@ def test_attention_bwd_fused_short_unmasked(ops, B, S, heads):
     dqkv = torch.full_like(qkv, float('nan'))
     delta = torch.full((B, heads, S), float('nan'), device='cuda')
     call('merlot_attention_bwd', qkv.data_ptr(), qkv.stride(0), o.data_ptr(), o.stride(0), do.data_ptr(), do.stride(0), lse.data_ptr(),
-         None, None, dqkv.data_ptr(), dqkv.stride(0), delta.data_ptr(), B, S, heads, 0.125, torch.cuda.current_stream().cuda_stream)
+         None, None, dqkv.data_ptr(), dqkv.stride(0), delta.data_ptr(), B, S, heads, 0.125, None, None, S, 1.0, torch.cuda.current_stream().cuda_stream)
     assert not bool(torch.isnan(dqkv.float()).any())
     want = (do.float() * o.float()).view(B, S, heads, 64).sum(-1).permute(0, 2, 1)
     assert float((delta - want).abs().max()) < 1e-3 * (1 + float(want.abs().max()))
@@ -306,7 +306,7 @@ def test_attention_nondefault_leading_dims(ops, B, S, heads, pad, pads):
     dqkv = torch.full((B * S, lddq), float('nan'), device='cuda', dtype=BF16)
     delta = torch.empty((B, heads, S), device='cuda')
     call('merlot_attention_bwd', qkv_full.data_ptr(), ld, o_full.data_ptr(), ldo, do_full.data_ptr(), lddo, lse.data_ptr(),
-         vp.data_ptr() if pad else None, None, dqkv.data_ptr(), lddq, delta.data_ptr(), B, S, heads, 0.125, stream)
+         vp.data_ptr() if pad else None, None, dqkv.data_ptr(), lddq, delta.data_ptr(), B, S, heads, 0.125, None, None, S, 1.0, stream)
     dq_ref = E.attention_bwd(qkv, o_ref, do, lse_ref, B, S, heads, valid).float()
     got = dqkv[:, :3 * D].float().cpu()
     for name, sl in [('dq', slice(0, D)), ('dk', slice(D, 2 * D)), ('dv', slice(2 * D, 3 * D))]:
@@ -365,6 +365,38 @@ def test_attention_fwd_fused_colsum(ops, B, S, pad, vq):
     ops.attention_fwd(qkv.cuda(), B, S, heads, vc, colsum_lo=lo1, valid_q_only=False, weight=1 / heads)
     assert rel_l2(lo1, lo1_r) < 5e-3
     assert abs(float(lo1.sum()) - B * S) < 1e-2 * B * S                    # probabilities: every query row sums to 1
+
+
+@pytest.mark.parametrize("B,S,pad,split", [(3, 328, True, 200), (2, 410, True, 250), (2, 200, True, 96), (2, 148, True, 0), (2, 328, True, 328),
+                                           (3, 198, False, 100), (1, 578, True, 300), (2, 50, True, 20)])
+def test_attention_log_from_the_backward(ops, B, S, pad, split):
+    """the attention LOG side output (valid pairs only, queries below / from `split`) taken from the BACKWARD launch (round 4):
+    S <= 512 masked = two lane accumulators of the fused kernel's dK / dV pass (chunks below, above and straddling the split: 250
+    and 100 are not multiples of 32, 0 and S put everything on one side), unmasked / long / short sequences = the tiled column-sum
+    kernel launched by the entry -- equal to the stand-alone op, accumulated in place, and the gradients are the plain call's bit
+    for bit."""
+    heads = 12
+    qkv, valid, g = _attn_inputs(B, S, heads, 500 + S, pad)
+    vc = None if valid is None else valid.cuda()
+    o, lse = ops.attention_fwd(qkv.cuda(), B, S, heads, vc)
+    do = rnd((B * S, heads * 64), g).cuda()
+    lo_r, hi_r = torch.full((B, S), 0.25).cuda(), torch.full((B, S), -0.5).cuda()
+    ops.attention_colsum(qkv.cuda(), lse, B, S, heads, lo_r, hi_r, qsplit=split, valid=vc, valid_q_only=True, weight=1 / heads)
+    lo, hi = torch.full((B, S), 0.25).cuda(), torch.full((B, S), -0.5).cuda()
+    d1 = ops.attention_bwd(qkv.cuda(), o, do, lse, B, S, heads, vc, log_lo=lo, log_hi=hi, log_split=split, log_weight=1 / heads)
+    d0 = ops.attention_bwd(qkv.cuda(), o, do, lse, B, S, heads, vc)
+    assert torch.equal(d0, d1)
+    assert float((lo - lo_r).abs().max()) < 2e-5 * max(1.0, float(lo_r.abs().max())) and float((hi - hi_r).abs().max()) < 2e-5 * max(1.0, float(hi_r.abs().max()))
+    # against the emulation's definition, and the bookkeeping: every VALID query row's probabilities over valid keys sum to 1
+    lo_e, hi_e = torch.full((B, S), 0.25), torch.full((B, S), -0.5)
+    E.attention_colsum(qkv, lse.cpu(), B, S, heads, lo_e, hi_e, qsplit=split, valid=valid, valid_q_only=True, weight=1 / heads)
+    assert rel_l2(lo + hi, lo_e + hi_e) < 5e-3
+    nvalid = B * S if valid is None else int(valid.sum())
+    assert abs(float((lo - 0.25).sum() + (hi + 0.5).sum()) - nvalid) < 1e-2 * nvalid
+    # only one of the two requested
+    lo2 = torch.zeros(B, S).cuda()
+    ops.attention_bwd(qkv.cuda(), o, do, lse, B, S, heads, vc, log_lo=lo2, log_split=split, log_weight=1 / heads)
+    assert float((lo2 - (lo_r - 0.25)).abs().max()) < 2e-5 * max(1.0, float(lo_r.abs().max()))
 
 
 @pytest.mark.parametrize("B,S,P,Lc", [(2, 328, 200, 32), (2, 148, 20, 32), (1, 130, 2, 16)])

@@ -219,3 +219,31 @@ def test_adamw_matches_reference_update_rule():
         assert np.allclose(p.cpu().numpy(), pr, rtol=1e-5, atol=1e-7)
         assert np.allclose(m.float().cpu().numpy(), mr, rtol=1e-5, atol=1e-9)
         assert np.allclose(v.float().cpu().numpy(), vr, rtol=1e-5, atol=1e-12)
+
+
+def test_attention_log_from_the_backward_matches_the_forward_values_on_the_hip_path():
+    """`attention_log_in_backward` on the real kernels (config #1 geometry: joint S = 148, the fused backward's masked R = 256
+    instantiation): zeros before `backward()`, the forward-time fractions afterwards; every other output of the step is untouched."""
+    from merlot_amd import MerlotModel, ParamStore
+    cfg = tiny_config()
+    b = synth_batch(cfg)
+    w = mo.init_weights(cfg, 0)
+    res = {}
+    for mode in (False, True):
+        c = dict(cfg, attention_log_in_backward=mode)
+        st = ParamStore(c, 'cuda', seed=0)
+        st.load_tf_weights(w)
+        pm = MerlotModel(c, True, False, b['image'].cuda(), b['input_ids'].cuda(), mask_input=True,
+                         shuffled_idx_img=torch.from_numpy(b['shuffled_idx_img']).cuda(), params=st,
+                         noise={k: torch.from_numpy(v) for k, v in b['noise'].items()})
+        before = {k: float(v) for k, v in pm.attention_log.items()}
+        loss = pm.mask_loss()[0] + pm.contrastive_loss()[0]
+        st.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+        res[mode] = (before, {k: float(v) for k, v in pm.attention_log.items()}, float(loss), st.grad.clone())
+    assert all(v == 0.0 for v in res[True][0].values()) and res[False][0] == res[False][1]
+    for k, v in res[False][1].items():
+        assert abs(res[True][1][k] - v) < 2e-5, k
+    assert res[True][2] == res[False][2]
+    assert float((res[True][3] - res[False][3]).abs().max()) <= 1e-5 * float(res[False][3].abs().max())
