@@ -61,7 +61,7 @@ enum merlot_epilogue {
  * zero again, so one block serves every launch of a stream and needs zeroing once, at allocation).  The library itself
  * keeps no device or host state: launches on different streams are independent as long as each stream uses its own
  * block.  workspace == NULL is accepted only for shapes merlot_gemm_bf16_nt_plan() maps to a non-claiming kernel
- * (plans other than 21 / 22); otherwise MERLOT_ESHAPE.
+ * (plans other than 22); otherwise MERLOT_ESHAPE.  An A operand of 4 GiB or more is cut into row ranges of that kernel internally.
  * colsum_out (optional, f32 [N], ACCUMULATED; bf16 output only): column sums of the stored C -- the bias gradient of the
  * layer whose output gradient this launch produces (utils/transformer.py:149-153) -- fused into the epilogue of the
  * persistent kernel, otherwise computed by merlot_colsum_bf16 right behind the GEMM. */
@@ -77,8 +77,7 @@ int64_t merlot_gemm_nt_workspace_bytes(void);
 #define MERLOT_NT_KERNEL_RING_128x256 11    /* gemm_nt_ring_kernel<Cfg<2,4,2,2,32,3>>: 2 workgroups / CU            */
 #define MERLOT_NT_KERNEL_RING_256x64 14     /* gemm_nt_ring_kernel<Cfg<4,1,2,2,32,3>>: narrow outputs               */
 #define MERLOT_NT_KERNEL_RING_256x128 15    /* gemm_nt_ring_kernel<Cfg<4,1,2,4,32,3>>                               */
-#define MERLOT_NT_KERNEL_PERSIST_STATIC 20  /* gemm_nt_persist_kernel: persistent 256x256, static tile striding      */
-#define MERLOT_NT_KERNEL_PERSIST_DYN 21     /* gemm_nt_persist_dyn_kernel: persistent 256x256, dynamic tile claims   */
+/* (20, 21: the lock-step persistent kernels of rounds 1-3, retired in ABI v5) */
 #define MERLOT_NT_KERNEL_P8 22              /* gemm_nt_p8_kernel: persistent 256x256, BK 64, two wave groups in ping-pong */
 int merlot_gemm_bf16_nt_plan(int64_t M, int64_t N, int64_t K);
 

@@ -2,10 +2,12 @@
 // See DESIGN.md 3.1 for the measurements behind every choice.
 //
 // Kernels in this file
-//   gemm_nt_persist_dyn_kernel   production NT for large problems: persistent 256x256 tiles, 8 waves, BK 32, one
-//                                continuous 3-stage LDS-DMA ring across tiles, dynamic per-XCD tile claims, interior
+//   gemm_nt_p8_kernel (gemm_p8.inc) production NT for large problems: persistent 256x256 tiles, 8 waves in two ping-pong groups,
+//                                BK 64, one continuous LDS-DMA stream across tiles, dynamic per-XCD tile claims, interior
 //                                tiles through fast_tile_epilogue (bias once per tile, prefetched auxiliary operand).
-//   gemm_nt_persist_kernel       same with static tile striding (K < 128, and the A/B reference for the claims).
+//                                (Rounds 1-3 also kept the lock-step persistent kernels it replaced -- static striding for K < 128,
+//                                64-bit addressing for operands of 4 GiB and more; retired in round 4: K = 64 runs the 128x256
+//                                ring kernel, larger operands are cut into row ranges of the same kernel.)
 //   gemm_nt_ring_kernel<Cfg>     non-persistent ring kernel: 128x256 (ragged tile counts, 2 WG/CU), 256x64 and
 //                                256x128 (narrow outputs), 256x256 (experiments).
 //   gemm_tn_ring_kernel<Cfg>     wgrad: operands as stored ([R][M], [R][N]) through ds_read_b64_tr_b16, split-R
@@ -58,6 +60,8 @@ struct GemmNTArgs {
     int cg;               // persistent kernel: tiles are enumerated in groups of `cg` tile columns (0: plain row-major)
     int dephase;          // experiments only: workgroup i of an XCD starts ((i * 5) & 7) * dephase shader cycles late (0: off)
     int dbg;              // experiments only: 1 = skip epilogue, 2 = skip main loop
+    int64_t m_off;        // rows of C in front of this launch when a GEMM is cut into row ranges: the dropout mask is a function of the
+                          // element's GLOBAL index (m_off + m) * N + n
 };
 
 struct GemmTNArgs {
@@ -144,7 +148,7 @@ __device__ __forceinline__ void nt_epilogue_quad(const GemmNTArgs& p, int m, int
             if (p.drop_thresh) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const uint64_t idx = (uint64_t)m * (uint64_t)p.N + (uint64_t)(n + e);
+                    const uint64_t idx = (uint64_t)(m + p.m_off) * (uint64_t)p.N + (uint64_t)(n + e);
                     v[e] = dropout_keep(p.drop_seed, idx, p.drop_thresh) ? v[e] * p.drop_scale : 0.f;
                 }
             }
@@ -435,7 +439,7 @@ __device__ __forceinline__ void epilogue_row8(const GemmNTArgs& p, int m, int n,
     } else if (EPI == MERLOT_EPI_RESIDUAL) {
         if (p.drop_thresh) {
             bool keep[8];
-            const uint64_t idx0 = (uint64_t)m * (uint64_t)p.N + (uint64_t)n;      // n % 8 == 0 on this path
+            const uint64_t idx0 = (uint64_t)(m + p.m_off) * (uint64_t)p.N + (uint64_t)n;      // n % 8 == 0 on this path
             if (!(p.N & 1)) {
                 dropout_keep_n<8>(p.drop_seed, idx0, p.drop_thresh, keep);
             } else {
@@ -584,7 +588,7 @@ __device__ __forceinline__ void staged_epilogue(const GemmNTArgs& p, f32x16 (&ac
                 } else if (EPI == MERLOT_EPI_RESIDUAL) {
                     if (p.drop_thresh) {
                         bool keep[8];
-                        dropout_keep_n<8>(p.drop_seed, (uint64_t)m * (uint64_t)p.N + (uint64_t)n, p.drop_thresh, keep);
+                        dropout_keep_n<8>(p.drop_seed, (uint64_t)(m + p.m_off) * (uint64_t)p.N + (uint64_t)n, p.drop_thresh, keep);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = keep[e] ? v[e] * p.drop_scale : 0.f;
                     }
@@ -907,7 +911,7 @@ __device__ __forceinline__ void fast_tile_epilogue(const GemmNTArgs& p, f32x16 (
             } else if (EPI == MERLOT_EPI_RESIDUAL) {
                 if (p.drop_thresh && !no_math) {
                     bool keep[8];                        // interior tiles: N % 256 == 0, the index is even
-                    dropout_keep_n<8>(p.drop_seed, (uint64_t)m * (uint64_t)p.N + (uint64_t)n, p.drop_thresh, keep);
+                    dropout_keep_n<8>(p.drop_seed, (uint64_t)(m + p.m_off) * (uint64_t)p.N + (uint64_t)n, p.drop_thresh, keep);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = keep[e] ? v[e] * p.drop_scale : 0.f;
                 }
@@ -951,136 +955,7 @@ __device__ __forceinline__ void fast_tile_epilogue(const GemmNTArgs& p, f32x16 (
     }
 }
 
-using RingP = ring::Cfg<4, 2, 2, 4, 32, 3>;          // 256x256, BK 32, 3 stages (96 KB) + 64 KB epilogue staging
-constexpr int PERSIST_LDS = RingP::RING_BYTES + 8 * 8192;
-
-template <int EPI, bool OUT_F32>
-__global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const GemmNTArgs p) {
-    using C = RingP;
-    extern __shared__ __attribute__((aligned(1024))) char dsm[];
-    constexpr int BK = C::BK, S = C::STAGES;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ntiles = p.ntm * p.ntn;
-    const int nk = p.K / BK;
-    // tile order: round j hands 32 consecutive tiles to each XCD (block b sits on XCD b % 8)
-    const int slot = xcd_remap(blockIdx.x, gridDim.x);
-    const int my_tiles = slot < ntiles ? (ntiles - slot + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-    const int total_steps = my_tiles * nk;
-
-    constexpr int CH = BK / 8;
-    const int prow = lane / CH, pch = lane % CH;
-    int a_rowoff[C::A_PIECES], b_rowoff[C::B_PIECES], a_chunk[C::A_PIECES], b_chunk[C::B_PIECES];
-#pragma unroll
-    for (int i = 0; i < C::A_PIECES; ++i) {
-        a_rowoff[i] = (wave * C::A_PIECES + i) * C::RP + prow;
-        a_chunk[i] = ((pch ^ (a_rowoff[i] >> 2)) & 3) * 8;
-    }
-#pragma unroll
-    for (int i = 0; i < C::B_PIECES; ++i) {
-        b_rowoff[i] = (wave * C::B_PIECES + i) * C::RP + prow;
-        b_chunk[i] = ((pch ^ (b_rowoff[i] >> 2)) & 3) * 8;
-    }
-    // load stream state
-    const bf16* a_src[C::A_PIECES];
-    const bf16* b_src[C::B_PIECES];
-    int ld_tile = slot, ld_kt = 0, ld_step = 0;
-    auto set_tile = [&](int tile) {
-        const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
-#pragma unroll
-        for (int i = 0; i < C::A_PIECES; ++i)
-            a_src[i] = p.A + (int64_t)min(tm * C::BM + a_rowoff[i], p.M - 1) * p.lda + a_chunk[i];
-#pragma unroll
-        for (int i = 0; i < C::B_PIECES; ++i)
-            b_src[i] = p.B + (int64_t)min(tn * C::BN + b_rowoff[i], p.N - 1) * p.ldb + b_chunk[i];
-    };
-    auto stage_next = [&]() {
-        if (ld_step >= total_steps) return;
-        char* la = dsm + (ld_step % S) * C::STAGE_BYTES + wave * C::A_PIECES * 1024;
-        char* lb = dsm + (ld_step % S) * C::STAGE_BYTES + C::A_BYTES + wave * C::B_PIECES * 1024;
-        const int k0 = ld_kt * BK;
-#pragma unroll
-        for (int i = 0; i < C::A_PIECES; ++i)
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(a_src[i] + k0), LDS_PTR(la + i * 1024), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < C::B_PIECES; ++i)
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(b_src[i] + k0), LDS_PTR(lb + i * 1024), 16, 0, 0);
-        ++ld_step;
-        if (++ld_kt == nk) {
-            ld_kt = 0;
-            ld_tile += gridDim.x;
-            if (ld_tile < ntiles) set_tile(ld_tile);
-        }
-    };
-
-    const int wm = wave / C::WN, wn = wave % C::WN;
-    const int hi = lane >> 5;
-    int a_row[C::FM], b_row[C::FN];
-#pragma unroll
-    for (int f = 0; f < C::FM; ++f) a_row[f] = (wm * C::FM + f) * 32 + (lane & 31);
-#pragma unroll
-    for (int f = 0; f < C::FN; ++f) b_row[f] = (wn * C::FN + f) * 32 + (lane & 31);
-    char* slab = dsm + C::RING_BYTES + wave * 8192;
-
-    if (my_tiles > 0) set_tile(slot);
-#pragma unroll
-    for (int t = 0; t < S - 1; ++t) stage_next();
-
-    int g = 0;
-    for (int tile = slot; tile < ntiles; tile += gridDim.x) {
-        f32x16 acc[C::FM][C::FN];
-#pragma unroll
-        for (int i = 0; i < C::FM; ++i)
-#pragma unroll
-            for (int j = 0; j < C::FN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        for (int kt = 0; kt < nk; ++kt, ++g) {
-            if (g + S - 1 <= total_steps)
-                ring::wait_vmcnt<(S - 2) * C::LOADS>();
-            else
-                ring::wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            stage_next();
-            const char* la = dsm + (g % S) * C::STAGE_BYTES;
-            const char* lb = la + C::A_BYTES;
-#pragma unroll
-            for (int kk = 0; kk < BK / 16; ++kk) {
-                bf16x8 af[C::FM], bfr[C::FN];
-#pragma unroll
-                for (int f = 0; f < C::FM; ++f) af[f] = *reinterpret_cast<const bf16x8*>(la + ring::kc_off<BK>(a_row[f], 2 * kk + hi));
-#pragma unroll
-                for (int f = 0; f < C::FN; ++f) bfr[f] = *reinterpret_cast<const bf16x8*>(lb + ring::kc_off<BK>(b_row[f], 2 * kk + hi));
-#pragma unroll
-                for (int fi = 0; fi < C::FM; ++fi)
-#pragma unroll
-                    for (int fj = 0; fj < C::FN; ++fj)
-                        acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[fj], af[fi], acc[fi][fj], 0, 0, 0);
-            }
-        }
-        if (DBG_BIT(p, 1) && acc[0][0][0] != 12345.678f) continue;
-        const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
-        const int m_base = tm * C::BM + wm * C::FM * 32, n_base = tn * C::BN + wn * C::FN * 32;
-#pragma unroll
-        for (int fi = 0; fi < C::FM; ++fi)
-#pragma unroll
-            for (int fp = 0; fp < C::FN / 2; ++fp)
-                slab_epilogue<EPI, OUT_F32>(p, acc[fi][2 * fp], acc[fi][2 * fp + 1], slab, m_base + fi * 32, n_base + fp * 64, lane);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Persistent NT kernel with DYNAMIC tile claims (production).  Same schedule as gemm_nt_persist_kernel while every
-// workgroup progresses evenly: XCD x hands out ITS band of tiles (round j, position i -> tile j*nwg + band_x + i) in
-// order, so co-resident workgroups still share B panels in their XCD's L2.  The difference: the k-th tile of a band
-// goes to whichever workgroup of that XCD asks k-th (one agent-scope atomic per tile, issued a whole tile ahead of
-// its use), not to a fixed owner.  A workgroup that starts late or runs slowly -- its CU is shared with an RCCL
-// all-reduce kernel of the overlapped gradient reduction, which also keeps a 160 KiB-LDS workgroup from becoming
-// resident there at all -- then simply takes fewer tiles instead of stretching the whole launch by a full tile round.
-// Counters live in a small pool of self-resetting slots (the last workgroup to leave zeroes its slot).
-// ------------------------------------------------------------------------------------------------
-// Tile enumeration of the dynamic persistent kernel.  Row-major order makes a 32-tile XCD band 2-3 tile rows x ALL tile
+// Tile enumeration of the persistent ping-pong kernel (gemm_p8.inc).  Row-major order makes a 32-tile XCD band 2-3 tile rows x ALL tile
 // columns: with 12 columns the weight panel (12 x 393 KB at K = 768) exceeds the XCD's 4 MB L2 and is re-fetched through
 // the fabric in every round of tiles.  Grouped order walks the grid column group by column group (cg columns wide, all
 // rows inside a group, row-major within it): a band is ~32/cg rows x cg columns, successive bands of an XCD stay in the
@@ -1107,185 +982,9 @@ __device__ long long g_persist_trace[256 * TRACE_TILES * 8];
 #else
 #define PERSIST_TRACE(i, j, v) ((void)0)
 #endif
-// Tile-claim counters of the two dynamic persistent kernels live in CALLER-owned workspace (GemmNTArgs::ctr): the library
+// Tile-claim counters of the persistent ping-pong kernel live in CALLER-owned workspace (GemmNTArgs::ctr): the library
 // holds no device or host state, so launches on different streams are independent as long as each uses its own block.
 constexpr int64_t NT_WORKSPACE_BYTES = 64;
-
-template <int EPI, bool OUT_F32>
-__global__ __launch_bounds__(512) void gemm_nt_persist_dyn_kernel(const GemmNTArgs p) {
-    using C = RingP;
-    extern __shared__ __attribute__((aligned(1024))) char dsm[];
-    constexpr int BK = C::BK, S = C::STAGES;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ntiles = p.ntm * p.ntn;
-    const int nk = p.K / BK;
-    const int nwg = gridDim.x;
-    const int xcd = blockIdx.x & 7;
-    const int n_x = (nwg >> 3) + (xcd < (nwg & 7) ? 1 : 0);          // workgroups in this XCD's band
-    const int slot = xcd_remap(blockIdx.x, nwg);
-    const int band0 = slot - ((int)blockIdx.x >> 3);                  // first tile of the band in round 0
-    unsigned int* ctr = p.ctr;
-    // an LDS-address-space pointer: through a generic `volatile int*` the read compiled to flat_load + s_waitcnt vmcnt(0), which
-    // drains the whole LDS-DMA stream once per tile (profiles/r03_m_p8_ktile.txt)
-    volatile lds_int_t* bcast = (volatile lds_int_t*)LDS_PTR(dsm + C::RING_BYTES);   // wave 0's idle epilogue slab
-    const bool fast_ok = !DBG_BIT(p, 32) && !(p.N & 1) && ((p.ldc & 7) == 0) && ((p.ld_aux_in & 7) == 0) && ((p.ld_aux_out & 7) == 0) &&
-                         ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) && ((reinterpret_cast<uintptr_t>(p.aux_in) & 15) == 0) &&
-                         ((reinterpret_cast<uintptr_t>(p.aux_out) & 15) == 0) && ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0) &&
-                         !(OUT_F32 && p.accumulate) && !(EPI == MERLOT_EPI_GELU && !p.aux_out && false);
-
-    constexpr int CH = BK / 8;
-    const int prow = lane / CH, pch = lane % CH;
-    int a_rowoff[C::A_PIECES], b_rowoff[C::B_PIECES], a_chunk[C::A_PIECES], b_chunk[C::B_PIECES];
-#pragma unroll
-    for (int i = 0; i < C::A_PIECES; ++i) {
-        a_rowoff[i] = (wave * C::A_PIECES + i) * C::RP + prow;
-        a_chunk[i] = ((pch ^ (a_rowoff[i] >> 2)) & 3) * 8;
-    }
-#pragma unroll
-    for (int i = 0; i < C::B_PIECES; ++i) {
-        b_rowoff[i] = (wave * C::B_PIECES + i) * C::RP + prow;
-        b_chunk[i] = ((pch ^ (b_rowoff[i] >> 2)) & 3) * 8;
-    }
-    const bf16* a_src[C::A_PIECES];
-    const bf16* b_src[C::B_PIECES];
-    auto set_tile = [&](int tile) {
-        int tm, tn;
-        tile_coords(p, tile, tm, tn);
-#pragma unroll
-        for (int i = 0; i < C::A_PIECES; ++i)
-            a_src[i] = p.A + (int64_t)min(tm * C::BM + a_rowoff[i], p.M - 1) * p.lda + a_chunk[i];
-#pragma unroll
-        for (int i = 0; i < C::B_PIECES; ++i)
-            b_src[i] = p.B + (int64_t)min(tn * C::BN + b_rowoff[i], p.N - 1) * p.ldb + b_chunk[i];
-    };
-    // load stream: ld_step stages issued so far; it follows the claimed tiles one after the other
-    int ld_kt = 0, ld_step = 0, next_tile = ntiles;
-    bool stream_end = false;
-    auto stage_next = [&]() {
-        if (stream_end) return;
-        char* la = dsm + (ld_step % S) * C::STAGE_BYTES + wave * C::A_PIECES * 1024;
-        char* lb = dsm + (ld_step % S) * C::STAGE_BYTES + C::A_BYTES + wave * C::B_PIECES * 1024;
-        const int k0 = ld_kt * BK;
-#pragma unroll
-        for (int i = 0; i < C::A_PIECES; ++i)
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(a_src[i] + k0), LDS_PTR(la + i * 1024), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < C::B_PIECES; ++i)
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(b_src[i] + k0), LDS_PTR(lb + i * 1024), 16, 0, 0);
-        ++ld_step;
-        if (++ld_kt == nk) {                             // the stream moves on to the tile claimed at kt == 0
-            ld_kt = 0;
-            next_tile = __builtin_amdgcn_readfirstlane(*bcast);
-            if (next_tile < ntiles) set_tile(next_tile);
-            else stream_end = true;
-        }
-    };
-
-    const int wm = wave / C::WN, wn = wave % C::WN;
-    const int hi = lane >> 5;
-    int a_row[C::FM], b_row[C::FN];
-#pragma unroll
-    for (int f = 0; f < C::FM; ++f) a_row[f] = (wm * C::FM + f) * 32 + (lane & 31);
-#pragma unroll
-    for (int f = 0; f < C::FN; ++f) b_row[f] = (wn * C::FN + f) * 32 + (lane & 31);
-    char* slab = dsm + C::RING_BYTES + wave * 8192;
-
-    // thread 0 claims one tile AHEAD of the load stream: tile i+1 is claimed before tile i starts (here for i = 0,
-    // then at the top of tile i-1's epilogue), published through LDS after wave 0's slab is idle again, and read by
-    // every wave when the stream wraps from tile i to tile i+1 (at least one s_barrier later).
-    auto claim = [&]() -> int {
-        const unsigned int sq = (unsigned int)n_x + atomicAdd(ctr + xcd, 1u);          // position in the band's order
-        const unsigned int t2 = (sq / (unsigned int)n_x) * (unsigned int)nwg + (unsigned int)band0 + sq % (unsigned int)n_x;
-        return t2 < (unsigned int)ntiles ? (int)t2 : ntiles;
-    };
-    bool claims_open = true;
-    if (tid == 0) {
-        const int c = claim();
-        claims_open = c < ntiles;
-        *bcast = c;
-    }
-    __syncthreads();
-    set_tile(slot);                                      // grid <= ntiles: the first tile is the static one
-#pragma unroll
-    for (int t = 0; t < S - 1; ++t) stage_next();
-
-    int g = 0;
-    int trace_i = 0;
-    for (int tile = slot; tile < ntiles; tile = next_tile) {
-        if (DBG_BIT(p, 512) && tid == 0 && trace_i < TRACE_TILES) {
-            PERSIST_TRACE(blockIdx.x, 0, __builtin_amdgcn_s_memtime());
-            PERSIST_TRACE(blockIdx.x, 3, tile);
-        }
-        f32x16 acc[C::FM][C::FN];
-#pragma unroll
-        for (int i = 0; i < C::FM; ++i)
-#pragma unroll
-            for (int j = 0; j < C::FN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        for (int kt = 0; kt < nk; ++kt, ++g) {
-            if (ld_step - g == S - 1)
-                ring::wait_vmcnt<(S - 2) * C::LOADS>();
-            else
-                ring::wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            stage_next();
-            const char* la = dsm + (g % S) * C::STAGE_BYTES;
-            const char* lb = la + C::A_BYTES;
-#pragma unroll
-            for (int kk = 0; kk < BK / 16; ++kk) {
-                bf16x8 af[C::FM], bfr[C::FN];
-#pragma unroll
-                for (int f = 0; f < C::FM; ++f) af[f] = *reinterpret_cast<const bf16x8*>(la + ring::kc_off<BK>(a_row[f], 2 * kk + hi));
-#pragma unroll
-                for (int f = 0; f < C::FN; ++f) bfr[f] = *reinterpret_cast<const bf16x8*>(lb + ring::kc_off<BK>(b_row[f], 2 * kk + hi));
-#pragma unroll
-                for (int fi = 0; fi < C::FM; ++fi)
-#pragma unroll
-                    for (int fj = 0; fj < C::FN; ++fj)
-                        acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[fj], af[fi], acc[fi][fj], 0, 0, 0);
-            }
-        }
-        if (DBG_BIT(p, 512) && tid == 0 && trace_i < TRACE_TILES)
-            PERSIST_TRACE(blockIdx.x, 1, __builtin_amdgcn_s_memtime());
-        int claimed = ntiles;
-        if (tid == 0 && claims_open) claimed = claim();  // for the tile after next; the return is awaited below
-        int tm, tn;
-        tile_coords(p, tile, tm, tn);
-        const int m_base = tm * C::BM + wm * C::FM * 32, n_base = tn * C::BN + wn * C::FN * 32;
-        if (!DBG_BIT(p, 1)) {
-            const bool interior = fast_ok && (tm + 1) * C::BM <= p.M && (tn + 1) * C::BN <= p.N;
-            if (interior) {
-                fast_tile_epilogue<EPI, OUT_F32>(p, acc, slab, m_base, n_base, lane);
-            } else {
-#pragma unroll
-                for (int fi = 0; fi < C::FM; ++fi)
-#pragma unroll
-                    for (int fp = 0; fp < C::FN / 2; ++fp)
-                        slab_epilogue<EPI, OUT_F32>(p, acc[fi][2 * fp], acc[fi][2 * fp + 1], slab, m_base + fi * 32, n_base + fp * 64, lane);
-            }
-        }
-        if (tid == 0) {
-            claims_open = claimed < ntiles;
-            *bcast = claimed;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // published before the next s_barrier
-            if (DBG_BIT(p, 512) && trace_i < TRACE_TILES)
-                PERSIST_TRACE(blockIdx.x, 2, __builtin_amdgcn_s_memtime());
-        }
-        ++trace_i;
-    }
-    // departure: the last workgroup out zeroes the slot for its next user (all claims precede all departures)
-    if (tid == 0) {
-        __threadfence();
-        if (atomicAdd(ctr + 8, 1u) == (unsigned int)nwg - 1u) {
-#pragma unroll
-            for (int x = 0; x < 8; ++x) atomicExch(ctr + x, 0u);
-            atomicExch(ctr + 8, 0u);
-        }
-    }
-}
 
 // LDS transpose-read of one 8-deep MFMA operand fragment (rows r..r+3 and r+4..r+7 of a 64-B-stride panel)
 __device__ __forceinline__ bf16x8 tr_pair(const char* p) {
@@ -1486,53 +1185,7 @@ int launch_ring(GemmNTArgs& a, int epilogue, int out_f32, hipStream_t s) {
     return MERLOT_ESHAPE;
 }
 
-template <int EPI, bool OUT_F32>
-int launch_persist_one(GemmNTArgs& a, hipStream_t s) {
-    auto kern = gemm_nt_persist_kernel<EPI, OUT_F32>;
-    MERLOT_ENSURE_LDS(kern, PERSIST_LDS, "merlot_gemm_bf16_nt(persistent)");
-    a.ntm = cdiv(a.M, RingP::BM);
-    a.ntn = cdiv(a.N, RingP::BN);
-    int grid = a.ntm * a.ntn;
-    if (grid > 256) grid = 256;                      // one workgroup per CU (gridDim.x % 8 == 0 keeps the XCD bands even)
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), PERSIST_LDS, s, a);
-    return merlot_launch_status("merlot_gemm_bf16_nt(persistent)");
-}
-
-template <int EPI, bool OUT_F32>
-int launch_persist_dyn_one(GemmNTArgs& a, hipStream_t s) {
-    auto kern = gemm_nt_persist_dyn_kernel<EPI, OUT_F32>;
-    MERLOT_ENSURE_LDS(kern, PERSIST_LDS, "merlot_gemm_bf16_nt(persistent)");
-    a.ntm = cdiv(a.M, RingP::BM);
-    a.ntn = cdiv(a.N, RingP::BN);
-    a.cg = 0;                                            // row-major tile enumeration (profiles/r01_i_gemm_ceiling.txt section 5)
-#ifdef MERLOT_EXPERIMENTS
-    if (const char* e = getenv("MERLOT_NT_TILE_CG_DYN")) a.cg = atoi(e);
-#endif
-    int grid = a.ntm * a.ntn;
-    if (grid > 256) grid = 256;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), PERSIST_LDS, s, a);
-    return merlot_launch_status("merlot_gemm_bf16_nt(persistent, dynamic)");
-}
-
-int launch_persist(GemmNTArgs& a, int epilogue, int out_f32, int kind, hipStream_t s) {   // 0 static, 1 dynamic claims
-#define PERSIST_CASE(E)                                                                                      \
-    case E:                                                                                                  \
-        if (kind == 1) return out_f32 ? launch_persist_dyn_one<E, true>(a, s) : launch_persist_dyn_one<E, false>(a, s); \
-        return out_f32 ? launch_persist_one<E, true>(a, s) : launch_persist_one<E, false>(a, s);
-    switch (epilogue) {
-        PERSIST_CASE(MERLOT_EPI_NONE)
-        PERSIST_CASE(MERLOT_EPI_GELU)
-        PERSIST_CASE(MERLOT_EPI_RESIDUAL)
-        PERSIST_CASE(MERLOT_EPI_DGELU)
-    }
-#undef PERSIST_CASE
-    merlot_set_error("merlot_gemm_bf16_nt: unknown epilogue %d", epilogue);
-    return MERLOT_ESHAPE;
-}
-
-// (configs 1,2,4-10,12,13 of the round-1 tile sweep -- profiles/r01_gemm_tile_sweep.txt -- lost everywhere and were
-// removed from the build; ids kept stable)
-using RingC = ring::Cfg<4, 2, 2, 4, 32, 4>;   // 256x256, BK 32, 4 stages, 128 KB, 8 waves
+using RingC = ring::Cfg<4, 2, 2, 4, 32, 4>;   // 256x256, BK 32, 4 stages, 128 KB, 8 waves (experiments build only)
 using RingK = ring::Cfg<2, 4, 2, 2, 32, 3>;   // 128x256, BK 32, 3 stages, 72 KB (2 blocks/CU)
 using RingN64 = ring::Cfg<4, 1, 2, 2, 32, 3>;   // 256x64,  4 waves, 60 KB: narrow outputs (ResNet-stem 1x1 / 3x3 with 32..64 filters)
 using RingN128 = ring::Cfg<4, 1, 2, 4, 32, 3>;  // 256x128, 4 waves, 72 KB
@@ -1549,7 +1202,7 @@ int nt_plan(int64_t M, int64_t N, int64_t K) {
     // well-filled rounds of 256 workgroups: the ping-pong persistent kernel (K-tiles of 64, at least 2 per tile; round 2:
     // +5..13 % over the lock-step persistent kernel on every shape of the step, profiles/r02_p8_ab.txt)
     int cfg = (tiles * 100 >= rounds * 256 * 85) ? MERLOT_NT_KERNEL_P8 : MERLOT_NT_KERNEL_RING_128x256;
-    if (cfg == MERLOT_NT_KERNEL_P8 && K < 128) cfg = MERLOT_NT_KERNEL_PERSIST_STATIC;
+    if (cfg == MERLOT_NT_KERNEL_P8 && K < 128) cfg = MERLOT_NT_KERNEL_RING_128x256;   // one K-tile of 64: the ring kernel (BK 32)
     // (round 1 sent every [T, 768] x [768, 768] launch to the 128x256 ring kernel; the ping-pong kernel wins those too once
     // its rounds are filled: 166 vs 200 us at T = 101376, 70 vs 78 at 41984, neutral at 16384 = 75 % of one round,
     // which the fill rule above already routes to the ring kernel -- profiles/r02_a_p8_vs_ring_768.txt)
@@ -1566,8 +1219,32 @@ int gemm_nt_dispatch(GemmNTArgs& a, int epilogue, int out_f32, hipStream_t s) {
     if (const char* e = getenv("MERLOT_DBG")) a.dbg = atoi(e);
     if (const char* e = getenv("MERLOT_NT_CFG_DYN")) cfg = atoi(e);
 #endif
-    if (cfg == MERLOT_NT_KERNEL_P8 && !p8_ok(a)) cfg = MERLOT_NT_KERNEL_PERSIST_DYN;   // operands beyond 2 GiB: 64-bit addressing
-    if (cfg == MERLOT_NT_KERNEL_P8 || cfg == MERLOT_NT_KERNEL_PERSIST_DYN)
+    if (cfg == MERLOT_NT_KERNEL_P8 && !p8_ok(a)) {
+        // The ping-pong kernel addresses its operands with unsigned 32-bit byte offsets.  An A operand of 4 GiB or more is cut into
+        // row ranges of whole tiles that fit (round 4; rounds 1-3 kept a second persistent kernel with 64-bit addressing for this):
+        // the same kernel, the same tiles, launched back to back on the stream -- the claim counters are zero again when a launch
+        // ends --, `m_off` keeps the dropout mask's element index global.
+        MERLOT_CHECK(a.K % 64 == 0 && a.K >= 128 && ((int64_t)a.N + 256) * a.ldb * 2 < (1LL << 32), MERLOT_ESHAPE,
+                     "merlot_gemm_bf16_nt: no kernel for M=%d N=%d K=%d ldb=%lld", a.M, a.N, a.K, (long long)a.ldb);
+        MERLOT_CHECK(a.ctr != nullptr, MERLOT_ESHAPE, "merlot_gemm_bf16_nt: this shape needs the caller's zeroed workspace");
+        const int64_t rows_max = ((((1LL << 32) - 1) / (a.lda * 2)) - 256) / 256 * 256;
+        MERLOT_CHECK(rows_max >= 256, MERLOT_ESHAPE, "merlot_gemm_bf16_nt: lda=%lld is too large for the tiled kernels", (long long)a.lda);
+        const int csz = out_f32 ? 4 : 2;
+        for (int64_t r0 = 0; r0 < a.M; r0 += rows_max) {
+            GemmNTArgs c = a;
+            c.M = (int)(a.M - r0 < rows_max ? a.M - r0 : rows_max);
+            c.m_off = a.m_off + r0;
+            c.A = a.A + r0 * a.lda;
+            c.C = (char*)a.C + r0 * a.ldc * csz;
+            if (a.aux_in) c.aux_in = a.aux_in + r0 * a.ld_aux_in;
+            if (a.aux_out) c.aux_out = a.aux_out + r0 * a.ld_aux_out;
+            if (a.row_scale) c.row_scale = a.row_scale + r0;
+            const int rc = gemm_nt_dispatch(c, epilogue, out_f32, s);
+            if (rc != MERLOT_OK) return rc;
+        }
+        return MERLOT_OK;
+    }
+    if (cfg == MERLOT_NT_KERNEL_P8)
         MERLOT_CHECK(a.ctr != nullptr, MERLOT_ESHAPE,
                      "merlot_gemm_bf16_nt: this shape runs a persistent kernel with dynamic tile claims and needs the caller's "
                      "zeroed workspace (merlot_gemm_nt_workspace_bytes() bytes, one block per concurrently used stream)");
@@ -1587,8 +1264,6 @@ int gemm_nt_dispatch(GemmNTArgs& a, int epilogue, int out_f32, hipStream_t s) {
         case MERLOT_NT_KERNEL_RING_128x256: return launch_ring<RingK>(a, epilogue, out_f32, s);
         case MERLOT_NT_KERNEL_RING_256x64: return launch_ring<RingN64>(a, epilogue, out_f32, s);
         case MERLOT_NT_KERNEL_RING_256x128: return launch_ring<RingN128>(a, epilogue, out_f32, s);
-        case MERLOT_NT_KERNEL_PERSIST_STATIC: return launch_persist(a, epilogue, out_f32, 0, s);
-        case MERLOT_NT_KERNEL_PERSIST_DYN: return launch_persist(a, epilogue, out_f32, 1, s);
         case MERLOT_NT_KERNEL_P8: return launch_p8(a, epilogue, out_f32, s);
 #ifdef MERLOT_EXPERIMENTS
         case 3: return launch_ring<RingC>(a, epilogue, out_f32, s);

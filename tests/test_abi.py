@@ -137,8 +137,8 @@ def test_argument_validation_happens_before_any_launch():
     assert rc == -1 and b'frame 1 lies outside the source buffer' in d.merlot_last_error()
     rc = d.merlot_image_frames(fake, 384, jobs.ctypes.data, fake, 2, fake, 16, 16, fake, 16, None)
     assert rc == -1 and b'workspace too small' in d.merlot_last_error()
-    rc = d.merlot_im2col_patches(fake, fake, 1, 64, 64, 8, -0.5, None)
-    assert rc == -1 and b'patch_size 16' in d.merlot_last_error()
+    rc = d.merlot_im2col_patches(fake, fake, 1, 60, 60, 12, -0.5, None)        # 3 * 12 * 12 = 432: not a multiple of 64
+    assert rc == -1 and b'patch_size must be a multiple of 8' in d.merlot_last_error()
 
 
 def test_product_has_no_cpu_fallback():

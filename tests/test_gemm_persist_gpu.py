@@ -21,7 +21,7 @@ from common import rel_l2
 pytestmark = pytest.mark.gpu
 
 BF16, F32 = torch.bfloat16, torch.float32
-PERSIST_DYN = 22          # MERLOT_NT_KERNEL_P8: the ping-pong persistent kernel (round 2) took over these shapes
+PERSIST_DYN = 22          # MERLOT_NT_KERNEL_P8: the ping-pong persistent kernel (round 2) took over these shapes (the lock-step ones were retired in round 4)
 
 
 @pytest.fixture(scope='module')
@@ -204,6 +204,35 @@ def test_operands_between_2_and_4_gib_stay_on_the_ping_pong_kernels():
     for r0 in range(0, M, 50000):
         want += a[r0:r0 + 50000].double().t() @ bb[r0:r0 + 50000].double()
     assert rel_l2(dw, want.float()) < 2e-3
+
+
+def test_an_operand_of_4_gib_and_more_is_cut_into_row_ranges_of_the_same_kernel():
+    """A = [720 000, 3072] bf16 = 4.4 GB (rounds 1-3 sent this to a second persistent kernel with 64-bit addressing; round 4 cuts it
+    into row ranges of whole tiles of the ping-pong kernel): rows on both sides of the cut and the ragged last tile against a small
+    GEMM on those rows, and the dropout mask of the residual epilogue against merlot_dropout_apply on the WHOLE tensor -- the mask is
+    a function of the element's global index, so the second range has to continue where the first ended."""
+    from merlot_amd import ops
+    M, K, N = 720000 + 11, 3072, 256
+    assert (M + 256) * K * 2 >= 2 ** 32
+    g = torch.Generator(device='cuda').manual_seed(5)
+    a = torch.empty(M, K, device='cuda', dtype=torch.bfloat16)
+    for r0 in range(0, M, 90000):                           # filled in pieces: the fp32 temporary of one randn call would be 8.8 GB
+        a[r0:r0 + 90000] = (torch.randn(min(90000, M - r0), K, device='cuda', generator=g) * 0.5).to(torch.bfloat16)
+    b = (torch.randn(N, K, device='cuda', generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, device='cuda', generator=g)
+    out = ops.gemm_nt(a, b, bias=bias)
+    cut = ((2 ** 32 - 1) // (K * 2) - 256) // 256 * 256     # first row of the second range (gemm_nt_dispatch)
+    assert 0 < cut < M
+    for r0 in (0, cut - 150, cut, M - 300):
+        want = torch.addmm(bias, a[r0:r0 + 300].float(), b.float().t())
+        assert rel_l2(out[r0:r0 + 300], want) < 6e-3, r0
+    zero = torch.zeros(M, N, device='cuda', dtype=torch.bfloat16)
+    dropped = ops.gemm_nt(a, b, bias=bias, epilogue=ops.EPI_RESIDUAL, aux_in=zero, dropout_p=0.25, dropout_seed=77)
+    want = ops.dropout_apply(out, 0.25, 77)                 # bf16(out) * mask / 0.75 vs bf16(acc * mask / 0.75): one rounding apart
+    keep_g, keep_w = dropped != 0, want != 0
+    assert torch.equal(keep_g[cut - 512:cut + 512], keep_w[cut - 512:cut + 512]) and torch.equal(keep_g[-512:], keep_w[-512:])
+    assert float((keep_g != keep_w).float().mean()) < 1e-5  # (an output that rounds to exactly 0 is the only legitimate difference)
+    assert rel_l2(dropped[cut - 512:cut + 512], want[cut - 512:cut + 512]) < 6e-3
 
 
 def test_two_k_tiles_per_tile_many_tiles_per_workgroup(ops):
