@@ -500,7 +500,9 @@ class ResNetStemFn(torch.autograd.Function):
         N, h1, w1, C = ctx.c_shape
         d = ops.gemm_nt(dy, lin.wbT).view(N, h1, w1, C)
 
-        def conv_bwd(entry, dyc, need_dx=True):
+        def conv_bwd(entry, dyc, need_dx=True, add=None):
+            """`add` (1x1 convolutions only): a gradient of the convolution's INPUT arriving on another path (the bottleneck block's
+            shortcut), added in the input-gradient GEMM's residual epilogue instead of by a separate pass over the tensor."""
             _, name, a, khat, rstd, wbT, xshape, stride, kh = entry
             Nn, Hh, Ww, Cc = xshape
             co = khat.shape[1]
@@ -517,10 +519,15 @@ class ResNetStemFn(torch.autograd.Function):
                 dyp = torch.zeros((dyf.shape[0], kp_co), device=dyf.device, dtype=BF16)
                 dyp[:, :co] = dyf
                 dyf = dyp
+            if add is not None and kh == 1 and wbT.shape[0] == Cc:
+                dp = ops.gemm_nt(dyf, wbT, epilogue=EPI_RESIDUAL, aux_in=add.reshape(-1, Cc))   # [T, C] + the other path's gradient
+                return dp.view(Nn, Hh, Ww, Cc)
             dp = ops.gemm_nt(dyf, wbT)                                                  # [T, Kp]
             if kh == 1:
-                return dp[:, :Cc].reshape(Nn, Hh, Ww, Cc) if dp.shape[1] != Cc else dp.view(Nn, Hh, Ww, Cc)
-            return ops.col2im3x3(dp, Nn, Hh, Ww, Cc, stride)
+                out = dp[:, :Cc].reshape(Nn, Hh, Ww, Cc) if dp.shape[1] != Cc else dp.view(Nn, Hh, Ww, Cc)
+            else:
+                out = ops.col2im3x3(dp, Nn, Hh, Ww, Cc, stride)
+            return out if add is None else out + add
 
         def gn_bwd(entry, dyg):
             _, name, x, y, stats, relu, has_res = entry
@@ -537,9 +544,6 @@ class ResNetStemFn(torch.autograd.Function):
             i -= 1
             return e
 
-        def add(a_, b_):
-            return a_ + b_                               # one bf16 kernel (fp32 inside), not three passes
-
         while i >= 0 and tape[i][0] == 'block_end':
             pop()
             # main branch, last to first: gn(res) <- conv <- [pool] <- gn <- conv <- gn <- conv
@@ -550,7 +554,7 @@ class ResNetStemFn(torch.autograd.Function):
             e = pop(); d_h, _ = gn_bwd(e, d_h)
             d_h = conv_bwd(pop(), d_h)
             e = pop(); d_h, _ = gn_bwd(e, d_h)
-            d_c = conv_bwd(pop(), d_h)
+            conv1 = pop()                                                                # its input gradient joins the shortcut's below
             assert pop()[0] == 'main_begin'
             # shortcut branch
             if tape[i][0] == 'gn':                                                       # projection shortcut
@@ -561,7 +565,7 @@ class ResNetStemFn(torch.autograd.Function):
             else:
                 d_s = d_short
             assert pop()[0] == 'block_begin'
-            d = add(d_c, d_s)
+            d = conv_bwd(conv1, d_h, add=d_s.contiguous())       # d(block input) = conv1's input gradient + the shortcut's, one GEMM
         assert pop()[0] == 'pool'
         d = ops.avgpool2_bwd(d.contiguous())
         for j in range(3):                                                               # the three stem convolutions
