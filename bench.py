@@ -170,13 +170,13 @@ def gemm_source_hash():
 
 def measured_traffic():
     """HBM-side bytes per launch of the representative dominant launch (M=101376 N=3072 K=768, bias epilogue), from the
-    TCC counters collected in separate rocprofv3 --pmc passes over THIS kernel (profiles/r03_traffic.txt, written by
+    TCC counters collected in separate rocprofv3 --pmc passes over THIS kernel (profiles/r04_traffic.txt, written by
     scripts/gpu_traffic.sh): 2 * FETCH_SIZE (gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE, in bytes.  The
     file records the hash of the GEMM sources it was measured on; if the sources changed since, the figure is STALE and
     is not reported (traffic: null, with the reason)."""
-    path = os.path.join(ROOT, 'profiles', 'r03_traffic.txt')
+    path = os.path.join(ROOT, 'profiles', 'r04_traffic.txt')
     if not os.path.exists(path):
-        return {'bytes_per_launch': None, 'why': 'profiles/r03_traffic.txt absent'}
+        return {'bytes_per_launch': None, 'why': 'profiles/r04_traffic.txt absent'}
     fetch = write = src = None
     for line in open(path):
         if line.startswith('gemm_source_hash'):
@@ -188,13 +188,13 @@ def measured_traffic():
             else:
                 write = kb
     if fetch is None or write is None:
-        return {'bytes_per_launch': None, 'why': 'profiles/r03_traffic.txt holds no gemm_nt_p8_kernel<0, false, false, true> rows'}
+        return {'bytes_per_launch': None, 'why': 'profiles/r04_traffic.txt holds no gemm_nt_p8_kernel<0, false, false, true> rows'}
     if src != gemm_source_hash():
-        return {'bytes_per_launch': None, 'why': f'profiles/r03_traffic.txt was measured on GEMM sources {src}, the tree has '
+        return {'bytes_per_launch': None, 'why': f'profiles/r04_traffic.txt was measured on GEMM sources {src}, the tree has '
                                                  f'{gemm_source_hash()}: stale, re-run scripts/gpu_traffic.sh'}
     return {'bytes_per_launch': (2.0 * fetch + write) * 1024.0, 'algorithmic_bytes_per_launch': 3119.0e6,
             'launch': 'forward Linear M=405504 (= 128 examples x 16 frames x 198 tokens) N=3072 K=768, bias epilogue, bf16 out (gemm_nt_p8_kernel<0,false,false,true>)',
-            'source': 'profiles/r03_traffic.txt', 'gemm_source_hash': src}
+            'source': 'profiles/r04_traffic.txt', 'gemm_source_hash': src}
 
 
 def main():

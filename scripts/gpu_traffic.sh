@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM traffic of the dominant kernels from the TCC counters -- separate --pmc passes with --kernel-trace only, as
-# MI355X_MICROARCH.md prescribes -- over the PRODUCT library.  Writes gpurun_out/r03_traffic.txt; copy it to profiles/.
+# MI355X_MICROARCH.md prescribes -- over the PRODUCT library.  Writes gpurun_out/r04_traffic.txt; copy it to profiles/.
 # The file records the hash of the GEMM sources (bench.py refuses a file whose hash differs from the tree's) and the
 # sha256 of the measured libmerlot_hip.so.
 export TMPDIR=/tmp
@@ -13,7 +13,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   cp /tmp/pmc_$c/g_counter_collection.csv $R/gpurun_out/pmc_$c.csv
 done
 cd $R
-python - <<'PY' > gpurun_out/r03_traffic.txt
+python - <<'PY' > gpurun_out/r04_traffic.txt
 import csv, collections, hashlib, os, sys
 sys.path.insert(0, os.getcwd())
 import bench
@@ -41,4 +41,4 @@ for k, d in vals.items():
     if 'FETCH_SIZE' in d and 'WRITE_SIZE' in d:
         print('HBM_MB | %s | %.1f' % (k, (2 * d['FETCH_SIZE'] + d['WRITE_SIZE']) / 1024.0))
 PY
-cat gpurun_out/r03_traffic.txt
+cat gpurun_out/r04_traffic.txt
