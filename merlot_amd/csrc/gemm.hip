@@ -818,7 +818,11 @@ __device__ __forceinline__ void slab_epilogue(const GemmNTArgs& p, const f32x16&
 // cost as much as the whole K=768 main loop was LATENCY: `bias` was re-loaded after every store (may alias C) and
 // each residual / pre-activation row segment was loaded right where it was consumed, 16 dependent round trips per
 // wave per tile.  Here bias is read once per tile and the auxiliary operand runs PF passes (1 KiB each) ahead.
-template <int EPI, bool OUT_F32, int FM = 2, int FN = 4, int PF = 8, bool RS = false>
+// FLAG: the run-time option of the GELU epilogue (the pre-activation output exists) and of the RESIDUAL epilogue (dropout is on)
+// resolved at compile time, so that their 16 passes are straight-line code (round 4, profiles/r04_l_epilogue_flags.txt: proj -4 %,
+// fc2 -2.5 %; doing the same for the column sums of the NONE / DGELU epilogues made THOSE kernels 5-19 % slower -- two copies of
+// the epilogue in a kernel whose main loop is register-tight -- and was taken back).
+template <int EPI, bool OUT_F32, int FM = 2, int FN = 4, int PF = 8, bool RS = false, bool FLAG = false>
 __device__ __forceinline__ void fast_tile_epilogue(const GemmNTArgs& p, f32x16 (&acc)[FM][FN], char* slab, int m_base,
                                                    int n_base, int lane) {
     static_assert(FM * FN == 8, "a wave owns 8 accumulators = 4 slabs of 32 x 64");
@@ -849,7 +853,7 @@ __device__ __forceinline__ void fast_tile_epilogue(const GemmNTArgs& p, f32x16 (
         for (int q = 0; q < PF; ++q) aux[q] = *reinterpret_cast<const bf16x8*>(aux_addr(q));
         __builtin_amdgcn_sched_barrier(0);               // keep the prefetch up here (the scheduler sinks loads)
     }
-    const bool want_cs = !OUT_F32 && p.colsum != nullptr;       // wave-uniform
+    const bool want_cs = !OUT_F32 && p.colsum != nullptr;       // wave-uniform (NONE / DGELU: stays a run-time test, see FLAG)
     float cacc[NFP][8];
 #pragma unroll
     for (int fp = 0; fp < NFP; ++fp)
@@ -889,7 +893,7 @@ __device__ __forceinline__ void fast_tile_epilogue(const GemmNTArgs& p, f32x16 (
             }
             const bool no_store = DBG_BIT(p, 8), no_math = DBG_BIT(p, 128);       // experiments only
             if (EPI == MERLOT_EPI_GELU) {
-                if (p.aux_out && !no_store) {
+                if (FLAG && !no_store) {
                     bf16x8 u8;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) u8[e] = (bf16)v[e];
@@ -909,7 +913,7 @@ __device__ __forceinline__ void fast_tile_epilogue(const GemmNTArgs& p, f32x16 (
                     v[e + 1] *= g1;
                 }
             } else if (EPI == MERLOT_EPI_RESIDUAL) {
-                if (p.drop_thresh && !no_math) {
+                if (FLAG && !no_math) {
                     bool keep[8];                        // interior tiles: N % 256 == 0, the index is even
                     dropout_keep_n<8>(p.drop_seed, (uint64_t)(m + p.m_off) * (uint64_t)p.N + (uint64_t)n, p.drop_thresh, keep);
 #pragma unroll
