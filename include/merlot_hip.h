@@ -221,6 +221,11 @@ int merlot_dropout_apply(const void* x, void* y, int64_t rows, int64_t N, float 
 /* table[idx[r],:] += src[r,:]  (f32, atomics) ; idx<0 skipped.  Backward of the gathers. */
 int merlot_scatter_add_rows(const float* src, const int32_t* idx, float* table, int64_t rows, int H,
                             merlot_stream_t stream);
+/* The same for MANY rows onto FEW distinct table rows (the word-embedding gradient: model/modeling.py:262-296's gather, backward): the
+ * caller sorts -- perm = a stable argsort of idx (int32), sorted_idx = idx[perm] -- and rows of one index are summed in registers
+ * and written once; atomics only where a run of equal indices crosses a block boundary.  Negative indices are skipped.  H % 4 == 0. */
+int merlot_scatter_add_sorted(const float* src, const int32_t* perm, const int32_t* sorted_idx, float* table, int64_t rows, int H,
+                              merlot_stream_t stream);
 /* 2x2 VALID average pool of a [n_img, h1, w1, H] bf16 grid taken from rows [n, cls_skip + h*w1 + w] of
  * x[n_img, S, H]; writes f32 [n_img, 1 + h2*w2, H] with row 0 = x[n,0,:] (the CLS slot)
  * (utils/vision_transformer.py:251-267 + model/modeling.py:101-105). */

@@ -181,6 +181,43 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __re
     }
 }
 
+// table[sorted_idx[j], :] += src[perm[j], :] over j in SORTED index order (perm = a stable argsort of the row indices, made by the
+// caller): a block owns a contiguous range of sorted positions, a thread 4 columns; rows of one index are summed in registers and
+// written once -- with a plain read-modify-write when the index's run lies strictly inside the block's range (no other block can
+// touch that table row), with atomics for the first and the last index of the range (their runs may continue in a neighbour).
+// The word-embedding gradient of a step is 65 536 rows of 768 floats onto ~20 000 distinct tokens: 50 M fp32 atomics (708 us) before.
+constexpr int SCS_ROWS = 32;
+__global__ __launch_bounds__(256) void scatter_add_sorted_kernel(const float* __restrict__ src, const int32_t* __restrict__ perm,
+                                                                 const int32_t* __restrict__ sidx, float* __restrict__ table,
+                                                                 int64_t rows, int H) {
+    const int64_t p0 = (int64_t)blockIdx.x * SCS_ROWS, p1 = p0 + SCS_ROWS < rows ? p0 + SCS_ROWS : rows;
+    const int first = sidx[p0], last = sidx[p1 - 1];
+    const bool first_shared = p0 > 0 && sidx[p0 - 1] == first, last_shared = p1 < rows && sidx[p1] == last;
+    for (int col = threadIdx.x * 4; col < H; col += blockDim.x * 4) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        int cur = first;
+        for (int64_t j = p0; j <= p1; ++j) {
+            const int k = j < p1 ? sidx[j] : -2147483647;               // sentinel: flush the last run
+            if (k != cur) {
+                if (cur >= 0) {
+                    float* t = table + (int64_t)cur * H + col;
+                    if ((cur == first && first_shared) || (cur == last && last_shared)) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) atomicAdd(t + e, acc[e]);
+                    } else {
+                        f32x4 o = *reinterpret_cast<const f32x4*>(t);
+                        o += acc;
+                        *reinterpret_cast<f32x4*>(t) = o;
+                    }
+                }
+                acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                cur = k;
+            }
+            if (j < p1) acc += *reinterpret_cast<const f32x4*>(src + (int64_t)perm[j] * H + col);
+        }
+    }
+}
+
 // ---- CLS + 2x2 average pool ------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cls_avgpool_fwd_kernel(const bf16* __restrict__ x, float* __restrict__ out,
                                                               int n_img, int h1, int w1, int cls_skip, int pool, int H) {
@@ -561,6 +598,18 @@ extern "C" int merlot_scatter_add_rows(const float* src, const int32_t* idx, flo
     hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid_for(rows * H, 256)), dim3(256), 0, STREAM, src, idx, table, rows,
                        H);
     return merlot_launch_status("merlot_scatter_add_rows");
+}
+
+extern "C" int merlot_scatter_add_sorted(const float* src, const int32_t* perm, const int32_t* sorted_idx, float* table, int64_t rows,
+                                         int H, merlot_stream_t stream) {
+    MERLOT_CHECK(src && perm && sorted_idx && table && rows > 0 && H > 0 && H % 4 == 0, MERLOT_ESHAPE,
+                 "merlot_scatter_add_sorted: bad args (H must be a multiple of 4)");
+    MERLOT_CHECK(((uintptr_t)src & 15) == 0 && ((uintptr_t)table & 15) == 0, MERLOT_EALIGN, "merlot_scatter_add_sorted: 16-byte aligned rows");
+    const int64_t blocks = (rows + SCS_ROWS - 1) / SCS_ROWS;
+    MERLOT_CHECK(blocks < (1LL << 31), MERLOT_ESHAPE, "merlot_scatter_add_sorted: too many rows");
+    hipLaunchKernelGGL(scatter_add_sorted_kernel, dim3((unsigned)blocks), dim3(H >= 1024 ? 256 : (H / 4 + 63) / 64 * 64), 0, STREAM, src, perm,
+                       sorted_idx, table, rows, H);
+    return merlot_launch_status("merlot_scatter_add_sorted");
 }
 
 extern "C" int merlot_cls_avgpool_fwd(const void* x, float* out, int n_img, int h1, int w1, int cls_skip, int pool, int H,

@@ -189,6 +189,28 @@ def test_patch_embed_other_patch_sizes(ops, P, H, W):
         ops.patch_embed_fwd(torch.rand(1, 48, 48, 3).to(BF16).cuda(), rnd((768, 432), g, 0.03).cuda(), bias.cuda(), 12)
 
 
+@pytest.mark.parametrize("rows,H,nid", [(65536, 768, 20000), (5000, 768, 3), (4097, 64, 4097), (70001, 256, 50370)])
+def test_scatter_add_rows_sorted_path(ops, rows, H, nid):
+    """large scatters (the word-embedding gradient) are sorted by index and reduced per run of equal indices
+    (merlot_scatter_add_sorted): runs inside a block's range, runs across block boundaries (nid = 3: every run spans many blocks),
+    unique indices, skipped negative indices, a row count that is not a multiple of the block's 32 -- against index_add_ in fp64;
+    the table is ACCUMULATED into."""
+    g = torch.Generator().manual_seed(rows + nid)
+    idx = torch.randint(0, nid, (rows,), generator=g, dtype=torch.int32)
+    idx[torch.rand(rows, generator=g) < 0.01] = -1
+    src = torch.randn((rows, H), generator=g)
+    tab0 = torch.randn((nid, H), generator=g)
+    want = tab0.double()
+    keep = idx >= 0
+    want.index_add_(0, idx[keep].long(), src[keep].double())
+    tab = tab0.clone().cuda()
+    ops.scatter_add_rows(src.cuda(), idx.cuda(), tab)
+    assert float((tab.cpu().double() - want).abs().max()) < 1e-4 * max(1.0, float(want.abs().max()))
+    tab2 = tab0.clone().cuda()                              # deterministic where no run crosses a block boundary; always close
+    ops.scatter_add_rows(src.cuda(), idx.cuda(), tab2)
+    assert float((tab2 - tab).abs().max()) < 1e-5 * max(1.0, float(want.abs().max()))
+
+
 # ---- LayerNorm ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("rows,H,xf32", [(1, 768, False), (1000, 768, False), (333, 768, True), (64, 1024, False), (50, 256, True)])
 def test_layernorm(ops, rows, H, xf32):
