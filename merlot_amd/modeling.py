@@ -587,7 +587,10 @@ def model_fn_builder(config):
             images = images.permute(3, 0, 1, 2).contiguous()
         elif mode != 'train':                                                   # :686-687
             images = images.reshape([-1] + list(config.model['image_size']) + [3])
-        model = MerlotModel(config=config.model, is_training=True,            # quirk kept: always True (:691-693)
+        mcfg = config.model
+        if mode != 'train' and mcfg.get('attention_log_in_backward', False):
+            mcfg = dict(mcfg, attention_log_in_backward=False)                  # no backward follows an eval / predict graph
+        model = MerlotModel(config=mcfg, is_training=True,                    # quirk kept: always True (:691-693)
                             image=images, input_ids=features['input_ids'],
                             use_tpu=config.device.get('use_tpu', False),
                             shuffled_idx_img=features.get('shuffled_idx_img', None), mask_input=True,
