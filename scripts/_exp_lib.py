@@ -10,7 +10,7 @@ for p in (ROOT, os.path.join(ROOT, 'tests')):
         sys.path.insert(0, p)
 from merlot_amd import lib  # noqa: E402
 
-EXP = os.path.join(lib._HERE, 'libmerlot_hip_exp.so')
+EXP = os.environ.get('EXP_LIB') or os.path.join(lib._HERE, 'libmerlot_hip_exp.so')
 assert os.path.exists(EXP), "experiments build missing: run merlot_amd/csrc/build.sh exp"
 lib.LIB.path = EXP
 lib.LIB.protos['merlot_probe_persist_trace'] = ('int', [('void*', 'dst'), ('int64_t', 'bytes'), ('merlot_stream_t', 'stream')])

@@ -27,12 +27,13 @@ def bench(fn, iters=30):
     return e0.elapsed_time(e1) * 1e3 / iters
 
 
-row, tot = [], 0.0
-for (M, N, name) in [(768, 768, 'dWproj'), (3072, 768, 'dW1'), (768, 3072, 'dW2'), (2304, 768, 'dWqkv')]:
-    a = torch.randn(T, M, device='cuda').bfloat16()
-    b = torch.randn(T, N, device='cuda').bfloat16()
-    out = torch.zeros((M, N), device='cuda')
-    t = bench(lambda: ops.gemm_tn(a, b, out, accumulate=True))
-    tot += t
-    row.append(f'{name} {t:6.1f} us {2.0 * T * M * N / t / 1e6:5.0f} TF')
-print(f'{os.path.basename(lib.LIB.path or "libmerlot_hip.so"):24s} sum {tot:7.1f} us | ' + ' | '.join(row), flush=True)
+if __name__ == '__main__':
+    row, tot = [], 0.0
+    for (M, N, name) in [(768, 768, 'dWproj'), (3072, 768, 'dW1'), (768, 3072, 'dW2'), (2304, 768, 'dWqkv')]:
+        a = torch.randn(T, M, device='cuda').bfloat16()
+        b = torch.randn(T, N, device='cuda').bfloat16()
+        out = torch.zeros((M, N), device='cuda')
+        t = bench(lambda: ops.gemm_tn(a, b, out, accumulate=True))
+        tot += t
+        row.append(f'{name} {t:6.1f} us {2.0 * T * M * N / t / 1e6:5.0f} TF')
+    print(f'{os.path.basename(lib.LIB.path or "libmerlot_hip.so"):24s} sum {tot:7.1f} us | ' + ' | '.join(row), flush=True)
