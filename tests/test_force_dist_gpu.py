@@ -72,7 +72,7 @@ def test_trainer_step_under_forced_rccl_collectives_matches_the_plain_step(monke
         assert all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
         assert abs(lf - l0) <= 1e-6 * max(1.0, abs(l0))
         d = float((gf - g0).abs().max())
-        assert d <= max(2.0 * noise, 1e-7 * scale), (d, noise, scale)
+        assert d <= max(2.0 * noise, 1e-5 * scale), (d, noise, scale)     # (two plain steps may happen to agree to the bit: the atomics' bound then)
         # bf16 bucket payload (optimizer.grad_reduce_dtype: bfloat16): each gradient element is rounded to bf16 once
         launched.clear()
         lb, gb, _, _ = _step(copy.deepcopy(config), ctx, batch, payload='bfloat16')
