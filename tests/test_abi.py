@@ -34,7 +34,7 @@ SURVEY_8B = {
     'merlot_bias_gelu_fwd': ['merlot_gelu_fwd'],
     'merlot_bias_gelu_bwd': ['merlot_gelu_bwd'],
     'merlot_gather_rows_fwd': ['merlot_gather_add4'],
-    'merlot_gather_rows_bwd': ['merlot_scatter_add_rows'],
+    'merlot_gather_rows_bwd': ['merlot_scatter_add_rows', 'merlot_scatter_add_sorted'],   # many rows onto few table rows: sorted + per-run reduction
     'merlot_vocab_ce_fwd': ['merlot_vocab_ce_fwd', 'merlot_vocab_ce_scratch_bytes'],
     'merlot_vocab_ce_bwd': ['merlot_gemm_bf16_nt', 'merlot_gemm_bf16_tn', 'merlot_colsum_bf16'],   # dlogits come out of the forward
     'merlot_contrastive_logits_ce_fwd': ['merlot_l2norm_fwd', 'merlot_gemm_bf16_nt', 'merlot_softmax_ce'],
