@@ -325,10 +325,12 @@ int merlot_weight_std_bwd(const float* dkhat_t, int64_t ld, const float* khat, c
 int merlot_groupnorm_fwd(const void* x, const float* gamma, const float* beta, const void* res, void* y, float* stats,
                          int N, int H, int W, int C, int G, float eps, int relu, merlot_stream_t stream);
 /* dy' = relu ? dy * (y > 0) : dy.  dgamma / dbeta (f32 [C]) are ACCUMULATED; gsum: f32 [N, G, 2] scratch; dx bf16;
- * dres (optional) = dy' for the residual branch. */
-int merlot_groupnorm_bwd(const void* dy, const void* y, const void* x, const float* stats, const float* gamma,
-                         float* dgamma, float* dbeta, float* gsum, void* dx, void* dres, int N, int H, int W, int C,
-                         int G, float eps, int relu, merlot_stream_t stream);
+ * dres (optional) = dy' for the residual branch.  y may be NULL for a relu layer WITHOUT a residual add (ABI v5): the mask is then
+ * recomputed from x as (x - mean) * rstd * gamma + beta > 0, the forward's own expression -- one tensor pass less in each of the two
+ * backward kernels; beta is read only for that. */
+int merlot_groupnorm_bwd(const void* dy, const void* y, const void* x, const float* stats, const float* gamma, const float* beta,
+                         float* dgamma, float* dbeta, float* gsum, void* dx, void* dres, int N, int H, int W, int C, int G,
+                         float eps, int relu, merlot_stream_t stream);
 /* tf.nn.avg_pool2d(ksize 2, strides 2) on even H, W; the backward takes dy [N, H/2, W/2, C] and writes dx [N, H, W, C]. */
 int merlot_avgpool2_fwd(const void* x, void* y, int N, int H, int W, int C, merlot_stream_t stream);
 int merlot_avgpool2_bwd(const void* dy, void* dx, int N, int H, int W, int C, merlot_stream_t stream);

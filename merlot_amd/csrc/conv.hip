@@ -160,39 +160,52 @@ __global__ void gn_finalize_kernel(float* __restrict__ stats, int64_t n_groups, 
     }
 }
 
-// y = [relu]( (x - mean) * rstd * gamma + beta [+ res] )
+// y = [relu]( (x - mean) * rstd * gamma + beta [+ res] ).  Grid (sample, position slice) like the statistics kernel: a thread always
+// touches the same 8 channels, so gamma, beta and the (mean, rstd) of its channels' groups are loaded ONCE per thread -- the first
+// version looked them up per element with an integer division by the run-time group width each, and ran at 60-70 % of the HBM rate
+// (round 4, profiles/r04_r_groupnorm_kernels.txt).
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16* __restrict__ x, const float* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       const bf16* __restrict__ res, bf16* __restrict__ y, int64_t N, int HW,
-                                                       int C, int G, float eps, int relu) {
+                                                       const bf16* __restrict__ res, bf16* __restrict__ y, int HW,
+                                                       int C, int G, int relu, int pos_per_block) {
+    const int n = blockIdx.x;
     const int cpr = C / 8, cpg = C / G;
-    const int64_t total = N * HW * cpr;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % cpr) * 8;
-        const int64_t n = i / ((int64_t)HW * cpr);
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + i * 8);
+    const int chunk = threadIdx.x % cpr, prow = threadIdx.x / cpr, pstep = blockDim.x / cpr;
+    const int p0 = blockIdx.y * pos_per_block, p1 = min(HW, p0 + pos_per_block);
+    float sc[8], sh[8];                                    // y = x * sc + sh
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = chunk * 8 + e, g = c / cpg;
+        const float mean = stats[((int64_t)n * G + g) * 2], rstd = stats[((int64_t)n * G + g) * 2 + 1];
+        sc[e] = rstd * gamma[c];
+        sh[e] = beta[c] - mean * rstd * gamma[c];
+    }
+    for (int p = p0 + prow; p < p1; p += pstep) {
+        const int64_t off = ((int64_t)n * HW + p) * C + chunk * 8;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + off);
         bf16x8 r8;
-        if (res) r8 = *reinterpret_cast<const bf16x8*>(res + i * 8);
+        if (res) r8 = *reinterpret_cast<const bf16x8*>(res + off);
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int g = (c + e) / cpg;
-            const float mean = stats[(n * G + g) * 2], rstd = stats[(n * G + g) * 2 + 1];
-            float f = ((float)v[e] - mean) * rstd * gamma[c + e] + beta[c + e];
+            float f = __builtin_fmaf((float)v[e], sc[e], sh[e]);
             if (res) f += (float)r8[e];
             if (relu) f = fmaxf(f, 0.f);
             o[e] = (bf16)f;
         }
-        *reinterpret_cast<bf16x8*>(y + i * 8) = o;
+        *reinterpret_cast<bf16x8*>(y + off) = o;
     }
 }
 
 // backward, pass 1: with dy' = relu ? dy * (y > 0) : dy and xhat = (x - mean) * rstd:
 //   dgamma[c] += sum dy' * xhat, dbeta[c] += sum dy'          (over samples and positions; atomics per block)
 //   gsum[n][g] = {sum_c gamma_c * dbeta_c(n), sum_c gamma_c * dgamma_c(n)}   (per sample)
+// (relu with y == nullptr: the ReLU mask is recomputed from x -- y = (x - mean) * rstd * gamma + beta, the forward's own expression --
+// instead of reading the stored output: one tensor pass less in each of the two backward kernels; layers with a residual add pass y)
 __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ y,
                                                            const bf16* __restrict__ x, const float* __restrict__ stats,
-                                                           const float* __restrict__ gamma, float* __restrict__ dgamma,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, float* __restrict__ gsum, int HW, int C,
                                                            int G, float eps, int relu, int pos_per_block) {
     extern __shared__ float sm[];                          // [C][2] per-channel partials of this block
@@ -203,12 +216,15 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const bf16* __restric
     const int p0 = blockIdx.y * pos_per_block, p1 = min(HW, p0 + pos_per_block);
     const int chunk = threadIdx.x % cpr;
     const int prow = threadIdx.x / cpr, pstep = blockDim.x / cpr;
-    float mean[8], rstd[8], dg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, db[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float mean[8], rstd[8], gam[8], bet[8], dg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, db[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool from_x = relu && y == nullptr;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int g = (chunk * 8 + e) / cpg;
         mean[e] = stats[((int64_t)n * G + g) * 2];
         rstd[e] = stats[((int64_t)n * G + g) * 2 + 1];
+        gam[e] = from_x ? rstd[e] * gamma[chunk * 8 + e] : 0.f;                    // y = x * gam + bet: gn_apply_kernel's own expression
+        bet[e] = from_x ? beta[chunk * 8 + e] - mean[e] * rstd[e] * gamma[chunk * 8 + e] : 0.f;
     }
     if (prow < pstep) {
         for (int p = p0 + prow; p < p1; p += pstep) {
@@ -216,11 +232,12 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const bf16* __restric
             const bf16x8 d8 = *reinterpret_cast<const bf16x8*>(dy + off);
             const bf16x8 x8 = *reinterpret_cast<const bf16x8*>(x + off);
             bf16x8 y8;
-            if (relu) y8 = *reinterpret_cast<const bf16x8*>(y + off);
+            if (relu && !from_x) y8 = *reinterpret_cast<const bf16x8*>(y + off);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float d = (float)d8[e];
-                if (relu && !((float)y8[e] > 0.f)) d = 0.f;
+                const float yv = from_x ? __builtin_fmaf((float)x8[e], gam[e], bet[e]) : (float)y8[e];
+                if (relu && !(yv > 0.f)) d = 0.f;
                 dg[e] += d * ((float)x8[e] - mean[e]) * rstd[e];
                 db[e] += d;
             }
@@ -242,35 +259,52 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const bf16* __restric
     }
 }
 
-// backward, pass 2: dx = rstd * (dy' * gamma - gsum0 / cnt - xhat * gsum1 / cnt); optionally dres = dy' (residual branch)
+// backward, pass 2: dx = rstd * (dy' * gamma - gsum0 / cnt - xhat * gsum1 / cnt); optionally dres = dy' (residual branch).
+// Same indexing as gn_apply_kernel: per-thread constants k1 = rstd * gamma, k2 = rstd * gsum0 / cnt, k3 = rstd * gsum1 / cnt, and
+// xhat = x * rstd - mean * rstd.
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ y,
                                                            const bf16* __restrict__ x, const float* __restrict__ stats,
                                                            const float* __restrict__ gsum, const float* __restrict__ gamma,
-                                                           bf16* __restrict__ dx, bf16* __restrict__ dres, int64_t N, int HW,
-                                                           int C, int G, float eps, int relu) {
+                                                           const float* __restrict__ beta, bf16* __restrict__ dx,
+                                                           bf16* __restrict__ dres, int HW, int C, int G, int relu,
+                                                           int pos_per_block) {
+    const int n = blockIdx.x;
     const int cpr = C / 8, cpg = C / G;
     const float inv_cnt = 1.0f / ((float)HW * (float)cpg);
-    const int64_t total = N * HW * cpr;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % cpr) * 8;
-        const int64_t n = i / ((int64_t)HW * cpr);
-        const bf16x8 d8 = *reinterpret_cast<const bf16x8*>(dy + i * 8);
-        const bf16x8 x8 = *reinterpret_cast<const bf16x8*>(x + i * 8);
+    const int chunk = threadIdx.x % cpr, prow = threadIdx.x / cpr, pstep = blockDim.x / cpr;
+    const int p0 = blockIdx.y * pos_per_block, p1 = min(HW, p0 + pos_per_block);
+    const bool from_x = relu && y == nullptr;
+    float rs[8], mr[8], k1[8], k2[8], k3[8], gam[8], bet[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = chunk * 8 + e, g = c / cpg;
+        const float mean = stats[((int64_t)n * G + g) * 2], rstd = stats[((int64_t)n * G + g) * 2 + 1];
+        rs[e] = rstd;
+        mr[e] = mean * rstd;
+        gam[e] = gamma[c];
+        bet[e] = from_x ? beta[c] - mean * rstd * gam[e] : 0.f;      // from_x: y = x * (rstd gamma) + this, gn_apply_kernel's own expression
+        k1[e] = rstd * gam[e];
+        k2[e] = rstd * gsum[((int64_t)n * G + g) * 2] * inv_cnt;
+        k3[e] = rstd * gsum[((int64_t)n * G + g) * 2 + 1] * inv_cnt;
+    }
+    for (int p = p0 + prow; p < p1; p += pstep) {
+        const int64_t off = ((int64_t)n * HW + p) * C + chunk * 8;
+        const bf16x8 d8 = *reinterpret_cast<const bf16x8*>(dy + off);
+        const bf16x8 x8 = *reinterpret_cast<const bf16x8*>(x + off);
         bf16x8 y8;
-        if (relu) y8 = *reinterpret_cast<const bf16x8*>(y + i * 8);
+        if (relu && !from_x) y8 = *reinterpret_cast<const bf16x8*>(y + off);
         bf16x8 o, r;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int g = (c + e) / cpg;
-            const float mean = stats[(n * G + g) * 2], rstd = stats[(n * G + g) * 2 + 1];
             float d = (float)d8[e];
-            if (relu && !((float)y8[e] > 0.f)) d = 0.f;
-            const float xhat = ((float)x8[e] - mean) * rstd;
-            o[e] = (bf16)(rstd * (d * gamma[c + e] - gsum[(n * G + g) * 2] * inv_cnt - xhat * gsum[(n * G + g) * 2 + 1] * inv_cnt));
+            const float xhat = __builtin_fmaf((float)x8[e], rs[e], -mr[e]);
+            const float yv = from_x ? __builtin_fmaf((float)x8[e], k1[e], bet[e]) : (float)y8[e];
+            if (relu && !(yv > 0.f)) d = 0.f;
+            o[e] = (bf16)(d * k1[e] - k2[e] - xhat * k3[e]);
             r[e] = (bf16)d;
         }
-        *reinterpret_cast<bf16x8*>(dx + i * 8) = o;
-        if (dres) *reinterpret_cast<bf16x8*>(dres + i * 8) = r;
+        *reinterpret_cast<bf16x8*>(dx + off) = o;
+        if (dres) *reinterpret_cast<bf16x8*>(dres + off) = r;
     }
 }
 
@@ -389,18 +423,17 @@ extern "C" int merlot_groupnorm_fwd(const void* x, const float* gamma, const flo
                        stats, HW, C, G, ppb);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(((int64_t)N * G + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats,
                        (int64_t)N * G, 1.0f / ((float)HW * (float)(C / G)), eps);
-    const int64_t total = (int64_t)N * HW * (C / 8);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, stats, gamma,
-                       beta, (const bf16*)res, (bf16*)y, (int64_t)N, HW, C, G, eps, relu);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(N, split), dim3(threads), 0, (hipStream_t)stream, (const bf16*)x, stats, gamma, beta,
+                       (const bf16*)res, (bf16*)y, HW, C, G, relu, ppb);
     return merlot_launch_status("merlot_groupnorm_fwd");
 }
 
 extern "C" int merlot_groupnorm_bwd(const void* dy, const void* y, const void* x, const float* stats, const float* gamma,
-                                    float* dgamma, float* dbeta, float* gsum, void* dx, void* dres, int N, int H, int W, int C,
-                                    int G, float eps, int relu, merlot_stream_t stream) {
+                                    const float* beta, float* dgamma, float* dbeta, float* gsum, void* dx, void* dres, int N, int H,
+                                    int W, int C, int G, float eps, int relu, merlot_stream_t stream) {
     CONV_CHECK_GEOM("merlot_groupnorm_bwd");
-    MERLOT_CHECK(dy && stats && gamma && dgamma && dbeta && gsum && dx && (!relu || y) && G > 0 && C % G == 0 && C % 8 == 0 &&
-                     C <= 2048, MERLOT_ESHAPE, "merlot_groupnorm_bwd: bad arguments");
+    MERLOT_CHECK(dy && stats && gamma && dgamma && dbeta && gsum && dx && (!relu || y || beta) && G > 0 && C % G == 0 && C % 8 == 0 &&
+                     C <= 2048, MERLOT_ESHAPE, "merlot_groupnorm_bwd: bad arguments (relu needs y, or beta to recompute the mask from x)");
     const int HW = H * W;
     const int threads = gn_block_threads(C);
     // enough blocks to fill the chip (>= ~2048) but no more: every block ends in atomics (2G here, 4C in the backward)
@@ -413,10 +446,9 @@ extern "C" int merlot_groupnorm_bwd(const void* dy, const void* y, const void* x
     hipError_t e = hipMemsetAsync(gsum, 0, sizeof(float) * 2 * (size_t)N * G, (hipStream_t)stream);
     MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(N, split), dim3(threads), sizeof(float) * 2 * C, (hipStream_t)stream, (const bf16*)dy,
-                       (const bf16*)y, (const bf16*)x, stats, gamma, dgamma, dbeta, gsum, HW, C, G, eps, relu, ppb);
-    const int64_t total = (int64_t)N * HW * (C / 8);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy,
-                       (const bf16*)y, (const bf16*)x, stats, gsum, gamma, (bf16*)dx, (bf16*)dres, (int64_t)N, HW, C, G, eps, relu);
+                       (const bf16*)y, (const bf16*)x, stats, gamma, beta, dgamma, dbeta, gsum, HW, C, G, eps, relu, ppb);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(N, split), dim3(threads), 0, (hipStream_t)stream, (const bf16*)dy,
+                       (const bf16*)y, (const bf16*)x, stats, gsum, gamma, beta, (bf16*)dx, (bf16*)dres, HW, C, G, relu, ppb);
     return merlot_launch_status("merlot_groupnorm_bwd");
 }
 

@@ -447,7 +447,8 @@ class ResNetStemFn(torch.autograd.Function):
         def gn(x, name, relu=True, res=None):
             g_, b_ = store.p(name + '/gamma'), store.p(name + '/beta')
             y, stats = ops.groupnorm_fwd(x, g_, b_, res=res, relu=relu)
-            tape.append(('gn', name, x, y if relu else None, stats, relu, res is not None))
+            # the backward's ReLU mask: recomputed from x for a layer without a residual add (no second read of y), from y otherwise
+            tape.append(('gn', name, x, y if (relu and res is not None) else None, stats, relu, res is not None))
             return y
 
         def pool(x):
@@ -532,7 +533,7 @@ class ResNetStemFn(torch.autograd.Function):
         def gn_bwd(entry, dyg):
             _, name, x, y, stats, relu, has_res = entry
             dx, dres = ops.groupnorm_bwd(dyg.contiguous(), y, x, stats, store.p(name + '/gamma'), store.g(name + '/gamma'),
-                                         store.g(name + '/beta'), relu=relu, want_dres=has_res)
+                                         store.g(name + '/beta'), beta=store.p(name + '/beta'), relu=relu, want_dres=has_res)
             return dx, dres
 
         # walk the tape backwards; the bottleneck blocks need their two branches' gradients joined

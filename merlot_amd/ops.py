@@ -517,14 +517,16 @@ def groupnorm_fwd(x, gamma, beta, *, res=None, relu=True, groups=32, eps=1e-4):
     return y, stats
 
 
-def groupnorm_bwd(dy, y, x, stats, gamma, dgamma, dbeta, *, relu=True, want_dres=False, groups=32, eps=1e-4):
+def groupnorm_bwd(dy, y, x, stats, gamma, dgamma, dbeta, *, beta=None, relu=True, want_dres=False, groups=32, eps=1e-4):
+    """y = None with relu (layers without a residual add; needs beta): the ReLU mask is recomputed from x instead of read from y."""
     _chk(dy, BF16, 'dy'); _chk(x, BF16, 'x'); _chk(stats, F32, 'stats'); _chk(dgamma, F32, 'dgamma'); _chk(dbeta, F32, 'dbeta')
+    _chk(beta, F32, 'beta')
     N, H, W, C = x.shape
     assert dy.is_contiguous() and x.is_contiguous()
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
     gsum = torch.empty((N, groups, 2), device=x.device, dtype=F32)
-    call('merlot_groupnorm_bwd', _p(dy), _p(y), _p(x), _p(stats), _p(gamma), _p(dgamma), _p(dbeta), _p(gsum), _p(dx), _p(dres),
+    call('merlot_groupnorm_bwd', _p(dy), _p(y), _p(x), _p(stats), _p(gamma), _p(beta), _p(dgamma), _p(dbeta), _p(gsum), _p(dx), _p(dres),
          N, H, W, C, groups, float(eps), 1 if relu else 0, _stream())
     return dx, dres
 

@@ -408,15 +408,15 @@ def groupnorm_fwd(x, gamma, beta, *, res=None, relu=True, groups=32, eps=1e-4):
     return y.to(BF16), stats
 
 
-def groupnorm_bwd(dy, y, x, stats, gamma, dgamma, dbeta, *, relu=True, want_dres=False, groups=32, eps=1e-4):
+def groupnorm_bwd(dy, y, x, stats, gamma, dgamma, dbeta, *, beta=None, relu=True, want_dres=False, groups=32, eps=1e-4):
     N, H, W, C = x.shape
     cnt = H * W * (C // groups)
     mean, rstd = stats[..., 0], stats[..., 1]
     d = dy.float()
-    if relu:
-        d = d * (y.float() > 0)
     g = x.float().reshape(N, H * W, groups, C // groups)
     xhat = ((g - mean[:, None, :, None]) * rstd[:, None, :, None]).reshape(N, H, W, C)
+    if relu:                                               # y = None: the mask recomputed from x (layers without a residual add)
+        d = d * ((y.float() if y is not None else xhat * gamma + beta) > 0)
     dgamma += (d * xhat).sum((0, 1, 2))
     dbeta += d.sum((0, 1, 2))
     dg = (d * gamma).reshape(N, H * W, groups, C // groups)

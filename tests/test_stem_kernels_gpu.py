@@ -52,6 +52,14 @@ def test_groupnorm_forward_backward(ops, N, H, W, C, relu, res):
     assert rel_l2(dga.cpu(), dga_r) < 2e-3 and rel_l2(dbe.cpu(), dbe_r) < 2e-3
     if res:
         assert torch.equal(dres.cpu(), dres_ref)
+    if relu and not res:
+        # the product's path for such layers: no y, the ReLU mask recomputed from x with the forward's own expression -- the SAME
+        # gradients as with the stored output (a pre-activation within rounding of 0 could flip: none does on these inputs)
+        dga2, dbe2 = torch.zeros(C).cuda(), torch.zeros(C).cuda()
+        dx2, _ = ops.groupnorm_bwd(dy.cuda(), None, x.cuda(), stats, gamma.cuda(), dga2, dbe2, beta=beta.cuda(), relu=True)
+        assert rel_l2(dx2, dx) < 1e-4 and rel_l2(dga2, dga) < 1e-5 and rel_l2(dbe2, dbe) < 1e-5      # (sums by atomics: last bits)
+        with pytest.raises(Exception):                      # neither y nor beta: no way to form the mask
+            ops.groupnorm_bwd(dy.cuda(), None, x.cuda(), stats, gamma.cuda(), dga2, dbe2, relu=True)
 
 
 def test_avgpool2(ops):
