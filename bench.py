@@ -212,6 +212,7 @@ def main():
     ap.add_argument('--fp8-fc2', action='store_true', help='with --config 5: also run fc2 on e4m3 operands (its input needs a separate two-pass quantisation)')
     ap.add_argument('--resnet-stem', action='store_true',
                     help='NOT the headline config: swap the patch stem for the ResNet-hybrid stem of merlot.yaml:30 (resnet_layers [3, 4, 9])')
+    ap.add_argument('--explicit-conv', action='store_true', help='with --resnet-stem: the 3x3 convolutions on explicit im2col matrices (the path of rounds 1-3) instead of the implicit GEMM')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--cpu-baseline-worker', type=int, default=0, help=argparse.SUPPRESS)
@@ -282,6 +283,7 @@ def main():
         train_gflop = 3.0 * fwd_gflop_per_segment(384, 16)
     if args.resnet_stem:
         config.model['resnet_layers'] = [3, 4, 9]
+        config.model['resnet_implicit_conv'] = not args.explicit_conv
         train_gflop = TRAIN_GFLOP_PER_SEGMENT_RESNET
     trainer = Trainer(config, device, ctx, seed=0)
     batch = synthetic_batch(config, args.examples, device, seed=1234 + rank)
@@ -324,6 +326,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, fwd_elapsed = float(t[0].item()), float(t[1].item())
 
+    hbm = None
+    if device.type == 'cuda':
+        free_b, total_b = torch.cuda.mem_get_info(device)
+        hbm = {'peak_allocated_gb': torch.cuda.max_memory_allocated(device) / 1e9, 'peak_reserved_gb': torch.cuda.max_memory_reserved(device) / 1e9,
+               'device_total_gb': total_b / 1e9, 'device_free_after_gb': free_b / 1e9}
     if rank == 0:
         value = world * seg_per_gpu * args.steps / elapsed
         res = {
@@ -351,6 +358,8 @@ def main():
                              'model_flops_utilization': world * seg_per_gpu * fwd_steps / fwd_elapsed *
                              (train_gflop / 3.0) / 1e3 / (world * PEAK_BF16_TFLOPS)},
         }
+        if hbm is not None:
+            res['hbm'] = hbm                                 # rank 0's allocator peaks (torch caching allocator; RCCL's buffers are in `device_free_after`)
         if timer is not None:
             summ = timer.summary()
             f, t, n = summ.get('gemm_nt', (0.0, 1.0, 0))

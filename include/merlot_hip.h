@@ -33,7 +33,7 @@ typedef void* merlot_stream_t;
 
 /* Bumped whenever a signature of this header changes.  merlot_abi_version() returns the value the library was built with;
  * a binding must compare the two before its first call (merlot_amd/lib.py does, and refuses a mismatching library). */
-#define MERLOT_ABI_VERSION 5
+#define MERLOT_ABI_VERSION 6
 
 const char* merlot_last_error(void);
 int merlot_abi_version(void);
@@ -311,6 +311,16 @@ int merlot_im2col3x3(const void* x, void* out, int N, int H, int W, int C, int s
 /* input gradient of the same gather: dx[n][y][x][c] = sum over taps of dpatches[(n,yo,xo)][(ky,kx,c)]. */
 int merlot_col2im3x3(const void* dpatches, void* dx, int N, int H, int W, int C, int stride, int Kp,
                      merlot_stream_t stream);
+/* 3x3 convolution, stride 1, SAME padding, as an IMPLICIT GEMM (csrc/conv_gemm.hip): the gather of merlot_im2col3x3 happens in the
+ * kernel's LDS-DMA source addresses, no patch matrix is written.  Replaces tf.layers.conv2d(kernel 3, strides 1, padding SAME) of
+ * utils/vision_transformer.py:40-56 for C % 32 == 0 (every 3x3 convolution of the released stem except the root).
+ *   y[(n,yo,xo)][co] = sum over (ky,kx,c) of x[n][yo+ky-1][xo+kx-1][c] * w[co][(ky,kx,c)]
+ * x: [n_img,H,W,C] bf16; w: [Co, ldw] bf16 with ldw >= 9*C (the wb operand of merlot_weight_std_fwd); y: [n_img*H*W, ldy] bf16;
+ * Co % 8 == 0.  Same K order and MFMA sequence as merlot_im2col3x3 + merlot_gemm_bf16_nt on the same tile: bit-identical to it.
+ * The layer's input gradient is the same call on dY with w' = [C][(2-ky, 2-kx, co)] (taps flipped, channels swapped).
+ * `zeros`: >= 16 bytes of zeroed device memory, 16-B aligned (the source of a tap that leaves the image). */
+int merlot_conv3x3_bf16(const void* x, const void* w, int64_t ldw, void* y, int64_t ldy, int n_img, int H, int W, int C, int Co,
+                        const void* zeros, merlot_stream_t stream);
 /* Weight standardisation of the hybrid stem's kernels (utils/vision_transformer.py:52-56): per output channel over (kh, kw, ci),
  * population variance, eps 1e-5.  k: fp32 master, HWIO = [K, Co].  Writes khat fp32 [K, Co], rstd [Co], the NT operand
  * wb bf16 [Co, Kp] and the dgrad operand wbT bf16 [Kp, Cop] (paddings untouched: zero them once). */

@@ -7,7 +7,7 @@ set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable"
-SRCS="gemm attention layernorm elementwise index conv image fp8 jpeg"
+SRCS="gemm attention layernorm elementwise index conv conv_gemm image fp8 jpeg"
 HDRS="common.h gemm_ring.h gemm_p8.inc attention_res.inc attention_fb.inc ../../include/merlot_hip.h"
 
 newer() {  # newer <target> <deps...>: true when target is missing or older than a dependency

@@ -427,6 +427,7 @@ class ResNetStemFn(torch.autograd.Function):
         vs = 'vision_backbone/vision_transformer'
         rs = f'{vs}/resnet50lite'
         tape = []
+        implicit = bool(cfg.get('resnet_implicit_conv', True))
 
         def conv(x, name, stride=1, shift=0.0):
             w = store.p(name + '/kernel')
@@ -434,6 +435,11 @@ class ResNetStemFn(torch.autograd.Function):
             co = w.shape[3]
             khat, rstd, wb, wbT = ResNetStemFn._std_kernel(w)
             N, Hh, Ww, C = x.shape
+            if kh == 3 and implicit and stride == 1 and shift == 0.0 and C % 32 == 0 and co % 32 == 0:
+                # implicit GEMM (csrc/conv_gemm.hip): no patch matrix in HBM; the tape keeps x, the backward gathers from it
+                y = ops.conv3x3(x, wb, co)
+                tape.append(('conv', name, None, khat, rstd, wbT, (N, Hh, Ww, C), stride, kh, x))
+                return y
             if kh == 1:
                 a = x.reshape(N * Hh * Ww, C)
                 Ho, Wo = Hh, Ww
@@ -441,7 +447,7 @@ class ResNetStemFn(torch.autograd.Function):
                 a = ops.im2col3x3(x, stride, shift)
                 Ho, Wo = Hh // stride, Ww // stride
             y = ops.gemm_nt(a, wb).view(N, Ho, Wo, co)
-            tape.append(('conv', name, a, khat, rstd, wbT, (N, Hh, Ww, C), stride, kh))
+            tape.append(('conv', name, a, khat, rstd, wbT, (N, Hh, Ww, C), stride, kh, None))
             return y
 
         def gn(x, name, relu=True, res=None):
@@ -504,17 +510,26 @@ class ResNetStemFn(torch.autograd.Function):
         def conv_bwd(entry, dyc, need_dx=True, add=None):
             """`add` (1x1 convolutions only): a gradient of the convolution's INPUT arriving on another path (the bottleneck block's
             shortcut), added in the input-gradient GEMM's residual epilogue instead of by a separate pass over the tensor."""
-            _, name, a, khat, rstd, wbT, xshape, stride, kh = entry
+            _, name, a, khat, rstd, wbT, xshape, stride, kh, x_in = entry
             Nn, Hh, Ww, Cc = xshape
             co = khat.shape[1]
             dyf = dyc.reshape(-1, co)
+            if x_in is not None:                                                        # implicit 3x3: the patches exist for this GEMM only
+                a = ops.im2col3x3(x_in, 1, 0.0)
             dk = torch.zeros((co + (co % 2), a.shape[1]), device=dyf.device, dtype=F32)
             ops.gemm_tn(dyf, a, dk, accumulate=False, m=co + (co % 2))                 # dKhat^T [Co, Kp]
+            a = None
             # weight standardisation backward (khat = (k - mean) * rstd per output channel), accumulated into the arena
             gk = store.g(name + '/kernel')
             ops.weight_std_bwd(dk, khat, rstd, gk.view(khat.shape))
             if not need_dx:
                 return None
+            if x_in is not None:
+                # dX = the same convolution of dY with the taps flipped: w'[ci][(ky', kx', co)] = khat[(2-ky', 2-kx', ci), co]
+                # -- one fp32 accumulation over the nine taps, no [T, 9 C] product in HBM and no col2im pass over it
+                wdg = wbT[:9 * Cc, :co].reshape(3, 3, Cc, co).flip(0, 1).permute(2, 0, 1, 3).reshape(Cc, 9 * co).contiguous()
+                out = ops.conv3x3(dyc.reshape(Nn, Hh, Ww, co).contiguous(), wdg, Cc)
+                return out if add is None else out + add
             kp_co = wbT.shape[1]
             if kp_co != co:                                                             # pad the reduction dim to 64
                 dyp = torch.zeros((dyf.shape[0], kp_co), device=dyf.device, dtype=BF16)

@@ -498,6 +498,29 @@ def im2col3x3(x, stride=1, shift=0.0):
     return out
 
 
+_ZEROS = {}
+
+
+def _zero_page(device):
+    """64 zeroed bf16 on `device` (the source of a tap outside the image in merlot_conv3x3_bf16), allocated once per device."""
+    z = _ZEROS.get(device)
+    if z is None:
+        z = _ZEROS[device] = torch.zeros(64, device=device, dtype=BF16)
+    return z
+
+
+def conv3x3(x, w, co=None):
+    """3x3 / stride 1 / SAME convolution as an implicit GEMM: x [N,H,W,C] bf16 (C % 32 == 0), w [>= Co, ld >= 9*C] bf16 with
+    k = (ky, kx, c) -> y [N,H,W,Co] bf16.  Bit-identical to gemm_nt(im2col3x3(x), w) without the patch matrix in HBM."""
+    _chk(x, BF16, 'x'); _chk(w, BF16, 'w')
+    N, H, W, C = x.shape
+    Co = w.shape[0] if co is None else co
+    assert x.is_contiguous() and w.stride(1) == 1 and w.shape[0] >= Co and w.shape[1] >= 9 * C
+    y = torch.empty((N, H, W, Co), device=x.device, dtype=BF16)
+    call('merlot_conv3x3_bf16', _p(x), _p(w), w.stride(0), _p(y), Co, N, H, W, C, Co, _p(_zero_page(x.device)), _stream())
+    return y
+
+
 def col2im3x3(dpatches, N, H, W, C, stride=1):
     _chk(dpatches, BF16, 'dpatches')
     assert dpatches.is_contiguous()

@@ -69,7 +69,7 @@ def test_library_exports_every_declared_symbol():
     for name in lib.parse_header():
         assert hasattr(dll, name), f"{name} declared in include/merlot_hip.h but not exported"
     d = lib.LIB.load()
-    assert d.merlot_abi_version() == 5
+    assert d.merlot_abi_version() == 6
     assert d.merlot_last_error() is not None
 
 

@@ -197,10 +197,11 @@ def test_resnet_hybrid_stem_matches_oracle(emu):
     assert np.median(list(rels.values())) < 0.25
 
 
-def test_resnet_hybrid_stem_autograd_wiring_exact_in_fp32(emu, monkeypatch):
-    """The stem's host code (tape, branch joins, weight-standardisation backward, im2col / col2im plumbing) with every
-    emulated kernel and every cast switched to fp32: tokens and all 56 gradients must then agree with the fp32 oracle
-    to round-off."""
+@pytest.mark.parametrize('implicit', [True, False])
+def test_resnet_hybrid_stem_autograd_wiring_exact_in_fp32(emu, monkeypatch, implicit):
+    """The stem's host code (tape, branch joins, weight-standardisation backward, im2col / col2im plumbing resp. the implicit 3x3
+    convolution with its flipped-tap input gradient) with every emulated kernel and every cast switched to fp32: tokens and all 56
+    gradients must then agree with the fp32 oracle to round-off."""
     import emu_ops
     from merlot_amd import layers as L, ParamStore
     import merlot_amd.ops as real_ops
@@ -209,7 +210,7 @@ def test_resnet_hybrid_stem_autograd_wiring_exact_in_fp32(emu, monkeypatch):
     monkeypatch.setattr(real_ops, 'cast_bf16', lambda x, out=None: x.float() if out is None else out.copy_(x))
     emu_gemm_nt = real_ops.gemm_nt                           # its default out_dtype was bound to bf16 at definition
     monkeypatch.setattr(real_ops, 'gemm_nt', lambda *a, **k: emu_gemm_nt(*a, **{**{'out_dtype': torch.float32}, **k}))
-    cfg = tiny_config(resnet_layers=[1, 1, 2])
+    cfg = tiny_config(resnet_layers=[1, 1, 2], resnet_implicit_conv=implicit)
     w = mo.init_weights(cfg, 2)
     for t in w.values():
         t.requires_grad_(True)

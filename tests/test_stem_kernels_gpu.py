@@ -31,6 +31,44 @@ def test_im2col_and_col2im(ops, N, H, W, C, stride):
         assert rel_l2(dx, emu.col2im3x3(dp, N, H, W, C, stride)) < 3e-3
 
 
+@pytest.mark.parametrize('N,H,W,C,Co', [(2, 8, 8, 32, 32), (3, 12, 10, 64, 64), (1, 14, 14, 256, 256), (2, 9, 7, 128, 128),
+                                        (1, 56, 56, 64, 64), (2, 5, 33, 32, 64), (1, 3, 3, 64, 128), (2, 1, 1, 32, 32),
+                                        (1, 28, 28, 128, 256), (5, 7, 7, 96, 40)])
+def test_conv3x3_implicit_gemm_is_the_explicit_path_bit_for_bit(ops, N, H, W, C, Co):
+    """merlot_conv3x3_bf16 against merlot_im2col3x3 + merlot_gemm_bf16_nt (same K order, same MFMA sequence: equal bits) and
+    against the emulation; then the layer's input gradient -- the same kernel on dY with flipped taps -- against the explicit
+    dgrad (GEMM to [T, 9 C] in bf16, col2im sum): equal up to the bf16 rounding of the nine partial products."""
+    g = torch.Generator().manual_seed(N * 1000 + H * 10 + C)
+    x = torch.randn(N, H, W, C, generator=g).to(BF16)
+    Kp = (9 * C + 63) // 64 * 64
+    w = torch.zeros(Co, Kp, dtype=BF16)
+    w[:, :9 * C] = (torch.randn(Co, 9 * C, generator=g) / (3 * C ** 0.5)).to(BF16)
+    y = ops.conv3x3(x.cuda(), w.cuda(), Co)
+    y_explicit = ops.gemm_nt(ops.im2col3x3(x.cuda()), w.cuda()).view(N, H, W, Co)
+    assert torch.equal(y, y_explicit)
+    assert rel_l2(y.cpu(), emu.conv3x3(x, w, Co)) < 6e-3
+    if Co % 32 == 0:
+        dy = torch.randn(N, H, W, Co, generator=g).to(BF16)
+        wdg = w[:, :9 * C].reshape(Co, 3, 3, C).flip(1, 2).permute(3, 1, 2, 0).reshape(C, 9 * Co).contiguous()
+        dx = ops.conv3x3(dy.cuda(), wdg.cuda(), C).cpu()
+        wT = torch.zeros(Kp, (Co + 63) // 64 * 64, dtype=BF16)
+        wT[:9 * C, :Co] = w[:, :9 * C].t()
+        dyp = torch.zeros(N * H * W, wT.shape[1], dtype=BF16)
+        dyp[:, :Co] = dy.reshape(-1, Co)
+        dx_explicit = emu.col2im3x3(emu.gemm_nt(dyp, wT), N, H, W, C)
+        assert rel_l2(dx, dx_explicit) < 4e-3
+        ref = torch.nn.functional.conv_transpose2d(dy.float().permute(0, 3, 1, 2),
+                                                   w[:, :9 * C].float().reshape(Co, 3, 3, C).permute(0, 3, 1, 2), padding=1)
+        assert rel_l2(dx, ref.permute(0, 2, 3, 1)) < 3e-3
+
+
+def test_conv3x3_rejects_what_the_kernel_cannot_take(ops):
+    from merlot_amd.lib import MerlotHipError
+    x = torch.zeros(1, 4, 4, 24, dtype=BF16).cuda()
+    with pytest.raises(MerlotHipError, match='multiple of 32'):
+        ops.conv3x3(x, torch.zeros(32, 9 * 24, dtype=BF16).cuda(), 32)
+
+
 @pytest.mark.parametrize('N,H,W,C,relu,res', [(3, 8, 8, 32, True, False), (2, 14, 14, 256, False, False),
                                                (2, 7, 9, 1024, True, True), (4, 16, 16, 64, True, False)])
 def test_groupnorm_forward_backward(ops, N, H, W, C, relu, res):

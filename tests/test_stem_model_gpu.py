@@ -38,9 +38,11 @@ def test_hip_resnet_stem_matches_reference_program_forward():
     assert rel_l2(tok, ref) < 6e-2            # the reference program's fp32 graph (bf16 policy alone moves it ~4 %)
 
 
-def test_hip_model_with_resnet_stem_forward_backward():
+@pytest.mark.parametrize('implicit', [True, False])
+def test_hip_model_with_resnet_stem_forward_backward(implicit):
+    """implicit: the 3x3 convolutions as implicit GEMMs (csrc/conv_gemm.hip, the default); False: on explicit im2col matrices."""
     from merlot_amd import MerlotModel, ParamStore
-    cfg = tiny_config(resnet_layers=[1, 1, 2])
+    cfg = tiny_config(resnet_layers=[1, 1, 2], resnet_implicit_conv=implicit)
     w = mo.init_weights(cfg, 2)
     for t in w.values():
         t.requires_grad_(True)
