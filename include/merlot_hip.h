@@ -321,6 +321,14 @@ int merlot_col2im3x3(const void* dpatches, void* dx, int N, int H, int W, int C,
  * `zeros`: >= 16 bytes of zeroed device memory, 16-B aligned (the source of a tap that leaves the image). */
 int merlot_conv3x3_bf16(const void* x, const void* w, int64_t ldw, void* y, int64_t ldy, int n_img, int H, int W, int C, int Co,
                         const void* zeros, merlot_stream_t stream);
+/* Weight gradient of the same layer, implicit as well (no patch matrix): dw[co][(ky,kx,c)] (+)= sum over pixels of
+ * dy[pix][co] * x[pix shifted by the tap][c], fp32 [Co, lddw], lddw >= 9*C.  dy: [n_img*H*W, lddy] bf16.  The pixel axis is split over
+ * workgroups; partial tiles go to `workspace` (merlot_conv3x3_wgrad_workspace_bytes(), fp32, 16-B aligned, caller-owned) and are folded
+ * without atomics, like merlot_gemm_bf16_tn.  Replaces the kernel gradient of tf.layers.conv2d (utils/vision_transformer.py:40-56). */
+int64_t merlot_conv3x3_wgrad_workspace_bytes(int n_img, int H, int W, int C, int Co);
+int merlot_conv3x3_wgrad_bf16(const void* dy, int64_t lddy, const void* x, float* dw, int64_t lddw, int n_img, int H, int W, int C,
+                              int Co, int accumulate, const void* zeros, void* workspace, int64_t workspace_bytes,
+                              merlot_stream_t stream);
 /* Weight standardisation of the hybrid stem's kernels (utils/vision_transformer.py:52-56): per output channel over (kh, kw, ci),
  * population variance, eps 1e-5.  k: fp32 master, HWIO = [K, Co].  Writes khat fp32 [K, Co], rstd [Co], the NT operand
  * wb bf16 [Co, Kp] and the dgrad operand wbT bf16 [Kp, Cop] (paddings untouched: zero them once). */

@@ -514,11 +514,12 @@ class ResNetStemFn(torch.autograd.Function):
             Nn, Hh, Ww, Cc = xshape
             co = khat.shape[1]
             dyf = dyc.reshape(-1, co)
-            if x_in is not None:                                                        # implicit 3x3: the patches exist for this GEMM only
-                a = ops.im2col3x3(x_in, 1, 0.0)
-            dk = torch.zeros((co + (co % 2), a.shape[1]), device=dyf.device, dtype=F32)
-            ops.gemm_tn(dyf, a, dk, accumulate=False, m=co + (co % 2))                 # dKhat^T [Co, Kp]
-            a = None
+            if x_in is not None:                                                        # implicit 3x3: gathered from x, no patch matrix
+                dk = torch.zeros((co, wbT.shape[0]), device=dyf.device, dtype=F32)       # dKhat^T [Co, Kp], padding columns stay 0
+                ops.conv3x3_wgrad(dyf, x_in, dk)
+            else:
+                dk = torch.zeros((co + (co % 2), a.shape[1]), device=dyf.device, dtype=F32)
+                ops.gemm_tn(dyf, a, dk, accumulate=False, m=co + (co % 2))             # dKhat^T [Co, Kp]
             # weight standardisation backward (khat = (k - mean) * rstd per output channel), accumulated into the arena
             gk = store.g(name + '/kernel')
             ops.weight_std_bwd(dk, khat, rstd, gk.view(khat.shape))

@@ -521,6 +521,21 @@ def conv3x3(x, w, co=None):
     return y
 
 
+def conv3x3_wgrad(dy, x, dw, accumulate=False):
+    """Kernel gradient of conv3x3 without the patch matrix: dw[co][(ky,kx,c)] (+)= sum_pixels dy[pix][co] * x[pix + tap][c].
+    dy [N*H*W, Co] bf16 (row stride % 8 == 0), x [N,H,W,C] bf16, dw fp32 [>= Co, ld >= 9*C]."""
+    _chk(dy, BF16, 'dy'); _chk(x, BF16, 'x'); _chk(dw, F32, 'dw')
+    N, H, W, C = x.shape
+    Co = dy.shape[1]
+    assert x.is_contiguous() and dy.stride(1) == 1 and dw.stride(1) == 1 and dy.shape[0] == N * H * W
+    assert dw.shape[0] >= Co and dw.shape[1] >= 9 * C
+    nbytes = LIB.query('merlot_conv3x3_wgrad_workspace_bytes', N, H, W, C, Co)
+    ws = torch.empty(nbytes // 4, device=x.device, dtype=F32) if nbytes else None       # caller-owned partial tiles of the pixel ranges
+    call('merlot_conv3x3_wgrad_bf16', _p(dy), dy.stride(0), _p(x), _p(dw), dw.stride(0), N, H, W, C, Co, 1 if accumulate else 0,
+         _p(_zero_page(x.device)), _p(ws), nbytes, _stream())
+    return dw
+
+
 def col2im3x3(dpatches, N, H, W, C, stride=1):
     _chk(dpatches, BF16, 'dpatches')
     assert dpatches.is_contiguous()

@@ -28,8 +28,12 @@ for (H, C, Co) in ((112, 32, 32), (112, 32, 64), (56, 64, 64), (56, 128, 128), (
     t_fe = bench(lambda: ops.gemm_nt(ops.im2col3x3(x), w), 10)
     t_bi = bench(lambda: ops.conv3x3(dy, wdg, C), 10)
     t_be = bench(lambda: ops.col2im3x3(ops.gemm_nt(dyp, wT), N, H, H, C), 10)
+    dw = torch.zeros(Co, Kp, device='cuda')
+    dy2 = dy.reshape(-1, Co)
+    t_wi = bench(lambda: ops.conv3x3_wgrad(dy2, x, dw), 10)
+    t_we = bench(lambda: ops.gemm_tn(dy2, ops.im2col3x3(x), dw, accumulate=False), 10)
     gf = 2.0 * N * H * H * 9 * C * Co / 1e9
     print(f'[{N} x {H}^2] {C:3d} -> {Co:3d}: forward implicit {t_fi:7.1f} us ({gf / t_fi * 1e3:5.0f} TFLOP/s) explicit {t_fe:7.1f} us | '
-          f'input gradient implicit {t_bi:7.1f} us explicit {t_be:7.1f} us | forward bits equal: {same}', flush=True)
+          f'input gradient implicit {t_bi:7.1f} us explicit {t_be:7.1f} us | weight gradient implicit {t_wi:7.1f} us ({gf / t_wi * 1e3:5.0f} TFLOP/s) explicit (im2col + gemm_tn) {t_we:7.1f} us | forward bits equal: {same}', flush=True)
     del x, dy, dyp
     torch.cuda.empty_cache()

@@ -385,6 +385,17 @@ def conv3x3(x, w, co=None):
     return (a[:, :9 * C].float() @ w[:Co, :9 * C].float().t()).to(BF16).view(N, H, W, Co)
 
 
+def conv3x3_wgrad(dy, x, dw, accumulate=False):
+    N, H, W, C = x.shape
+    Co = dy.shape[1]
+    g = dy.float().t() @ im2col3x3(x)[:, :9 * C].float()
+    if accumulate:
+        dw[:Co, :9 * C] += g
+    else:
+        dw[:Co, :9 * C] = g
+    return dw
+
+
 def col2im3x3(dpatches, N, H, W, C, stride=1):
     L = (H // stride) * (W // stride)
     cols = dpatches[:, :9 * C].float().reshape(N, L, 9, C).permute(0, 3, 2, 1).reshape(N, C * 9, L)
@@ -509,7 +520,7 @@ def weight_std_bwd(dkhat_t, khat, rstd, gk2d):
 _NAMES = ['weight_std_fwd', 'weight_std_bwd', 'gemm_nt', 'gemm_tn', 'patch_embed_fwd', 'patch_embed_wgrad', 'ln_fwd', 'ln_bwd', 'attention_fwd',
           'attention_bwd', 'attention_colsum', 'cast_bf16', 'cast_transpose_bf16', 'colsum_bf16', 'gather_add4',
           'scatter_add_rows', 'dropout_apply', 'cls_avgpool_fwd', 'cls_avgpool_bwd', 'softmax_ce', 'vocab_ce', 'l2norm_fwd',
-          'l2norm_bwd', 'gelu_fwd', 'gelu_bwd', 'mask_inputs', 'temporal_labels', 'shuffled_idx', 'im2col3x3', 'col2im3x3', 'conv3x3',
+          'l2norm_bwd', 'gelu_fwd', 'gelu_bwd', 'mask_inputs', 'temporal_labels', 'shuffled_idx', 'im2col3x3', 'col2im3x3', 'conv3x3', 'conv3x3_wgrad',
           'groupnorm_fwd', 'groupnorm_bwd', 'avgpool2_fwd', 'avgpool2_bwd', 'cast_transpose_batched', 'image_frames', 'adamw_step']
 
 

@@ -62,6 +62,28 @@ def test_conv3x3_implicit_gemm_is_the_explicit_path_bit_for_bit(ops, N, H, W, C,
         assert rel_l2(dx, ref.permute(0, 2, 3, 1)) < 3e-3
 
 
+@pytest.mark.parametrize('N,H,W,C,Co', [(2, 8, 8, 32, 32), (3, 12, 10, 64, 64), (1, 14, 14, 256, 256), (2, 9, 7, 128, 136),
+                                        (4, 56, 56, 64, 64), (2, 5, 33, 32, 64), (1, 3, 3, 64, 128), (2, 1, 1, 32, 32),
+                                        (16, 28, 28, 128, 256), (5, 7, 7, 96, 40)])
+def test_conv3x3_implicit_weight_gradient(ops, N, H, W, C, Co):
+    """merlot_conv3x3_wgrad_bf16 (no patch matrix; pixel counts that are not multiples of 32, images narrower than a K-step, ragged
+    filter counts, many pixel ranges) against dy^T @ im2col(x) in fp32 and against the explicit HIP path; accumulate on top."""
+    g = torch.Generator().manual_seed(N * 1000 + H * 10 + C)
+    x = torch.randn(N, H, W, C, generator=g).to(BF16)
+    dy = torch.randn(N * H * W, Co, generator=g).to(BF16)
+    Kp = (9 * C + 63) // 64 * 64
+    ref = dy.float().t() @ emu.im2col3x3(x)[:, :9 * C].float()
+    dw = torch.full((Co, Kp), 7.0, device='cuda')
+    ops.conv3x3_wgrad(dy.cuda(), x.cuda(), dw)
+    assert rel_l2(dw[:, :9 * C].cpu(), ref) < 2e-6
+    assert torch.all(dw[:, 9 * C:] == 7.0)                       # padding columns untouched
+    ex = torch.zeros((Co + Co % 2, Kp), device='cuda')
+    ops.gemm_tn(dy.cuda(), ops.im2col3x3(x.cuda()), ex, accumulate=False, m=Co + Co % 2) if Co % 2 == 0 else None
+    assert rel_l2(dw[:, :9 * C], ex[:Co, :9 * C]) < 2e-6
+    ops.conv3x3_wgrad(dy.cuda(), x.cuda(), dw, accumulate=True)
+    assert rel_l2(dw[:, :9 * C].cpu(), 2 * ref) < 2e-6
+
+
 def test_conv3x3_rejects_what_the_kernel_cannot_take(ops):
     from merlot_amd.lib import MerlotHipError
     x = torch.zeros(1, 4, 4, 24, dtype=BF16).cuda()
