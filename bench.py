@@ -233,7 +233,7 @@ def main():
     from merlot_amd.train import Trainer, synthetic_batch
 
     if args.examples is None:
-        args.examples = 48 if args.config == 5 else (64 if args.resnet_stem else 128)   # the hybrid stem keeps ~10x the activations per frame (32 / 48 / 64 examples: 2 300 / 2 411 / 2 504 segments/s, profiles/r04_i_retire_persist.txt)
+        args.examples = 48 if args.config == 5 else ((64 if args.explicit_conv else 80) if args.resnet_stem else 128)   # the hybrid stem keeps several times the activations per frame (implicit 3x3 convolutions, 64 / 80 / 96 examples: 2 952 / 3 011 / 3 040 segments/s at 165 / 206 / 246 GB, profiles/r04_v_stem_batch.txt)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))

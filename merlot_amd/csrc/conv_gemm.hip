@@ -441,13 +441,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
 }
 
 using ConvW = ring::Cfg<2, 4, 2, 2, 32, 3>;       // 128 filters x 256 patch columns, 8 waves, two workgroups per CU
+using ConvW64 = ring::Cfg<1, 4, 2, 2, 32, 3>;     // 64 filters x 256 patch columns, 4 waves (the 32 / 64-filter layers at 112^2 and 56^2)
 
 struct ConvWgradPlan {
-    int ntm, ntn, splits, rchunk;
+    int bm, ntm, ntn, splits, rchunk;
 };
 ConvWgradPlan conv_wgrad_plan(int64_t T, int C, int Co) {
     ConvWgradPlan pl;
-    pl.ntm = cdiv(Co, ConvW::BM);
+    pl.bm = Co <= 64 ? ConvW64::BM : ConvW::BM;
+    pl.ntm = cdiv(Co, pl.bm);
     pl.ntn = cdiv(9 * C, ConvW::BN);
     const int tiles = pl.ntm * pl.ntn;
     const int ksteps = cdiv(T, ConvW::BK);
@@ -517,9 +519,15 @@ extern "C" int merlot_conv3x3_wgrad_bf16(const void* dy, int64_t lddy, const voi
     a.ntm = pl.ntm; a.ntn = pl.ntn; a.splits = pl.splits; a.rchunk = pl.rchunk;
     a.accumulate = accumulate;
     hipStream_t s = (hipStream_t)stream;
-    auto kern = conv3x3_wgrad_ring_kernel<ConvW>;
-    MERLOT_ENSURE_LDS(kern, ConvW::LDS_BYTES, "merlot_conv3x3_wgrad_bf16");
-    hipLaunchKernelGGL(kern, dim3(pl.ntm * pl.ntn * pl.splits), dim3(ConvW::NT), ConvW::LDS_BYTES, s, a, (float*)workspace);
+    if (pl.bm == ConvW64::BM) {
+        auto kern = conv3x3_wgrad_ring_kernel<ConvW64>;
+        MERLOT_ENSURE_LDS(kern, ConvW64::LDS_BYTES, "merlot_conv3x3_wgrad_bf16");
+        hipLaunchKernelGGL(kern, dim3(pl.ntm * pl.ntn * pl.splits), dim3(ConvW64::NT), ConvW64::LDS_BYTES, s, a, (float*)workspace);
+    } else {
+        auto kern = conv3x3_wgrad_ring_kernel<ConvW>;
+        MERLOT_ENSURE_LDS(kern, ConvW::LDS_BYTES, "merlot_conv3x3_wgrad_bf16");
+        hipLaunchKernelGGL(kern, dim3(pl.ntm * pl.ntn * pl.splits), dim3(ConvW::NT), ConvW::LDS_BYTES, s, a, (float*)workspace);
+    }
     if (pl.splits > 1) {
         const int64_t total = (int64_t)a.M * (a.N / 4);
         int grid = (int)((total + 255) / 256);
