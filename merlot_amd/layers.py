@@ -406,9 +406,11 @@ class ResNetStemFn(torch.autograd.Function):
     """ResNet-hybrid stem (utils/vision_transformer.py:114-170, 206-223): image NHWC bf16 ->
     [n_img*h1*w1, H] bf16 tokens, the drop-in for PatchEmbedFn when `resnet_layers` is set.
 
-    Convolutions run on the MFMA GEMMs: 1x1 directly on the [N*H*W, C] activations, 3x3 on an im2col matrix
-    (`merlot_im2col3x3`, dgrad through `merlot_col2im3x3`); GroupNorm + ReLU (+ the bottleneck's residual add) and the
-    2x2 average pools are the kernels of csrc/conv.hip.  Kernels are weight-standardised (:52-56) from the fp32 masters
+    Convolutions run on the MFMA GEMMs: 1x1 directly on the [N*H*W, C] activations, 3x3 (stride 1, C % 32 == 0: all but the
+    root) as implicit GEMMs -- `merlot_conv3x3_bf16` forward and, with flipped taps, input gradient, `merlot_conv3x3_wgrad_bf16`
+    weight gradient; no patch matrix -- or, for the 3-channel stride-2 root and with `model.resnet_implicit_conv: false`, on an
+    im2col matrix (`merlot_im2col3x3`, dgrad through `merlot_col2im3x3`); GroupNorm + ReLU (+ the bottleneck's residual add)
+    and the 2x2 average pools are the kernels of csrc/conv.hip.  Kernels are weight-standardised (:52-56) from the fp32 masters
     every step -- a few MB of parameters, done with torch ops on the device -- and the standardisation is
     back-propagated into the master gradient.  Activations saved for the backward: conv inputs (or their im2col
     matrices), conv outputs, GroupNorm statistics and outputs.
