@@ -38,6 +38,44 @@ def test_hip_resnet_stem_matches_reference_program_forward():
     assert rel_l2(tok, ref) < 6e-2            # the reference program's fp32 graph (bf16 policy alone moves it ~4 %)
 
 
+@pytest.mark.parametrize('size', [64, 96])
+def test_implicit_and_explicit_convolutions_agree_through_the_whole_stem(size):
+    """The stem with its 3x3 convolutions as implicit GEMMs against the same stem on explicit im2col matrices.  Each convolution is
+    equal bits (tests/test_stem_kernels_gpu.py), but the GroupNorm statistics are summed with fp32 atomics, so two runs of the SAME
+    path already differ by a bf16 ulp here and there: the tokens of the two paths must agree as well as two runs of one path do;
+    the 56 gradients differ in addition by the input gradient's single fp32 accumulation over the taps (explicit: nine bf16 partial
+    products) and the weight gradient's split over pixel ranges."""
+    from merlot_amd import ParamStore
+    from merlot_amd import layers as L
+    toks, grads = [], []
+    g = torch.Generator().manual_seed(size)
+    image = torch.rand(8, size, size, 3, generator=g).to(torch.bfloat16).cuda()
+    cot = None
+    for implicit in (True, True, False):
+        cfg = tiny_config(resnet_layers=[1, 1, 2], image_size=[size, size], resnet_implicit_conv=implicit)
+        w = mo.init_weights(cfg, seed=3, perturb=True)
+        st = ParamStore(cfg, 'cuda', seed=0)
+        st.load_tf_weights(w)
+        st.refresh(True)
+        st.zero_grad()
+        tok = L.ResNetStemFn.apply(image, st, cfg, torch.zeros(1, device='cuda', requires_grad=True))
+        if cot is None:
+            cot = torch.randn(tok.shape, generator=torch.Generator().manual_seed(1)).to(torch.bfloat16).cuda()
+        (tok.float() * cot.float()).sum().backward()
+        torch.cuda.synchronize()
+        toks.append(tok.detach().clone())
+        grads.append({k: v.clone() for k, v in st.export_tf_grads().items() if 'resnet50lite' in k or 'conv_postresnet_proj' in k})
+    noise = rel_l2(toks[0], toks[1])                                    # implicit vs implicit: the atomics' summation order
+    assert rel_l2(toks[0], toks[2]) < max(3 * noise, 2e-3), (rel_l2(toks[0], toks[2]), noise)
+    assert len(grads[0]) == 56
+    gnoise = {k: rel_l2(grads[0][k], grads[1][k]) for k in grads[0]}
+    rels = {k: rel_l2(grads[0][k], grads[2][k]) for k in grads[0]}
+    print('tokens: noise %.2e implicit vs explicit %.2e; gradients: noise median %.2e max %.2e, implicit vs explicit median %.2e max %.2e'
+          % (noise, rel_l2(toks[0], toks[2]), np.median(list(gnoise.values())), max(gnoise.values()), np.median(list(rels.values())), max(rels.values())))
+    assert max(rels.values()) < max(3 * max(gnoise.values()), 3e-2) and np.median(list(rels.values())) < max(3 * np.median(list(gnoise.values())), 1e-2), \
+        sorted(rels.items(), key=lambda kv: -kv[1])[:5]
+
+
 @pytest.mark.parametrize('implicit', [True, False])
 def test_hip_model_with_resnet_stem_forward_backward(implicit):
     """implicit: the 3x3 convolutions as implicit GEMMs (csrc/conv_gemm.hip, the default); False: on explicit im2col matrices."""
