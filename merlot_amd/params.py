@@ -20,11 +20,24 @@ from . import ops
 
 class Lin(object):
     """Handle of one Linear: fp32 master + grad views, bf16 straight ([out,in]) and transposed ([in,out]) copies."""
-    __slots__ = ('name', 'w', 'b', 'gw', 'gb', 'wb', 'wbT', 'ld_wbT')
+    __slots__ = ('name', 'w', 'b', 'gw', 'gb', 'wb', '_wbT', '_store', 'ld_wbT')
 
-    def __init__(self, name):
+    def __init__(self, name, store=None):
         self.name = name
-        self.w = self.b = self.gw = self.gb = self.wb = self.wbT = None
+        self.w = self.b = self.gw = self.gb = self.wb = self._wbT = None
+        self._store = store
+
+    @property
+    def wbT(self):
+        """the transposed bf16 copy; Linears registered since the last refresh get theirs in ONE batched launch at the first read
+        (a model's first forward registers ~100 of them: one launch, not one launch over the growing table per registration)."""
+        if self._store is not None and self._store._t_dirty:
+            self._store._flush_transposed()
+        return self._wbT
+
+    @wbT.setter
+    def wbT(self, v):
+        self._wbT = v
 
 
 class LN(object):
@@ -143,6 +156,7 @@ class ParamStore(object):
         self.bf16 = torch.zeros(off, device=self.device, dtype=torch.bfloat16)
         self._tflat = self._tjobs = None      # flat buffer of transposed bf16 copies + device job table
         self._ttiles = self._tjobs_n = 0
+        self._t_dirty = False                 # Linears registered since the transposed copies were last written
         self._lins = {}
         self._lns = {}
         self.version = -1       # bumped by refresh(); compared with master_version
@@ -200,8 +214,9 @@ class ParamStore(object):
             return
         ops.cast_bf16(self.master, self.bf16)
         if self._lins:
-            if self._tjobs is None or self._tjobs_n != len(self._lins):
+            if self._tjobs is None or self._tjobs_n != len(self._lins) or self._t_dirty:
                 self._build_transpose_jobs()
+            self._t_dirty = False
             ops.cast_transpose_batched(self.master, self._tflat, self._tjobs, self._ttiles)
         self.version = self.master_version
 
@@ -226,8 +241,9 @@ class ParamStore(object):
         for name, (o, in_dim, ld) in views.items():
             self._lins[name].wbT = self._tflat[o:o + in_dim * ld].view(in_dim, ld)
 
-    def _make_transposed(self, name, lin):
-        """a Linear registered after the last refresh: rebuild the table (rare) and fill every copy."""
+    def _flush_transposed(self):
+        """Linears were registered after the last refresh: rebuild the table and fill every copy (one launch)."""
+        self._t_dirty = False
         self._build_transpose_jobs()
         ops.cast_transpose_batched(self.master, self._tflat, self._tjobs, self._ttiles)
 
@@ -236,7 +252,7 @@ class ParamStore(object):
         key = scope + '/kernel' if (scope + '/kernel') in self.offsets else scope
         h = self._lins.get(key) if need_T else None
         if h is None:
-            h = Lin(key)
+            h = Lin(key, self)
             h.w, h.gw, h.wb = self.p(key), self.g(key), self.b16(key)
             bname = scope + '/bias'
             if bias and bname in self.offsets:
@@ -244,7 +260,7 @@ class ParamStore(object):
             if need_T:
                 self._lins[key] = h
                 if self.version >= 0:
-                    self._make_transposed(key, h)
+                    self._t_dirty = True                     # its transposed copy is made at the first read of any .wbT
         return h
 
     def ln(self, scope):
