@@ -337,6 +337,14 @@ int merlot_weight_std_fwd(const float* k, int K, int Co, float* khat, float* rst
 /* gk[K, Co] += rstd * (dkhat - mean_K(dkhat) - khat * mean_K(dkhat * khat)); dkhat_t = the wgrad GEMM's output, [Co, ld]. */
 int merlot_weight_std_bwd(const float* dkhat_t, int64_t ld, const float* khat, const float* rstd, int K, int Co, float* gk,
                           merlot_stream_t stream);
+/* Every kernel of the stem in ONE launch each way (52 kernels of a few KB to a few MB).  jobs: device int64 table, offsets in elements
+ * from the respective base.  Forward job = {k, K, Co, khat, rstd, wb, Kp, wbT, Cop, wdg (< 0: none), Cin, first block}; wdg (3x3 kernels) is
+ * the operand of the input gradient as an implicit convolution of dY: wdg[ci][(2-ky, 2-kx, co)] = khat[(ky,kx,ci)][co], bf16 [Cin, 9 Co].
+ * Backward job = {dkhat_t, ld, khat, rstd, K, Co, gk, first block}; total_blocks = sum over jobs of ceil(Co / 16). */
+int merlot_weight_std_fwd_batched(const float* k_base, const void* jobs, int njobs, int64_t total_blocks, float* khat_base,
+                                  float* rstd_base, void* wb_base, void* wbT_base, void* wdg_base, merlot_stream_t stream);
+int merlot_weight_std_bwd_batched(const float* dk_base, const void* jobs, int njobs, int64_t total_blocks, const float* khat_base,
+                                  const float* rstd_base, float* gk_base, merlot_stream_t stream);
 /* y = [relu]( (x - mean) * rsqrt(var + eps) * gamma + beta [+ res] ), moments per (sample, group) over (H, W, C/G) from
  * one pass (var = E[x^2] - E[x]^2, :196-201).  stats: f32 [N, G, 2] = {mean, rsqrt(var + eps)}, written here, kept
  * for the backward.  res may be NULL. */

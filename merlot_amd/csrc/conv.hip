@@ -490,12 +490,14 @@ __device__ __forceinline__ float ws_reduce(float v, float (&red)[WS_K][WS_C], in
     for (int i = 0; i < WS_K; ++i) t += red[i][cl];
     return t;
 }
-__global__ __launch_bounds__(256) void weight_std_fwd_kernel(const float* __restrict__ k, int K, int Co, float* __restrict__ khat,
-                                                             float* __restrict__ rstd_out, bf16* __restrict__ wb, int Kp,
-                                                             bf16* __restrict__ wbT, int Cop) {
-    __shared__ float red[WS_K][WS_C];
+// wdg (3x3 kernels only, else null): the operand of the layer's INPUT gradient as an implicit convolution of dY (csrc/conv_gemm.hip):
+// wdg[ci][(2-ky, 2-kx, co)] = khat[(ky, kx, ci)][co], bf16 [Cin, 9 Co]
+__device__ __forceinline__ void weight_std_fwd_body(const float* __restrict__ k, int K, int Co, float* __restrict__ khat,
+                                                    float* __restrict__ rstd_out, bf16* __restrict__ wb, int Kp,
+                                                    bf16* __restrict__ wbT, int Cop, bf16* __restrict__ wdg, int Cin, int blk,
+                                                    float (&red)[WS_K][WS_C]) {
     const int cl = threadIdx.x & 15, kl = threadIdx.x >> 4;
-    const int c = blockIdx.x * WS_C + cl;
+    const int c = blk * WS_C + cl;
     const bool live = c < Co;
     const int cc = live ? c : Co - 1;
     float s = 0.f;
@@ -518,16 +520,47 @@ __global__ __launch_bounds__(256) void weight_std_fwd_kernel(const float* __rest
         khat[(int64_t)r * Co + c] = v;
         wb[(int64_t)c * Kp + r] = (bf16)v;
         wbT[(int64_t)r * Cop + c] = (bf16)v;
+        if (wdg) {
+            const int tap = r / Cin, ci = r - tap * Cin;
+            wdg[(int64_t)ci * (9 * Co) + (8 - tap) * Co + c] = (bf16)v;
+        }
     }
+}
+__global__ __launch_bounds__(256) void weight_std_fwd_kernel(const float* __restrict__ k, int K, int Co, float* __restrict__ khat,
+                                                             float* __restrict__ rstd_out, bf16* __restrict__ wb, int Kp,
+                                                             bf16* __restrict__ wbT, int Cop) {
+    __shared__ float red[WS_K][WS_C];
+    weight_std_fwd_body(k, K, Co, khat, rstd_out, wb, Kp, wbT, Cop, nullptr, 1, blockIdx.x, red);
+}
+// every kernel of the stem in ONE launch (52 kernels of a few KB to a few MB: 52 launches of 18 us each otherwise).  Job j = 12 int64:
+// {k offset, K, Co, khat offset, rstd offset, wb offset, Kp, wbT offset, Cop, wdg offset (< 0: none), Cin, first block}; offsets in
+// elements from the respective base; a block finds its job by binary search on the first-block column.
+constexpr int WS_JOB = 12;
+__device__ __forceinline__ const int64_t* ws_find_job(const int64_t* __restrict__ jobs, int njobs, int stride, int first_col, int64_t b) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {                                    // last job whose first block <= b
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid * stride + first_col] <= b) lo = mid; else hi = mid - 1;
+    }
+    return jobs + lo * stride;
+}
+__global__ __launch_bounds__(256) void weight_std_fwd_batched_kernel(const float* __restrict__ k_base, const int64_t* __restrict__ jobs,
+                                                                     int njobs, float* __restrict__ khat_base,
+                                                                     float* __restrict__ rstd_base, bf16* __restrict__ wb_base,
+                                                                     bf16* __restrict__ wbT_base, bf16* __restrict__ wdg_base) {
+    __shared__ float red[WS_K][WS_C];
+    const int64_t* j = ws_find_job(jobs, njobs, WS_JOB, 11, blockIdx.x);
+    weight_std_fwd_body(k_base + j[0], (int)j[1], (int)j[2], khat_base + j[3], rstd_base + j[4], wb_base + j[5], (int)j[6],
+                        wbT_base + j[7], (int)j[8], j[9] >= 0 ? wdg_base + j[9] : nullptr, (int)j[10], (int)(blockIdx.x - j[11]), red);
 }
 
 // dk = rstd * (dkhat - mean_K(dkhat) - khat * mean_K(dkhat * khat)), accumulated into the gradient arena.
 // dkhat is read TRANSPOSED from the wgrad GEMM's output [Co(+pad), ld] (row = channel, K contiguous).
-__global__ __launch_bounds__(256) void weight_std_bwd_kernel(const float* __restrict__ dkt, int64_t ld, const float* __restrict__ khat,
-                                                             const float* __restrict__ rstd, int K, int Co, float* __restrict__ gk) {
-    __shared__ float red[WS_K][WS_C];
+__device__ __forceinline__ void weight_std_bwd_body(const float* __restrict__ dkt, int64_t ld, const float* __restrict__ khat,
+                                                    const float* __restrict__ rstd, int K, int Co, float* __restrict__ gk, int blk,
+                                                    float (&red)[WS_K][WS_C]) {
     const int cl = threadIdx.x & 15, kl = threadIdx.x >> 4;
-    const int c = blockIdx.x * WS_C + cl;
+    const int c = blk * WS_C + cl;
     const bool live = c < Co;
     const int cc = live ? c : Co - 1;
     float s1 = 0.f, s2 = 0.f;
@@ -545,6 +578,21 @@ __global__ __launch_bounds__(256) void weight_std_bwd_kernel(const float* __rest
     for (int r = kl; r < K; r += WS_K)
         gk[(int64_t)r * Co + c] += rs * (dkt[(int64_t)c * ld + r] - m1 - khat[(int64_t)r * Co + c] * m2);
 }
+__global__ __launch_bounds__(256) void weight_std_bwd_kernel(const float* __restrict__ dkt, int64_t ld, const float* __restrict__ khat,
+                                                             const float* __restrict__ rstd, int K, int Co, float* __restrict__ gk) {
+    __shared__ float red[WS_K][WS_C];
+    weight_std_bwd_body(dkt, ld, khat, rstd, K, Co, gk, blockIdx.x, red);
+}
+// job j = 8 int64: {dk offset, ld, khat offset, rstd offset, K, Co, gk offset, first block}
+constexpr int WS_BJOB = 8;
+__global__ __launch_bounds__(256) void weight_std_bwd_batched_kernel(const float* __restrict__ dk_base, const int64_t* __restrict__ jobs,
+                                                                     int njobs, const float* __restrict__ khat_base,
+                                                                     const float* __restrict__ rstd_base, float* __restrict__ gk_base) {
+    __shared__ float red[WS_K][WS_C];
+    const int64_t* j = ws_find_job(jobs, njobs, WS_BJOB, 7, blockIdx.x);
+    weight_std_bwd_body(dk_base + j[0], j[1], khat_base + j[2], rstd_base + j[3], (int)j[4], (int)j[5], gk_base + j[6],
+                        (int)(blockIdx.x - j[7]), red);
+}
 }  // namespace
 
 extern "C" int merlot_weight_std_fwd(const float* k, int K, int Co, float* khat, float* rstd, void* wb, int Kp, void* wbT, int Cop,
@@ -560,4 +608,22 @@ extern "C" int merlot_weight_std_bwd(const float* dkhat_t, int64_t ld, const flo
     MERLOT_CHECK(dkhat_t && khat && rstd && gk && K > 0 && Co > 0 && ld >= K, MERLOT_ESHAPE, "merlot_weight_std_bwd: bad arguments");
     hipLaunchKernelGGL(weight_std_bwd_kernel, dim3((Co + WS_C - 1) / WS_C), dim3(256), 0, (hipStream_t)stream, dkhat_t, ld, khat, rstd, K, Co, gk);
     return merlot_launch_status("merlot_weight_std_bwd");
+}
+
+extern "C" int merlot_weight_std_fwd_batched(const float* k_base, const void* jobs, int njobs, int64_t total_blocks, float* khat_base,
+                                             float* rstd_base, void* wb_base, void* wbT_base, void* wdg_base, merlot_stream_t stream) {
+    MERLOT_CHECK(k_base && jobs && njobs > 0 && total_blocks > 0 && total_blocks < (1ll << 31) && khat_base && rstd_base && wb_base && wbT_base,
+                 MERLOT_ESHAPE, "merlot_weight_std_fwd_batched: bad arguments");
+    hipLaunchKernelGGL(weight_std_fwd_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, k_base,
+                       (const int64_t*)jobs, njobs, khat_base, rstd_base, (bf16*)wb_base, (bf16*)wbT_base, (bf16*)wdg_base);
+    return merlot_launch_status("merlot_weight_std_fwd_batched");
+}
+
+extern "C" int merlot_weight_std_bwd_batched(const float* dk_base, const void* jobs, int njobs, int64_t total_blocks, const float* khat_base,
+                                             const float* rstd_base, float* gk_base, merlot_stream_t stream) {
+    MERLOT_CHECK(dk_base && jobs && njobs > 0 && total_blocks > 0 && total_blocks < (1ll << 31) && khat_base && rstd_base && gk_base,
+                 MERLOT_ESHAPE, "merlot_weight_std_bwd_batched: bad arguments");
+    hipLaunchKernelGGL(weight_std_bwd_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, dk_base,
+                       (const int64_t*)jobs, njobs, khat_base, rstd_base, gk_base);
+    return merlot_launch_status("merlot_weight_std_bwd_batched");
 }

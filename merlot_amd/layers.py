@@ -402,6 +402,63 @@ class PatchEmbedFn(torch.autograd.Function):
         return None, None, None, None
 
 
+class StemWeights(object):
+    """Every convolution kernel of the ResNet-hybrid stem, weight-standardised (utils/vision_transformer.py:52-56) in ONE launch per
+    forward and back-propagated into the master gradients in ONE launch per backward (`merlot_weight_std_fwd_batched` /
+    `_bwd_batched`: 52 kernels of a few KB to a few MB were 52 launches of 18 / 34 us each way).  Per kernel: khat fp32 [K, Co], rstd [Co],
+    wb bf16 [Co, Kp] (NT operand), wbT bf16 [Kp, Cop] (1x1 input-gradient operand), for 3x3 kernels wdg bf16 [Cin, 9 Co] (the
+    input-gradient operand of the implicit convolution: taps flipped), and dk fp32 [Co (+1), Kp], the slot the layer's weight-gradient
+    GEMM writes.  Flat buffers allocated once; paddings are zero from the allocation and never written."""
+
+    def __init__(self, store, scope):
+        self.store = store
+        names = [n for n, (_, _, shp) in store.offsets.items() if n.startswith(scope + '/') and n.endswith('/kernel') and len(shp) == 4]
+        dev = store.device
+        fj, bj, self.meta = [], [], {}
+        o = dict(khat=0, rstd=0, wb=0, wbT=0, wdg=0, dk=0)
+        blocks = 0
+        for name in names:
+            off, _, (kh, kw, ci, co) = store.offsets[name]
+            K = kh * kw * ci
+            Kp, Cop, co2 = (K + 63) // 64 * 64, (co + 63) // 64 * 64, co + co % 2
+            dg = o['wdg'] if kh == 3 and ci % 8 == 0 else -1
+            self.meta[name] = (K, co, Kp, Cop, ci, co2, dict(o), dg)
+            fj.append([off, K, co, o['khat'], o['rstd'], o['wb'], Kp, o['wbT'], Cop, dg, ci, blocks])
+            bj.append([o['dk'], Kp, o['khat'], o['rstd'], K, co, off, blocks])
+            blocks += (co + 15) // 16
+            o['khat'] += K * co
+            o['rstd'] += (co + 7) // 8 * 8
+            o['wb'] += co * Kp
+            o['wbT'] += Kp * Cop
+            o['dk'] += co2 * Kp
+            if dg >= 0:
+                o['wdg'] += 9 * ci * co
+        self.blocks = blocks
+        self.khat = torch.zeros(o['khat'], device=dev, dtype=F32)
+        self.rstd = torch.zeros(o['rstd'], device=dev, dtype=F32)
+        self.wb = torch.zeros(o['wb'], device=dev, dtype=BF16)
+        self.wbT = torch.zeros(o['wbT'], device=dev, dtype=BF16)
+        self.wdg = torch.zeros(max(o['wdg'], 8), device=dev, dtype=BF16)
+        self.dk = torch.zeros(o['dk'], device=dev, dtype=F32)
+        self.fjobs = torch.tensor(fj, dtype=torch.int64).to(dev)
+        self.bjobs = torch.tensor(bj, dtype=torch.int64).to(dev)
+
+    def standardise(self):
+        ops.weight_std_fwd_batched(self.store.master, self.fjobs, self.blocks, self.khat, self.rstd, self.wb, self.wbT, self.wdg)
+
+    def backward(self):
+        """store.grad[kernel] += the standardisation's backward of every dk slot (call once, after the last weight-gradient GEMM)."""
+        ops.weight_std_bwd_batched(self.dk, self.bjobs, self.blocks, self.khat, self.rstd, self.store.grad)
+
+    def get(self, name):
+        """-> khat [K, Co], wb [Co, Kp], wbT [Kp, Cop], wdg [Cin, 9 Co] or None, dk [Co (+1), Kp]"""
+        K, co, Kp, Cop, ci, co2, o, dg = self.meta[name]
+        return (self.khat[o['khat']:o['khat'] + K * co].view(K, co), self.wb[o['wb']:o['wb'] + co * Kp].view(co, Kp),
+                self.wbT[o['wbT']:o['wbT'] + Kp * Cop].view(Kp, Cop),
+                self.wdg[dg:dg + 9 * ci * co].view(ci, 9 * co) if dg >= 0 else None,
+                self.dk[o['dk']:o['dk'] + co2 * Kp].view(co2, Kp))
+
+
 class ResNetStemFn(torch.autograd.Function):
     """ResNet-hybrid stem (utils/vision_transformer.py:114-170, 206-223): image NHWC bf16 ->
     [n_img*h1*w1, H] bf16 tokens, the drop-in for PatchEmbedFn when `resnet_layers` is set.
@@ -417,30 +474,25 @@ class ResNetStemFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def _std_kernel(w_hwio):
-        """utils/vision_transformer.py:52-56 (merlot_weight_std_fwd): khat fp32 [K, Co], rstd [Co], the NT operand [Co, Kp] and the
-        dgrad operand [Kp, Co(+pad)] in bf16, reduction dims padded to 64."""
-        kh, kw, ci, co = w_hwio.shape
-        K = kh * kw * ci
-        return ops.weight_std_fwd(w_hwio.reshape(K, co), (K + 63) // 64 * 64, (co + 63) // 64 * 64)
-
-    @staticmethod
     def forward(ctx, image, store, cfg, anchor):
         vs = 'vision_backbone/vision_transformer'
         rs = f'{vs}/resnet50lite'
         tape = []
         implicit = bool(cfg.get('resnet_implicit_conv', True))
 
+        sw = getattr(store, '_stem_weights', None)
+        if sw is None:
+            sw = store._stem_weights = StemWeights(store, rs)
+        sw.standardise()                                  # every kernel of the stem: one launch
+
         def conv(x, name, stride=1, shift=0.0):
-            w = store.p(name + '/kernel')
-            kh = w.shape[0]
-            co = w.shape[3]
-            khat, rstd, wb, wbT = ResNetStemFn._std_kernel(w)
+            kh, _, _, co = store.offsets[name + '/kernel'][2]
+            khat, wb, wbT, wdg, dk = sw.get(name + '/kernel')
             N, Hh, Ww, C = x.shape
             if kh == 3 and implicit and stride == 1 and shift == 0.0 and C % 32 == 0 and co % 32 == 0:
                 # implicit GEMM (csrc/conv_gemm.hip): no patch matrix in HBM; the tape keeps x, the backward gathers from it
                 y = ops.conv3x3(x, wb, co)
-                tape.append(('conv', name, None, khat, rstd, wbT, (N, Hh, Ww, C), stride, kh, x))
+                tape.append(('conv', name, None, khat, (wdg, dk), wbT, (N, Hh, Ww, C), stride, kh, x))
                 return y
             if kh == 1:
                 a = x.reshape(N * Hh * Ww, C)
@@ -449,7 +501,7 @@ class ResNetStemFn(torch.autograd.Function):
                 a = ops.im2col3x3(x, stride, shift)
                 Ho, Wo = Hh // stride, Ww // stride
             y = ops.gemm_nt(a, wb).view(N, Ho, Wo, co)
-            tape.append(('conv', name, a, khat, rstd, wbT, (N, Hh, Ww, C), stride, kh, None))
+            tape.append(('conv', name, a, khat, (wdg, dk), wbT, (N, Hh, Ww, C), stride, kh, None))
             return y
 
         def gn(x, name, relu=True, res=None):
@@ -497,7 +549,7 @@ class ResNetStemFn(torch.autograd.Function):
         lin = store.lin(f'{vs}/conv_postresnet_proj')
         a = c.reshape(N * h1 * w1, C)
         out = ops.gemm_nt(a, lin.wb, bias=lin.b)
-        ctx.tape, ctx.store, ctx.lin, ctx.a_final, ctx.c_shape = tape, store, lin, a, (N, h1, w1, C)
+        ctx.tape, ctx.store, ctx.lin, ctx.a_final, ctx.c_shape, ctx.sw = tape, store, lin, a, (N, h1, w1, C), sw
         return out
 
     @staticmethod
@@ -512,25 +564,21 @@ class ResNetStemFn(torch.autograd.Function):
         def conv_bwd(entry, dyc, need_dx=True, add=None):
             """`add` (1x1 convolutions only): a gradient of the convolution's INPUT arriving on another path (the bottleneck block's
             shortcut), added in the input-gradient GEMM's residual epilogue instead of by a separate pass over the tensor."""
-            _, name, a, khat, rstd, wbT, xshape, stride, kh, x_in = entry
+            _, name, a, khat, (wdg, dk), wbT, xshape, stride, kh, x_in = entry
             Nn, Hh, Ww, Cc = xshape
             co = khat.shape[1]
             dyf = dyc.reshape(-1, co)
+            # dKhat^T [Co, Kp] into this kernel's slot of the stem's dk buffer; the weight standardisation's backward (khat = (k - mean) *
+            # rstd per output channel) runs once for all kernels at the end of the stem's backward (StemWeights.backward)
             if x_in is not None:                                                        # implicit 3x3: gathered from x, no patch matrix
-                dk = torch.zeros((co, wbT.shape[0]), device=dyf.device, dtype=F32)       # dKhat^T [Co, Kp], padding columns stay 0
                 ops.conv3x3_wgrad(dyf, x_in, dk)
             else:
-                dk = torch.zeros((co + (co % 2), a.shape[1]), device=dyf.device, dtype=F32)
-                ops.gemm_tn(dyf, a, dk, accumulate=False, m=co + (co % 2))             # dKhat^T [Co, Kp]
-            # weight standardisation backward (khat = (k - mean) * rstd per output channel), accumulated into the arena
-            gk = store.g(name + '/kernel')
-            ops.weight_std_bwd(dk, khat, rstd, gk.view(khat.shape))
+                ops.gemm_tn(dyf, a, dk, accumulate=False, m=co + (co % 2))
             if not need_dx:
                 return None
             if x_in is not None:
-                # dX = the same convolution of dY with the taps flipped: w'[ci][(ky', kx', co)] = khat[(2-ky', 2-kx', ci), co]
+                # dX = the same convolution of dY with the taps flipped: wdg[ci][(ky', kx', co)] = khat[(2-ky', 2-kx', ci), co]
                 # -- one fp32 accumulation over the nine taps, no [T, 9 C] product in HBM and no col2im pass over it
-                wdg = wbT[:9 * Cc, :co].reshape(3, 3, Cc, co).flip(0, 1).permute(2, 0, 1, 3).reshape(Cc, 9 * co).contiguous()
                 out = ops.conv3x3(dyc.reshape(Nn, Hh, Ww, co).contiguous(), wdg, Cc)
                 return out if add is None else out + add
             kp_co = wbT.shape[1]
@@ -591,6 +639,7 @@ class ResNetStemFn(torch.autograd.Function):
             e = pop(); d, _ = gn_bwd(e, d)
             d = conv_bwd(pop(), d, need_dx=(j < 2))
         assert i == -1
+        ctx.sw.backward()                                # every kernel's gradient through the standardisation: one launch
         store.notify_ready('vision_backbone/vision_transformer/resnet50lite')
         ctx.tape = None
         return None, None, None, None

@@ -632,6 +632,19 @@ def weight_std_fwd(k2d, Kp, Cop):
     return khat, rstd, wb, wbT
 
 
+def weight_std_fwd_batched(k_base, jobs, total_blocks, khat, rstd, wb, wbT, wdg):
+    """every job of `jobs` (device int64 [n, 12], include/merlot_hip.h) in one launch: the standardised kernels of a whole stem."""
+    _chk(k_base, F32, 'k_base'); _chk(khat, F32, 'khat'); _chk(rstd, F32, 'rstd'); _chk(wb, BF16, 'wb'); _chk(wbT, BF16, 'wbT'); _chk(wdg, BF16, 'wdg')
+    call('merlot_weight_std_fwd_batched', _p(k_base), _p(jobs), jobs.shape[0], int(total_blocks), _p(khat), _p(rstd), _p(wb), _p(wbT),
+         _p(wdg), _stream())
+
+
+def weight_std_bwd_batched(dk, jobs, total_blocks, khat, rstd, gk_base):
+    """gk_base[job's offset] += the standardisation's backward of every job's dkhat_t (device int64 [n, 8]) in one launch."""
+    _chk(dk, F32, 'dk'); _chk(khat, F32, 'khat'); _chk(rstd, F32, 'rstd'); _chk(gk_base, F32, 'gk_base')
+    call('merlot_weight_std_bwd_batched', _p(dk), _p(jobs), jobs.shape[0], int(total_blocks), _p(khat), _p(rstd), _p(gk_base), _stream())
+
+
 def weight_std_bwd(dkhat_t, khat, rstd, gk2d):
     """gk2d [K, Co] (a view of the gradient arena) += the standardisation's backward of dkhat_t [Co(+pad), ld >= K]."""
     _chk(dkhat_t, F32, 'dkhat_t'); _chk(khat, F32, 'khat'); _chk(rstd, F32, 'rstd'); _chk(gk2d, F32, 'gk2d')

@@ -517,7 +517,26 @@ def weight_std_bwd(dkhat_t, khat, rstd, gk2d):
     gk2d.add_(rstd[None, :] * (dkh - dkh.mean(0, keepdim=True) - khat * (dkh * khat).mean(0, keepdim=True)))
 
 
-_NAMES = ['weight_std_fwd', 'weight_std_bwd', 'gemm_nt', 'gemm_tn', 'patch_embed_fwd', 'patch_embed_wgrad', 'ln_fwd', 'ln_bwd', 'attention_fwd',
+def weight_std_fwd_batched(k_base, jobs, total_blocks, khat, rstd, wb, wbT, wdg):
+    for (ko, K, Co, o_khat, o_rstd, o_wb, Kp, o_wbT, Cop, o_wdg, Cin, _) in jobs.tolist():
+        kh, rs, b, bT = weight_std_fwd(k_base[ko:ko + K * Co].view(K, Co), Kp, Cop)
+        khat[o_khat:o_khat + K * Co] = kh.reshape(-1)
+        rstd[o_rstd:o_rstd + Co] = rs
+        wb[o_wb:o_wb + Co * Kp] = b.reshape(-1).to(wb.dtype)
+        wbT[o_wbT:o_wbT + Kp * Cop] = bT.reshape(-1).to(wbT.dtype)
+        if o_wdg >= 0:
+            v = bT[:K, :Co].reshape(3, 3, Cin, Co).flip(0, 1).permute(2, 0, 1, 3).reshape(-1)
+            wdg[o_wdg:o_wdg + 9 * Cin * Co] = v.to(wdg.dtype)
+
+
+def weight_std_bwd_batched(dk, jobs, total_blocks, khat, rstd, gk_base):
+    for (o_dk, ld, o_khat, o_rstd, K, Co, o_gk, _) in jobs.tolist():
+        rows = (dk.numel() - o_dk) // ld
+        weight_std_bwd(dk[o_dk:o_dk + min(rows, Co + Co % 2) * ld].view(-1, ld), khat[o_khat:o_khat + K * Co].view(K, Co),
+                       rstd[o_rstd:o_rstd + Co], gk_base[o_gk:o_gk + K * Co].view(K, Co))
+
+
+_NAMES = ['weight_std_fwd', 'weight_std_bwd', 'weight_std_fwd_batched', 'weight_std_bwd_batched', 'gemm_nt', 'gemm_tn', 'patch_embed_fwd', 'patch_embed_wgrad', 'ln_fwd', 'ln_bwd', 'attention_fwd',
           'attention_bwd', 'attention_colsum', 'cast_bf16', 'cast_transpose_bf16', 'colsum_bf16', 'gather_add4',
           'scatter_add_rows', 'dropout_apply', 'cls_avgpool_fwd', 'cls_avgpool_bwd', 'softmax_ce', 'vocab_ce', 'l2norm_fwd',
           'l2norm_bwd', 'gelu_fwd', 'gelu_bwd', 'mask_inputs', 'temporal_labels', 'shuffled_idx', 'im2col3x3', 'col2im3x3', 'conv3x3', 'conv3x3_wgrad',

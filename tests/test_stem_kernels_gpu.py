@@ -154,3 +154,47 @@ def test_weight_standardisation_kernels(kh, ci, co):
     gk = torch.full((K, co), 0.5).cuda()
     ops.weight_std_bwd(dkt.cuda(), khat, rstd, gk)
     assert (gk.cpu() - 0.5 - k2.grad).abs().max().item() < 1e-4 * max(1.0, float(k2.grad.abs().max()))
+
+
+def test_batched_weight_standardisation_is_the_per_kernel_launch_bit_for_bit(ops):
+    """merlot_weight_std_fwd_batched / _bwd_batched (every kernel of a stem in one launch) against one merlot_weight_std_fwd / _bwd
+    launch per kernel: equal bits; the flipped-tap input-gradient operand wdg against torch's flip / permute of wbT."""
+    g = torch.Generator().manual_seed(5)
+    shapes = [(3, 3, 3, 32), (3, 3, 32, 32), (1, 1, 64, 256), (3, 3, 64, 64), (1, 1, 256, 72), (3, 3, 32, 40)]
+    offs, o = [], 0
+    for shp in shapes:
+        n = shp[0] * shp[1] * shp[2] * shp[3]
+        offs.append(o)
+        o += (n + 63) // 64 * 64
+    master = torch.randn(o, generator=g).cuda()
+    fj, bj, meta = [], [], []
+    q = dict(khat=0, rstd=0, wb=0, wbT=0, wdg=0, dk=0)
+    blocks = 0
+    for (kh, kw, ci, co), off in zip(shapes, offs):
+        K = kh * kw * ci
+        Kp, Cop, co2 = (K + 63) // 64 * 64, (co + 63) // 64 * 64, co + co % 2
+        dg = q['wdg'] if kh == 3 and ci % 8 == 0 else -1
+        meta.append((K, co, Kp, Cop, ci, co2, dict(q), dg, off))
+        fj.append([off, K, co, q['khat'], q['rstd'], q['wb'], Kp, q['wbT'], Cop, dg, ci, blocks])
+        bj.append([q['dk'], Kp, q['khat'], q['rstd'], K, co, off, blocks])
+        blocks += (co + 15) // 16
+        q['khat'] += K * co; q['rstd'] += (co + 7) // 8 * 8; q['wb'] += co * Kp; q['wbT'] += Kp * Cop; q['dk'] += co2 * Kp
+        if dg >= 0:
+            q['wdg'] += 9 * ci * co
+    khat = torch.zeros(q['khat']).cuda(); rstd = torch.zeros(q['rstd']).cuda()
+    wb = torch.zeros(q['wb'], dtype=BF16).cuda(); wbT = torch.zeros(q['wbT'], dtype=BF16).cuda(); wdg = torch.zeros(q['wdg'], dtype=BF16).cuda()
+    ops.weight_std_fwd_batched(master, torch.tensor(fj).cuda(), blocks, khat, rstd, wb, wbT, wdg)
+    dk = torch.randn(q['dk'], generator=g).cuda()
+    grad = torch.randn(master.shape, generator=g).cuda()
+    grad_ref = grad.clone()
+    ops.weight_std_bwd_batched(dk, torch.tensor(bj).cuda(), blocks, khat, rstd, grad)
+    for (K, co, Kp, Cop, ci, co2, oo, dg, off) in meta:
+        kh1, rs1, wb1, wbT1 = ops.weight_std_fwd(master[off:off + K * co].view(K, co), Kp, Cop)
+        assert torch.equal(khat[oo['khat']:oo['khat'] + K * co].view(K, co), kh1) and torch.equal(rstd[oo['rstd']:oo['rstd'] + co], rs1)
+        assert torch.equal(wb[oo['wb']:oo['wb'] + co * Kp].view(co, Kp), wb1) and torch.equal(wbT[oo['wbT']:oo['wbT'] + Kp * Cop].view(Kp, Cop), wbT1)
+        if dg >= 0:
+            ref = wbT1[:K, :co].reshape(3, 3, ci, co).flip(0, 1).permute(2, 0, 1, 3).reshape(ci, 9 * co)
+            assert torch.equal(wdg[dg:dg + 9 * ci * co].view(ci, 9 * co), ref)
+        gk = grad_ref[off:off + K * co].view(K, co)
+        ops.weight_std_bwd(dk[oo['dk']:oo['dk'] + co2 * Kp].view(co2, Kp), kh1, rs1, gk)
+        assert torch.equal(grad[off:off + K * co].view(K, co), gk)
