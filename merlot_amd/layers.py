@@ -334,20 +334,26 @@ class GatherAddFn(torch.autograd.Function):
     def backward(ctx, dout):
         dout = dout.contiguous()
         H = ctx.H
+        reds = {}                                            # one reduction per period, shared by the tables that repeat with it
         for ent in ctx.tables:
             tab, gtab, idx = ent[0], ent[1], ent[2]
             period = ent[3] if len(ent) > 3 else None
             if period is not None and dout.shape[0] > period:
                 # the index pattern repeats every `period` rows (position tables): reduce over the repeats first, so
                 # the scatter issues `period` rows of atomics instead of one per token (fp32 atomics are slow here)
-                red = dout.view(-1, period, H).sum(0)
-                ops.scatter_add_rows(red, idx[:period].contiguous(), gtab.view(-1, H))
+                if period not in reds:
+                    reds[period] = dout.view(-1, period, H).sum(0)
+                ops.scatter_add_rows(reds[period], idx[:period].contiguous(), gtab.view(-1, H))
             else:
                 ops.scatter_add_rows(dout, idx, gtab.view(-1, H))
         dact = None
         if ctx.act_shape is not None and ctx.needs_input_grad[0]:
             if ctx.act_idx is None:
                 dact = dout.view(ctx.act_shape).to(ctx.act_dtype)
+            elif isinstance(ctx.act_inv, tuple):
+                # source row (n, j) sits at output row n * period + skip + j: the gradient is a strided slice, cast in ONE pass
+                period, skip = ctx.act_inv
+                dact = dout.view(-1, period, H)[:, skip:].to(ctx.act_dtype).reshape(ctx.act_shape)
             elif ctx.act_inv is not None:
                 # injective placement (every source row lands in exactly one output row): the gradient is a GATHER
                 dact = dout.index_select(0, ctx.act_inv).view(ctx.act_shape).to(ctx.act_dtype)
@@ -363,23 +369,50 @@ class GatherAddFn(torch.autograd.Function):
 
 def gather_add(act, act_idx, tables, rows, H, anchor, act_inv=None):
     """`anchor`: the store's dummy requires-grad tensor, so a gather of parameters only is still a graph root.
-    `act_inv` (optional, int64): for an injective act_idx, the output row each source row was placed in."""
+    `act_inv` (optional): for an injective act_idx, the output row each source row was placed in (int64 tensor), or the tuple
+    (period, skip) when source row (n, j) sits at output row n * period + skip + j."""
     return GatherAddFn.apply(act, act_idx, tables, rows, H, anchor, act_inv)
 
 
+class SplitHiddenFn(torch.autograd.Function):
+    """The joint encoder's output [B, S, H] bf16 -> one f32 tensor [B, end - start, H] per piece (model/modeling.py:184: the hidden states
+    handed to the heads, cast to f32).  One node instead of a slice + cast per piece: the backward writes every piece's gradient into ITS
+    slice of one bf16 buffer (a cast-copy per piece) where autograd's slice nodes would each zero-fill a full [B, S, H] tensor, copy their
+    slice in and add the results."""
+
+    @staticmethod
+    def forward(ctx, enc3, bounds):
+        ctx.shape, ctx.bounds, ctx.dtype = enc3.shape, bounds, enc3.dtype
+        return tuple(enc3[:, s:e].float() for s, e in bounds)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        # (autograd materialises the gradient of an unused piece as zeros; the pieces tile [0, S))
+        d = torch.empty(ctx.shape, device=douts[0].device, dtype=ctx.dtype)
+        assert sum(e - s for s, e in ctx.bounds) == ctx.shape[1]
+        for (s, e), g in zip(ctx.bounds, douts):
+            d[:, s:e].copy_(g)
+        return d, None
+
+
 class ClsAvgPoolFn(torch.autograd.Function):
-    """[n_img, S, H] bf16 ViT output -> f32 [n_img, 1 + h2*w2, H] = [cls slot 0 ; 2x2 avg-pooled grid]."""
+    """[n_img, S, H] bf16 ViT output -> (f32 [n_img, 1 + h2*w2, H] = [cls slot 0 ; 2x2 avg-pooled grid], f32 [n_img, H] = the tokens of
+    row `extra_row` (the contrastive head's image representation, model/modeling.py:99)).  Both consumers of the ViT output in ONE node:
+    a separate `hs[:, 1].float()` costs the backward a zero-filled [n_img, S, H] tensor and a full-size add to join two rows."""
 
     @staticmethod
-    def forward(ctx, x, n_img, h1, w1, cls_skip, pool):
-        ctx.args = (n_img, h1, w1, cls_skip, pool)
-        return ops.cls_avgpool_fwd(x.contiguous(), n_img, h1, w1, cls_skip, pool)
+    def forward(ctx, x, n_img, h1, w1, cls_skip, pool, extra_row):
+        ctx.args = (n_img, h1, w1, cls_skip, pool, extra_row)
+        x = x.contiguous()
+        return ops.cls_avgpool_fwd(x, n_img, h1, w1, cls_skip, pool), x.view(n_img, cls_skip + h1 * w1, -1)[:, extra_row].float()
 
     @staticmethod
-    def backward(ctx, dout):
-        n_img, h1, w1, cls_skip, pool = ctx.args
+    def backward(ctx, dout, dextra):
+        n_img, h1, w1, cls_skip, pool, extra_row = ctx.args
         dx = ops.cls_avgpool_bwd(dout.contiguous(), n_img, h1, w1, cls_skip, pool)
-        return dx.view(n_img * (cls_skip + h1 * w1), -1), None, None, None, None, None
+        if dextra is not None:
+            dx[:, extra_row] += dextra.to(dx.dtype)
+        return dx.view(n_img * (cls_skip + h1 * w1), -1), None, None, None, None, None, None
 
 
 class PatchEmbedFn(torch.autograd.Function):

@@ -171,7 +171,7 @@ class MerlotModel(object):
         else:
             conv = L.PatchEmbedFn.apply(image, st.lin(f'{vs}/conv2d', need_T=False), Pz, self._anchor)
         idx_conv, idx_cls, idx_pos = self._vit_prologue_indices(N, h1, w1, ncls)
-        conv_inv = (torch.arange(N, device=dev)[:, None] * Sv + ncls + torch.arange(h1 * w1, device=dev)[None]).reshape(-1)
+        conv_inv = (Sv, ncls)                             # patch j of frame n sits at row n * Sv + ncls + j
         x = L.gather_add(conv, idx_conv,
                          [(st.p(f'{vs}/pos_embs/cls_emb'), st.g(f'{vs}/pos_embs/cls_emb'), idx_cls, Sv),
                           (st.p(f'{vs}/pos_embs/pos_embs'), st.g(f'{vs}/pos_embs/pos_embs'), idx_pos, Sv)],
@@ -185,8 +185,7 @@ class MerlotModel(object):
         sp = cfg['spatial_pool_size']
         h2, w2 = h1 // sp, w1 // sp
         self.vision_transformer_info = {'hidden_state': hs3, 'cls': hs3[:, :ncls], 'num_h': h2, 'num_w': w2}
-        self.img_trg_h = hs3[:, 1].float()                                        # :99
-        feats = L.ClsAvgPoolFn.apply(hs, N, h1, w1, ncls, sp)                     # [N, vl, H] f32   :101-105
+        feats, self.img_trg_h = L.ClsAvgPoolFn.apply(hs, N, h1, w1, ncls, sp, 1)  # [N, vl, H] f32 :101-105, hs3[:, 1] f32 :99
         self.vision_transformer_info['seq'] = feats[:, 1:]
         vl = self.viz_chunk_length
         idx_img, idx_fcls, idx_fpos = self._final_pe_indices(N, h2, w2, shuffled_idx_img)
@@ -242,13 +241,13 @@ class MerlotModel(object):
                                   is_valid.to(torch.uint8).contiguous(), opts)
         enc3 = enc.view(self.B, Sj, H)
         self.encoder_info = {'hidden_state': enc3, '_hidden_state_flat': enc}
-        self.encoder_hidden_states = {}
         cur = 0
         for p in self.encoder_pieces:
             p['start'] = cur
             p['end'] = cur + p['x'].shape[1]
             cur = p['end']
-            self.encoder_hidden_states[p['name']] = enc3[:, p['start']:p['end']].float()     # :184
+        pieces = L.SplitHiddenFn.apply(enc3, tuple((p['start'], p['end']) for p in self.encoder_pieces))   # :184, f32
+        self.encoder_hidden_states = {p['name']: t for p, t in zip(self.encoder_pieces, pieces)}
 
         if log_attention_probs:
             if not (opts['log_in_backward'] and encoder_input.requires_grad):
