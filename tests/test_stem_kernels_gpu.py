@@ -33,7 +33,7 @@ def test_im2col_and_col2im(ops, N, H, W, C, stride):
 
 @pytest.mark.parametrize('N,H,W,C,Co', [(2, 8, 8, 32, 32), (3, 12, 10, 64, 64), (1, 14, 14, 256, 256), (2, 9, 7, 128, 128),
                                         (1, 56, 56, 64, 64), (2, 5, 33, 32, 64), (1, 3, 3, 64, 128), (2, 1, 1, 32, 32),
-                                        (1, 28, 28, 128, 256), (5, 7, 7, 96, 40)])
+                                        (1, 28, 28, 128, 256), (5, 7, 7, 96, 40), (1, 6, 6, 64, 512), (2, 4, 4, 512, 64)])
 def test_conv3x3_implicit_gemm_is_the_explicit_path_bit_for_bit(ops, N, H, W, C, Co):
     """merlot_conv3x3_bf16 against merlot_im2col3x3 + merlot_gemm_bf16_nt (same K order, same MFMA sequence: equal bits) and
     against the emulation; then the layer's input gradient -- the same kernel on dY with flipped taps -- against the explicit
@@ -64,7 +64,7 @@ def test_conv3x3_implicit_gemm_is_the_explicit_path_bit_for_bit(ops, N, H, W, C,
 
 @pytest.mark.parametrize('N,H,W,C,Co', [(2, 8, 8, 32, 32), (3, 12, 10, 64, 64), (1, 14, 14, 256, 256), (2, 9, 7, 128, 136),
                                         (4, 56, 56, 64, 64), (2, 5, 33, 32, 64), (1, 3, 3, 64, 128), (2, 1, 1, 32, 32),
-                                        (16, 28, 28, 128, 256), (5, 7, 7, 96, 40)])
+                                        (16, 28, 28, 128, 256), (5, 7, 7, 96, 40), (1, 6, 6, 64, 512), (2, 4, 4, 512, 64)])
 def test_conv3x3_implicit_weight_gradient(ops, N, H, W, C, Co):
     """merlot_conv3x3_wgrad_bf16 (no patch matrix; pixel counts that are not multiples of 32, images narrower than a K-step, ragged
     filter counts, many pixel ranges) against dy^T @ im2col(x) in fp32 and against the explicit HIP path; accumulate on top."""
