@@ -195,6 +195,7 @@ class TransformerStackFn(torch.autograd.Function):
         store.notify_ready(stack.scope + '/LayerNorm_ln_final')
         if ctx.log is not None and ctx.log[3] is not None:
             ctx.log[3]()                                 # every layer's log sums are queued: the owner finalises its metrics
+        ctx.log = None                                   # (the callback belongs to the model: do not keep the model alive through this node)
         ctx.saved = None
         ctx.final = None
         return dh, None, None, None, None, None
@@ -682,12 +683,13 @@ class L2NormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         y, inv = ops.l2norm_fwd(x.contiguous())
-        ctx.y, ctx.inv = y, inv
-        return y
+        ctx.save_for_backward(y, inv)                    # y is this node's OUTPUT: as a plain ctx attribute it is a reference cycle
+        return y                                         # (y -> grad_fn -> ctx -> y) that keeps the whole upstream graph alive until a gc pass
 
     @staticmethod
     def backward(ctx, dy):
-        return ops.l2norm_bwd(dy, ctx.y, ctx.inv)
+        y, inv = ctx.saved_tensors
+        return ops.l2norm_bwd(dy, y, inv)
 
 
 class SoftmaxCEFn(torch.autograd.Function):

@@ -226,9 +226,12 @@ class MerlotModel(object):
             log_hi = torch.zeros((self.B, Sj), device=dev, dtype=F32)
             log_vals = torch.zeros(4, device=dev, dtype=F32)
 
+            P_ = self.P
+
             def finish_log():                                                     # :186-203 from the fused block sums
+                # (closes over tensors and an int only: stored in the encoder's autograd node, a reference to `self` here would be a
+                # cycle through the graph that Python's collector cannot see -- one whole step's activations leaked per step)
                 tot = log_lo.sum() + log_hi.sum()
-                P_ = self.P
                 log_vals.copy_(torch.stack([log_hi[:, P_:].sum(), log_lo[:, P_:].sum(), log_hi[:, :P_].sum(), log_lo[:, :P_].sum()]) / tot)
             # `attention_log_in_backward` (an extension key, default off): in a TRAINING step the block sums come out of the
             # attention backward (its dK / dV pass forms P anyway) instead of a second Q K^T walk in each of the joint encoder's

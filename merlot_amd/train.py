@@ -152,7 +152,17 @@ class Trainer(object):
         self.check_inputs(wait=True)
         self.opt.step()
         self.step_idx += 1
-        return out
+        # the caller gets values, not a graph: the step's autograd nodes (and what their ctx objects still hold: LayerNorm inputs, the
+        # heads' activations -- several GB at the bench's batch) are released here instead of when the caller drops `out` a step later
+        def values(o):
+            if isinstance(o, torch.Tensor):
+                return o.detach()
+            if isinstance(o, dict):
+                return {k: values(v) for k, v in o.items()}
+            if isinstance(o, (list, tuple)):
+                return type(o)(values(v) for v in o)
+            return o
+        return values(out)
 
 
 def train(config, device, dist_ctx=None, max_steps=None, num_workers=None, log_every=100, seed=0):
