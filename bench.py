@@ -203,7 +203,7 @@ def main():
     ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--examples', type=int, default=None, help='examples (x16 segments) per GPU per step (default 128 = 2048 segments: the throughput plateau of the batch sweep, '
-                         '~220 GB of the 288; round 1 and most of round 2 were quoted at 32; config 5: 48 = 768 segments of 384^2, ~210 GB)')
+                         '208 GB of the 288; round 1 and most of round 2 were quoted at 32; config 5: 48 = 768 segments of 384^2, ~210 GB)')
     ap.add_argument('--config', type=int, default=2, choices=(2, 5),
                     help='BASELINE.json configs[]: 2 = the headline 4-segment 224^2 bf16 workload (configs[1]; DP over --gpus); '
                          '5 = NOT the headline: the 16-segment 384^2 long-video variant with fp8 forward GEMMs (configs[4])')
@@ -233,7 +233,7 @@ def main():
     from merlot_amd.train import Trainer, synthetic_batch
 
     if args.examples is None:
-        args.examples = 48 if args.config == 5 else ((64 if args.explicit_conv else 80) if args.resnet_stem else 128)   # the hybrid stem keeps several times the activations per frame (implicit 3x3 convolutions, 64 / 80 / 96 examples: 2 952 / 3 011 / 3 040 segments/s at 165 / 206 / 246 GB, profiles/r04_v_stem_batch.txt)
+        args.examples = 48 if args.config == 5 else ((64 if args.explicit_conv else 80) if args.resnet_stem else 128)   # the hybrid stem keeps several times the activations per frame (implicit 3x3 convolutions, 80 / 96 / 112 examples: 3 030 / 3 048 / 3 086 segments/s at 193 / 231 / 269 GB)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
