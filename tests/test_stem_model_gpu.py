@@ -66,13 +66,16 @@ def test_implicit_and_explicit_convolutions_agree_through_the_whole_stem(size):
         toks.append(tok.detach().clone())
         grads.append({k: v.clone() for k, v in st.export_tf_grads().items() if 'resnet50lite' in k or 'conv_postresnet_proj' in k})
     noise = rel_l2(toks[0], toks[1])                                    # implicit vs implicit: the atomics' summation order
-    assert rel_l2(toks[0], toks[2]) < max(3 * noise, 2e-3), (rel_l2(toks[0], toks[2]), noise)
+    # (the floors are twice the noise level seen on this problem -- 8-9e-3 on the tokens, 0.11 median / 0.16-0.20 max on the gradients, the
+    # chaotic amplification through 23 GroupNorm'd layers of tests below --, so that a run whose two implicit passes happen to agree exactly
+    # does not fail the comparison; a wrong tap or border is an O(1) difference)
+    assert rel_l2(toks[0], toks[2]) < max(3 * noise, 2e-2), (rel_l2(toks[0], toks[2]), noise)
     assert len(grads[0]) == 56
     gnoise = {k: rel_l2(grads[0][k], grads[1][k]) for k in grads[0]}
     rels = {k: rel_l2(grads[0][k], grads[2][k]) for k in grads[0]}
     print('tokens: noise %.2e implicit vs explicit %.2e; gradients: noise median %.2e max %.2e, implicit vs explicit median %.2e max %.2e'
           % (noise, rel_l2(toks[0], toks[2]), np.median(list(gnoise.values())), max(gnoise.values()), np.median(list(rels.values())), max(rels.values())))
-    assert max(rels.values()) < max(3 * max(gnoise.values()), 3e-2) and np.median(list(rels.values())) < max(3 * np.median(list(gnoise.values())), 1e-2), \
+    assert max(rels.values()) < max(3 * max(gnoise.values()), 0.4) and np.median(list(rels.values())) < max(3 * np.median(list(gnoise.values())), 0.25), \
         sorted(rels.items(), key=lambda kv: -kv[1])[:5]
 
 
