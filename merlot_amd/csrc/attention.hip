@@ -881,6 +881,7 @@ __global__ __launch_bounds__(64) void attn_colsum_kernel(const AttnArgs p) {
 
 #include "attention_res.inc"
 #include "attention_fb.inc"
+#include "attention_pp.inc"
 
 int check_attn(const void* qkv, int64_t ld, int B, int S, int heads) {
     MERLOT_CHECK(qkv != nullptr, MERLOT_ESHAPE, "attention: null qkv");
@@ -912,10 +913,18 @@ extern "C" int merlot_attention_fwd(const void* qkv, int64_t ld, void* out, int6
     // for the plain forward of short unmasked sequences (the ViT pass: K | V through the CU's memory pipe once instead of once
     // per 128-row block, 685 vs 780 us at the bench shape, profiles/r03_j_attention_res.txt; masked sequences: level -> tiled)
     bool res_plain = !valid && S > 64 && S <= 256;
+    // round 5: the persistent, prefetching single-pass kernel (attention_pp.inc) takes the plain forward of unmasked sequences of
+    // up to 224 tokens -- the ViT pass
+    bool pp = pp_fwd_ok(a, want_cs);
 #ifdef MERLOT_EXPERIMENTS
     if (const char* e = getenv("MERLOT_ATTN_DBG")) a.dbg = atoi(e);
     if (const char* e = getenv("MERLOT_ATTN_RESFWD")) res_plain = res_plain && atoi(e) != 0;
+    if (const char* e = getenv("MERLOT_ATTN_PP")) pp = pp && atoi(e) != 0;
 #endif
+    if (pp) {
+        rc = pp_fwd(a, (hipStream_t)stream);
+        return rc ? rc : merlot_launch_status("merlot_attention_fwd");
+    }
     if (S <= RES_MAX_S && (want_cs || res_plain)) {
         rc = res_fwd(a, (hipStream_t)stream);
         return rc ? rc : merlot_launch_status("merlot_attention_fwd");

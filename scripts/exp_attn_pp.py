@@ -1,0 +1,43 @@
+"""Round 5: the persistent, prefetching single-pass forward (attention_pp.inc) against the resident one-shot forward
+(attention_res.inc) on the ViT pass.  Experiments build: MERLOT_ATTN_PP=0/1 picks the kernel, MERLOT_ATTN_DBG=32 = data movement only."""
+import _exp_lib  # noqa: F401
+import os
+import torch
+from merlot_amd import ops
+from exp_attn_time import timeit
+
+
+def ref(qkv, B, S):
+    q, k, v = [t.reshape(B, S, 12, 64).permute(0, 2, 1, 3).float() for t in qkv.float().split(768, dim=1)]
+    s = q @ k.transpose(-1, -2) * 0.125
+    lse = torch.logsumexp(s, -1)
+    o = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B * S, 768)
+    return o, lse
+
+
+SC = int(os.environ.get('SCALE', 4))
+for B, S in ((3, 198), (5, 65), (4, 96), (2, 128), (3, 161), (2, 224), (1, 198), (43, 198), (300, 198)):
+    qkv = (torch.randn(B * S, 2304, device='cuda') * 0.7).bfloat16()
+    outs = {}
+    for k in ('0', '1'):
+        os.environ['MERLOT_ATTN_PP'] = k
+        outs[k] = ops.attention_fwd(qkv, B, S, 12, None)
+    torch.cuda.synchronize()
+    o_ref, lse_ref = ref(qkv, B, S)
+    e = [float((outs[k][0].float() - o_ref).abs().max()) for k in ('0', '1')]
+    el = [float((outs[k][1] - lse_ref).abs().max()) for k in ('0', '1')]
+    d = float((outs['0'][0].float() - outs['1'][0].float()).abs().max())
+    print(f'B {B:4d} S {S:4d}: |o - ref| res {e[0]:.2e} pp {e[1]:.2e} | |lse - ref| res {el[0]:.2e} pp {el[1]:.2e} | res vs pp {d:.2e}', flush=True)
+    assert e[1] < 2.5e-2 and el[1] < 2e-3, 'pp forward off'
+
+for B, S in ((512 * SC, 198), (128 * SC, 198), (512 * SC, 129)):
+    qkv = (torch.randn(B * S, 2304, device='cuda') * 0.7).bfloat16()
+    row = []
+    for k, dbg in (('0', '0'), ('1', '0'), ('0', '0'), ('1', '0'), ('1', '32')):
+        os.environ['MERLOT_ATTN_PP'] = k
+        os.environ['MERLOT_ATTN_DBG'] = dbg
+        t = timeit(lambda: ops.attention_fwd(qkv, B, S, 12, None))
+        row.append(f'{ {"0": "res", "1": "pp"}[k] }{ {"0": "", "32": "(data only)", "64": "(nt)", "96": "(nt, data only)"}[dbg] } {t:7.1f} us')
+    os.environ['MERLOT_ATTN_DBG'] = '0'
+    gb = B * S * 12 * 64 * 2 * 4 / 1e9
+    print(f'fwd B {B:5d} S {S:4d} ({gb:.2f} GB): ' + ' | '.join(row), flush=True)
