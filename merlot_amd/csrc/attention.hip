@@ -992,6 +992,15 @@ extern "C" int merlot_attention_bwd(const void* qkv, int64_t ld, const void* out
     if (const char* e = getenv("MERLOT_ATTN_DBG")) a.dbg = atoi(e);
     if (const char* e = getenv("MERLOT_ATTN_FB")) fb_mode = fb_ok(a) ? atoi(e) : 0;
 #endif
+    // round 5: the persistent, prefetching backward of unmasked sequences of up to 224 tokens (the ViT pass; attention_pp.inc)
+    bool pp = pp_bwd_ok(a);
+#ifdef MERLOT_EXPERIMENTS
+    if (const char* e = getenv("MERLOT_ATTN_PP")) pp = pp && atoi(e) != 0;
+#endif
+    if (pp) {
+        rc = pp_bwd(a, s);
+        return rc ? rc : merlot_launch_status("merlot_attention_bwd");
+    }
     if (fb_mode) {
         if (want_log && !fb_log_ok(a)) hipLaunchKernelGGL(attn_colsum_kernel, dim3(cdiv(S, 32), heads, B), dim3(64), 0, s, a);
         rc = fb_bwd(a, s);
@@ -1026,3 +1035,12 @@ extern "C" int merlot_attention_colsum(const void* qkv, int64_t ld, const float*
     hipLaunchKernelGGL(attn_colsum_kernel, dim3(cdiv(S, 32), heads, B), dim3(64), 0, (hipStream_t)stream, a);
     return merlot_launch_status("merlot_attention_colsum");
 }
+
+#ifdef MERLOT_EXPERIMENTS
+extern "C" int merlot_probe_attn_trace(void* dst, int64_t bytes, merlot_stream_t stream) {
+    MERLOT_CHECK(dst && bytes > 0 && bytes <= (int64_t)sizeof(long long) * 8 * 16 * 8, MERLOT_ESHAPE, "merlot_probe_attn_trace: bad size");
+    hipError_t e = hipMemcpyFromSymbolAsync(dst, HIP_SYMBOL(g_attn_trace), (size_t)bytes, 0, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipMemcpyFromSymbolAsync: %s", hipGetErrorString(e));
+    return MERLOT_OK;
+}
+#endif

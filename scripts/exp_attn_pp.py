@@ -41,3 +41,44 @@ for B, S in ((512 * SC, 198), (128 * SC, 198), (512 * SC, 129)):
     os.environ['MERLOT_ATTN_DBG'] = '0'
     gb = B * S * 12 * 64 * 2 * 4 / 1e9
     print(f'fwd B {B:5d} S {S:4d} ({gb:.2f} GB): ' + ' | '.join(row), flush=True)
+
+# ---- backward: persistent (attention_pp.inc) against the one-launch fused kernel (attention_fb.inc) and fp32 autograd
+def ref_bwd(qkv, do, B, S):
+    x = qkv.float().requires_grad_(True)
+    q, k, v = [t.reshape(B, S, 12, 64).permute(0, 2, 1, 3) for t in x.split(768, dim=1)]
+    s = q @ k.transpose(-1, -2) * 0.125
+    o = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B * S, 768)
+    o.backward(do.float())
+    return x.grad
+
+
+for B, S in ((3, 198), (5, 65), (4, 96), (2, 128), (3, 161), (2, 224), (1, 198), (43, 198), (300, 198)):
+    qkv = (torch.randn(B * S, 2304, device='cuda') * 0.7).bfloat16()
+    os.environ['MERLOT_ATTN_PP'] = '0'
+    o, lse = ops.attention_fwd(qkv, B, S, 12, None)
+    do = torch.randn_like(o)
+    outs = {}
+    for k in ('0', '1'):
+        os.environ['MERLOT_ATTN_PP'] = k
+        outs[k] = ops.attention_bwd(qkv, o, do, lse, B, S, 12, None)
+    torch.cuda.synchronize()
+    g = ref_bwd(qkv, do, B, S)
+    rel = [float((outs[k].float() - g).norm() / g.norm()) for k in ('0', '1')]
+    mx = [float((outs[k].float() - g).abs().max()) for k in ('0', '1')]
+    d = float((outs['0'].float() - outs['1'].float()).abs().max())
+    print(f'bwd B {B:4d} S {S:4d}: rel-L2 vs fp32 fused {rel[0]:.2e} pp {rel[1]:.2e} | max abs fused {mx[0]:.2e} pp {mx[1]:.2e} | fused vs pp {d:.2e}', flush=True)
+    assert rel[1] < 1e-2 and torch.isfinite(outs['1'].float()).all(), 'pp backward off'
+
+for B, S in ((512 * SC, 198), (128 * SC, 198), (512 * SC, 129)):
+    qkv = (torch.randn(B * S, 2304, device='cuda') * 0.7).bfloat16()
+    os.environ['MERLOT_ATTN_PP'] = '0'
+    o, lse = ops.attention_fwd(qkv, B, S, 12, None)
+    do = torch.randn_like(o)
+    row = []
+    for k, dbg in (('0', '0'), ('1', '0'), ('0', '0'), ('1', '0'), ('0', '1'), ('1', '32'), ('1', '64'), ('1', '128')):
+        os.environ['MERLOT_ATTN_PP'] = k
+        os.environ['MERLOT_ATTN_DBG'] = dbg
+        t = timeit(lambda: ops.attention_bwd(qkv, o, do, lse, B, S, 12, None))
+        row.append(f'{ {"0": "fused", "1": "pp"}[k] }{ {"0": "", "1": "(data only)", "32": "(data only)", "64": "(no pass 2)", "128": "(no pass 1)", "512": "(setprio)"}[dbg] } {t:7.1f} us')
+    os.environ['MERLOT_ATTN_DBG'] = '0'
+    print(f'bwd B {B:5d} S {S:4d}: ' + ' | '.join(row), flush=True)

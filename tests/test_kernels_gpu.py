@@ -301,9 +301,9 @@ def test_attention_fwd_bwd_at_the_baseline_config_lengths(ops, B, S, heads, pad)
 @pytest.mark.parametrize("B,S,heads", [(2, 65, 12), (2, 96, 3), (3, 100, 12), (2, 130, 2), (2, 160, 12), (2, 197, 12), (2, 224, 4),
                                        (2, 225, 12), (1, 256, 12)])
 def test_attention_bwd_fused_short_unmasked(ops, B, S, heads):
-    """Unmasked sequences of 65..256 tokens (the ViT pass: 198) take the ONE-launch backward of csrc/attention_fb.inc (K | V, then
-    Q | dO resident in LDS): every block / chunk raggedness of that range against the fp32 torch restatement, and the published
-    delta against sum(dO * O)."""
+    """Unmasked sequences of 65..224 tokens (the ViT pass: 198) take the persistent backward of csrc/attention_pp.inc, 225..256 the
+    ONE-launch backward of csrc/attention_fb.inc (K | V, then Q | dO resident in LDS): every block / chunk raggedness of that range
+    against the fp32 torch restatement, and the published delta against sum(dO * O)."""
     test_attention_fwd_bwd(ops, B, S, heads, False)
     from merlot_amd.lib import call
     qkv, _, g = _attn_inputs(B, S, heads, 7 + S, False)
@@ -319,11 +319,23 @@ def test_attention_bwd_fused_short_unmasked(ops, B, S, heads):
     assert float((delta - want).abs().max()) < 1e-3 * (1 + float(want.abs().max()))
 
 
-@pytest.mark.parametrize("B,S,heads,pad,pads", [(3, 198, 12, False, (64, 8, 16, 8)), (2, 130, 5, True, (8, 24, 8, 16)),
+@pytest.mark.parametrize("B,S,heads", [(40, 198, 12), (100, 70, 12), (300, 129, 1), (23, 224, 12)])
+def test_attention_persistent_kernels_many_items_per_workgroup(ops, B, S, heads):
+    """Round 5: unmasked sequences of 65..224 tokens run the PERSISTENT kernels of csrc/attention_pp.inc -- one workgroup per CU walks
+    its (batch, head) items with the next items' operands in flight, waits counted by hand.  More items than CUs (256), so that every
+    workgroup takes several items, a last round that only some workgroups take part in, and the zero-length requests behind the end of
+    the list: forward and backward against the fp32 torch restatement."""
+    assert B * heads > 256
+    test_attention_fwd_bwd(ops, B, S, heads, False)
+
+
+@pytest.mark.parametrize("B,S,heads,pad,pads", [(3, 198, 12, False, (64, 8, 16, 8)), (3, 198, 12, False, (64, 64, 128, 64)),
+                                                 (2, 130, 5, True, (8, 24, 8, 16)),
                                                  (2, 328, 3, True, (128, 8, 8, 8)), (1, 512, 2, True, (8, 8, 8, 8)),
                                                  (5, 77, 7, False, (16, 40, 8, 24))])
 def test_attention_nondefault_leading_dims(ops, B, S, heads, pad, pads):
-    """The resident forward and the fused backward build their LDS-DMA source addresses from the leading dimensions: operands with
+    """The resident / persistent forward and the fused / persistent backward build their LDS-DMA source addresses from the leading
+    dimensions (the persistent kernels want rows a multiple of 128 B apart: the second case; the others fall back): operands with
     padded rows (ld > 3 * heads * 64, ldo / lddo > heads * 64), odd head counts; the padding columns of the outputs stay untouched."""
     from merlot_amd.lib import call
     D = heads * 64
