@@ -33,7 +33,8 @@ def fwd_gflop_per_segment(image, n_group, text_len=32, hidden=768, inter=3072, l
     n x (1 + pooled grid + text_len) tokens, the text-only encoder on text_len tokens, + 1.09 for the heads."""
     lin = 2.0 * (4 * hidden * hidden + 2 * hidden * inter)             # per token and layer
     att = lambda s: 4.0 * s * s * hidden                               # per sequence and layer: QK^T + PV
-    grid = (image // patch) ** 2
+    ih, iw = (image, image) if isinstance(image, int) else image      # merlot.yaml:36 ships a non-square frame, [192, 352]
+    grid = (ih // patch) * (iw // patch)
     sv = ncls + grid
     sj = n_group * (1 + grid // (pool * pool) + text_len)
     vit = layers * (lin * sv + att(sv)) + 2.0 * grid * hidden * patch * patch * 3
@@ -212,6 +213,9 @@ def main():
     ap.add_argument('--fp8-fc2', action='store_true', help='with --config 5: also run fc2 on e4m3 operands (its input needs a separate two-pass quantisation)')
     ap.add_argument('--resnet-stem', action='store_true',
                     help='NOT the headline config: swap the patch stem for the ResNet-hybrid stem of merlot.yaml:30 (resnet_layers [3, 4, 9])')
+    ap.add_argument('--native-yaml', action='store_true',
+                    help='NOT the headline config: the model as model/configs/merlot.yaml ships it -- image_size [192, 352] (12 x 22 patches, joint S = 396) '
+                         'and resnet_layers [3, 4, 9]; everything else as the headline (12 + 12 + 12 layers, 16 segments per example in groups of 4)')
     ap.add_argument('--explicit-conv', action='store_true', help='with --resnet-stem: the 3x3 convolutions on explicit im2col matrices (the path of rounds 1-3) instead of the implicit GEMM')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
@@ -233,7 +237,7 @@ def main():
     from merlot_amd.train import Trainer, synthetic_batch
 
     if args.examples is None:
-        args.examples = 48 if args.config == 5 else ((64 if args.explicit_conv else 80) if args.resnet_stem else 128)   # the hybrid stem keeps several times the activations per frame (implicit 3x3 convolutions, 80 / 96 / 112 examples: 3 030 / 3 048 / 3 086 segments/s at 193 / 231 / 269 GB)
+        args.examples = 48 if args.config == 5 else 56 if args.native_yaml else ((64 if args.explicit_conv else 80) if args.resnet_stem else 128)   # the hybrid stem keeps several times the activations per frame (implicit 3x3 convolutions, 80 / 96 / 112 examples: 3 030 / 3 048 / 3 086 segments/s at 193 / 231 / 269 GB)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -281,10 +285,17 @@ def main():
         fp8 = not args.bf16
         config.model.update(image_size=[384, 384], num_chunks_in_group=16, fp8_forward=('all' if args.fp8_attn else True if args.fp8_fc2 else 'ln') if fp8 else False)
         train_gflop = 3.0 * fwd_gflop_per_segment(384, 16)
+    if args.native_yaml:
+        # model/configs/merlot.yaml:30,36.  SURVEY 8(d): 72.92 GFLOP forward per segment on the patch stem at 192 x 352 (the closed form below
+        # gives 72.9); the stem's 10.041 GFLOP per 224^2 frame scale with the pixel count (every convolution is 'SAME' / stride-aligned)
+        args.resnet_stem = True
+        config.model['image_size'] = [192, 352]
+        stem = 10.041 * (192 * 352) / (224 * 224)
+        train_gflop_native = 3.0 * (fwd_gflop_per_segment((192, 352), 4) - 2.0 * 264 * 768 * 768 / 1e9 + stem)
     if args.resnet_stem:
         config.model['resnet_layers'] = [3, 4, 9]
         config.model['resnet_implicit_conv'] = not args.explicit_conv
-        train_gflop = TRAIN_GFLOP_PER_SEGMENT_RESNET
+        train_gflop = train_gflop_native if args.native_yaml else TRAIN_GFLOP_PER_SEGMENT_RESNET
     trainer = Trainer(config, device, ctx, seed=0)
     batch = synthetic_batch(config, args.examples, device, seed=1234 + rank)
     seg_per_gpu = args.examples * config.data['num_chunks']
@@ -334,7 +345,8 @@ def main():
     if rank == 0:
         value = world * seg_per_gpu * args.steps / elapsed
         res = {
-            'metric': 'frame-caption segments/sec/node (4-seg, 224^2, bf16)' if args.config == 2 else
+            'metric': 'frame-caption segments/sec/node (4-seg, 192x352 as merlot.yaml ships it, bf16)' if args.native_yaml else
+                      'frame-caption segments/sec/node (4-seg, 224^2, bf16)' if args.config == 2 else
                       'frame-caption segments/sec/node (16-seg, 384^2, %s)' % (('fp8 QKV/fc1/fc2 GEMMs + attention forward' if args.fp8_attn else 'fp8 QKV/fc1/fc2 forward GEMMs' if args.fp8_fc2 else 'fp8 QKV/fc1 forward GEMMs') if fp8 else 'bf16'),
             'value': value, 'unit': 'segments/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
@@ -343,7 +355,8 @@ def main():
             'data': 'synthetic',
             'config': {'workload': (('merlot.yaml 4-segment ResNet-hybrid [3,4,9] + ViT-B/16' if args.resnet_stem else
                                      'merlot.yaml 4-segment full ViT-B/16 (patch stem)') + ' + 12-layer joint + 12-layer text-only, '
-                                    '224^2 frames, 32-token captions, fwd+bwd+DP all-reduce+AdamW, dropout 0.1') if args.config == 2 else
+                                    + ('192 x 352 frames (model/configs/merlot.yaml:30,36)' if args.native_yaml else '224^2 frames') +
+                                    ', 32-token captions, fwd+bwd+DP all-reduce+AdamW, dropout 0.1') if args.config == 2 else
                                    ('BASELINE configs[4]: 16-segment long-video variant, full ViT-B/16 at 384^2 (578 tokens/frame) + '
                                     '12-layer joint over 2832-token groups + 12-layer text-only, fwd+bwd+AdamW, dropout 0.1; '
                                     + ('fp8 forward GEMMs' if fp8 else 'all-bf16 comparison run')),
@@ -351,6 +364,7 @@ def main():
                        'segments_per_gpu_per_step': seg_per_gpu, 'examples_per_gpu': args.examples,
                        'num_chunks': config.data['num_chunks'], 'parallelism': f'dp{world}', 'grad_reduce': 'sum',
                        'stem': 'resnet-hybrid [3,4,9] (merlot.yaml:30)' if args.resnet_stem else 'patch 16x16 (north_star)',
+                       'image_size': list(config.model['image_size']), 'train_gflop_per_segment': train_gflop,
                        'final_loss': loss},
             'model_flops_utilization': value * train_gflop / 1e3 / (world * PEAK_BF16_TFLOPS),
             'forward_only': {'value': world * seg_per_gpu * fwd_steps / fwd_elapsed, 'unit': 'segments/s',
