@@ -158,30 +158,41 @@ def self_launch(n):
 
 
 GEMM_SOURCES = ('gemm.hip', 'gemm_p8.inc', 'gemm_ring.h', 'common.h')
+ATTENTION_SOURCES = ('attention.hip', 'attention_res.inc', 'attention_fb.inc', 'attention_pp.inc', 'common.h')
+TRAFFIC_FILE = 'r05_traffic.txt'
 
 
-def gemm_source_hash():
-    """sha256 (first 16 hex digits) of the sources of the dominant kernel: ties a PMC traffic file to the binary it measured."""
+def source_hash(files):
+    """sha256 (first 16 hex digits) of a kernel family's sources: ties the rows of a PMC traffic file to the code they measured."""
     import hashlib
     h = hashlib.sha256()
-    for f in GEMM_SOURCES:
+    for f in files:
         h.update(open(os.path.join(ROOT, 'merlot_amd', 'csrc', f), 'rb').read())
     return h.hexdigest()[:16]
 
 
+def gemm_source_hash():
+    return source_hash(GEMM_SOURCES)
+
+
 def measured_traffic():
     """HBM-side bytes per launch of the representative dominant launch (M=101376 N=3072 K=768, bias epilogue), from the
-    TCC counters collected in separate rocprofv3 --pmc passes over THIS kernel (profiles/r04_traffic.txt, written by
+    TCC counters collected in separate rocprofv3 --pmc passes over THIS kernel (profiles/' + TRAFFIC_FILE + ', written by
     scripts/gpu_traffic.sh): 2 * FETCH_SIZE (gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE, in bytes.  The
     file records the hash of the GEMM sources it was measured on; if the sources changed since, the figure is STALE and
     is not reported (traffic: null, with the reason)."""
-    path = os.path.join(ROOT, 'profiles', 'r04_traffic.txt')
+    path = os.path.join(ROOT, 'profiles', TRAFFIC_FILE)
     if not os.path.exists(path):
-        return {'bytes_per_launch': None, 'why': 'profiles/r04_traffic.txt absent'}
-    fetch = write = src = None
+        return {'bytes_per_launch': None, 'why': f'profiles/{TRAFFIC_FILE} absent'}
+    fetch = write = src = asrc = None
+    attn = {}
     for line in open(path):
         if line.startswith('gemm_source_hash'):
             src = line.split()[-1]
+        if line.startswith('attention_source_hash'):
+            asrc = line.split()[-1]
+        if line.startswith('HBM_MB') and 'attn_' in line:
+            attn[line.split(' | ')[1].strip()] = float(line.split()[-1]) * 1024.0 * 1024.0
         if 'gemm_nt_p8_kernel<0, false, false, true>' in line and line.split(' | ')[0] in ('FETCH_SIZE', 'WRITE_SIZE'):
             kb = float(line.split()[-1])                      # '<counter> | <kernel> | launches n | KB_per_launch v'
             if line.startswith('FETCH_SIZE'):
@@ -189,13 +200,18 @@ def measured_traffic():
             else:
                 write = kb
     if fetch is None or write is None:
-        return {'bytes_per_launch': None, 'why': 'profiles/r04_traffic.txt holds no gemm_nt_p8_kernel<0, false, false, true> rows'}
+        return {'bytes_per_launch': None, 'why': 'profiles/' + TRAFFIC_FILE + ' holds no gemm_nt_p8_kernel<0, false, false, true> rows'}
     if src != gemm_source_hash():
-        return {'bytes_per_launch': None, 'why': f'profiles/r04_traffic.txt was measured on GEMM sources {src}, the tree has '
+        return {'bytes_per_launch': None, 'why': f'profiles/' + TRAFFIC_FILE + ' was measured on GEMM sources {src}, the tree has '
                                                  f'{gemm_source_hash()}: stale, re-run scripts/gpu_traffic.sh'}
-    return {'bytes_per_launch': (2.0 * fetch + write) * 1024.0, 'algorithmic_bytes_per_launch': 3119.0e6,
+    # the attention rows of the same file carry their own hash: reported only while the attention sources are the measured ones
+    if asrc == source_hash(ATTENTION_SOURCES):
+        attention = {'hbm_bytes_per_launch': attn, 'attention_source_hash': asrc}
+    else:
+        attention = {'hbm_bytes_per_launch': None, 'why': f'attention rows measured on sources {asrc}, the tree has {source_hash(ATTENTION_SOURCES)}: stale'}
+    return {'bytes_per_launch': (2.0 * fetch + write) * 1024.0, 'algorithmic_bytes_per_launch': 3119.0e6, 'attention': attention,
             'launch': 'forward Linear M=405504 (= 128 examples x 16 frames x 198 tokens) N=3072 K=768, bias epilogue, bf16 out (gemm_nt_p8_kernel<0,false,false,true>)',
-            'source': 'profiles/r04_traffic.txt', 'gemm_source_hash': src}
+            'source': 'profiles/' + TRAFFIC_FILE + '', 'gemm_source_hash': src}
 
 
 def main():

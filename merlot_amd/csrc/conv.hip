@@ -160,6 +160,17 @@ __global__ void gn_finalize_kernel(float* __restrict__ stats, int64_t n_groups, 
     }
 }
 
+// GroupNorm's affine output y = x * sc + sh and its ReLU mask, in ONE place: gn_apply_kernel writes y, and the two backward kernels recompute
+// the mask from x where no residual joins (no second read of y).  The three are separately compiled loops: the mask is only the
+// forward's if they evaluate the same expression with the same roundings -- explicit FMAs (no contraction left to the compiler), and
+// the test is made on the value the forward STORED (bf16), so an element that rounds to zero is masked on both sides.
+__device__ __forceinline__ void gn_affine(float mean, float rstd, float gamma, float beta, float& sc, float& sh) {
+    sc = rstd * gamma;
+    sh = __builtin_fmaf(-mean, sc, beta);
+}
+__device__ __forceinline__ float gn_y(float x, float sc, float sh) { return __builtin_fmaf(x, sc, sh); }
+__device__ __forceinline__ bool gn_relu_passes(float yv) { return (float)(bf16)yv > 0.f; }
+
 // y = [relu]( (x - mean) * rstd * gamma + beta [+ res] ).  Grid (sample, position slice) like the statistics kernel: a thread always
 // touches the same 8 channels, so gamma, beta and the (mean, rstd) of its channels' groups are loaded ONCE per thread -- the first
 // version looked them up per element with an integer division by the run-time group width each, and ran at 60-70 % of the HBM rate
@@ -177,8 +188,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16* __restrict__ 
     for (int e = 0; e < 8; ++e) {
         const int c = chunk * 8 + e, g = c / cpg;
         const float mean = stats[((int64_t)n * G + g) * 2], rstd = stats[((int64_t)n * G + g) * 2 + 1];
-        sc[e] = rstd * gamma[c];
-        sh[e] = beta[c] - mean * rstd * gamma[c];
+        gn_affine(mean, rstd, gamma[c], beta[c], sc[e], sh[e]);
     }
     for (int p = p0 + prow; p < p1; p += pstep) {
         const int64_t off = ((int64_t)n * HW + p) * C + chunk * 8;
@@ -188,7 +198,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16* __restrict__ 
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float f = __builtin_fmaf((float)v[e], sc[e], sh[e]);
+            float f = gn_y((float)v[e], sc[e], sh[e]);
             if (res) f += (float)r8[e];
             if (relu) f = fmaxf(f, 0.f);
             o[e] = (bf16)f;
@@ -223,8 +233,8 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const bf16* __restric
         const int g = (chunk * 8 + e) / cpg;
         mean[e] = stats[((int64_t)n * G + g) * 2];
         rstd[e] = stats[((int64_t)n * G + g) * 2 + 1];
-        gam[e] = from_x ? rstd[e] * gamma[chunk * 8 + e] : 0.f;                    // y = x * gam + bet: gn_apply_kernel's own expression
-        bet[e] = from_x ? beta[chunk * 8 + e] - mean[e] * rstd[e] * gamma[chunk * 8 + e] : 0.f;
+        gam[e] = bet[e] = 0.f;
+        if (from_x) gn_affine(mean[e], rstd[e], gamma[chunk * 8 + e], beta[chunk * 8 + e], gam[e], bet[e]);     // y = x * gam + bet
     }
     if (prow < pstep) {
         for (int p = p0 + prow; p < p1; p += pstep) {
@@ -236,8 +246,8 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const bf16* __restric
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float d = (float)d8[e];
-                const float yv = from_x ? __builtin_fmaf((float)x8[e], gam[e], bet[e]) : (float)y8[e];
-                if (relu && !(yv > 0.f)) d = 0.f;
+                const float yv = from_x ? gn_y((float)x8[e], gam[e], bet[e]) : (float)y8[e];
+                if (relu && !gn_relu_passes(yv)) d = 0.f;
                 dg[e] += d * ((float)x8[e] - mean[e]) * rstd[e];
                 db[e] += d;
             }
@@ -282,8 +292,9 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const bf16* __restric
         rs[e] = rstd;
         mr[e] = mean * rstd;
         gam[e] = gamma[c];
-        bet[e] = from_x ? beta[c] - mean * rstd * gam[e] : 0.f;      // from_x: y = x * (rstd gamma) + this, gn_apply_kernel's own expression
         k1[e] = rstd * gam[e];
+        bet[e] = 0.f;
+        if (from_x) gn_affine(mean, rstd, gam[e], beta[c], k1[e], bet[e]);      // from_x: y = x * k1 + bet, gn_apply_kernel's own expression
         k2[e] = rstd * gsum[((int64_t)n * G + g) * 2] * inv_cnt;
         k3[e] = rstd * gsum[((int64_t)n * G + g) * 2 + 1] * inv_cnt;
     }
@@ -298,8 +309,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const bf16* __restric
         for (int e = 0; e < 8; ++e) {
             float d = (float)d8[e];
             const float xhat = __builtin_fmaf((float)x8[e], rs[e], -mr[e]);
-            const float yv = from_x ? __builtin_fmaf((float)x8[e], k1[e], bet[e]) : (float)y8[e];
-            if (relu && !(yv > 0.f)) d = 0.f;
+            const float yv = from_x ? gn_y((float)x8[e], k1[e], bet[e]) : (float)y8[e];
+            if (relu && !gn_relu_passes(yv)) d = 0.f;
             o[e] = (bf16)(d * k1[e] - k2[e] - xhat * k3[e]);
             r[e] = (bf16)d;
         }

@@ -85,7 +85,8 @@ class TransformerStackFn(torch.autograd.Function):
         fp8_fc2 = fp8 and opts.get('fp8') != 'ln'
         fp8_attn = opts.get('fp8') == 'all'              # + Q K^T and P V of the forward on the e4m3 MFMA
         need_bwd = ctx.needs_input_grad[0]
-        log_bwd = bool(opts.get('log_in_backward', False)) and need_bwd and log_lo is not None and not fp8_attn
+        log_bwd = bool(opts.get('log_in_backward', False)) and need_bwd and log_lo is not None
+        assert not (log_bwd and fp8_attn), "log_in_backward with the fp8 attention forward: the caller (modeling.py) must not ask for it"
         ctx.log = (log_lo, log_hi, opts.get('log_split'), opts.get('log_done')) if log_bwd else None
         if log_bwd:
             log_lo = log_hi = None                        # the forward launches carry no log side output
@@ -479,6 +480,21 @@ class StemWeights(object):
 
     def standardise(self):
         ops.weight_std_fwd_batched(self.store.master, self.fjobs, self.blocks, self.khat, self.rstd, self.wb, self.wbT, self.wdg)
+        self.generation = getattr(self, 'generation', 0) + 1
+        self.std_of_master = self.store.master_version
+
+    def restore_for(self, generation, master_version):
+        """ONE set of buffers serves every graph of the stem (tape entries hold views of it).  A second forward between a graph's forward
+        and its backward (an evaluation pass inside a training step, two live graphs) re-standardises in place: from the same master
+        weights that rewrites identical values, and the older graph's backward only has to make sure of it; after a weight update the
+        older graph's standardised kernels are gone, and its backward refuses instead of back-propagating with the wrong ones."""
+        if generation == self.generation:
+            return
+        if master_version != self.store.master_version:
+            raise RuntimeError("ResNet-hybrid stem: the master weights changed between this graph's forward and its backward and another "
+                               "stem forward has overwritten the shared standardised kernels; run backward before the optimizer step")
+        if self.std_of_master != self.store.master_version:
+            self.standardise()
 
     def backward(self):
         """store.grad[kernel] += the standardisation's backward of every dk slot (call once, after the last weight-gradient GEMM)."""
@@ -518,6 +534,7 @@ class ResNetStemFn(torch.autograd.Function):
         if sw is None:
             sw = store._stem_weights = StemWeights(store, rs)
         sw.standardise()                                  # every kernel of the stem: one launch
+        ctx.stem_generation, ctx.stem_master_version = sw.generation, store.master_version
 
         def conv(x, name, stride=1, shift=0.0):
             kh, _, _, co = store.offsets[name + '/kernel'][2]
@@ -589,6 +606,7 @@ class ResNetStemFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         store, tape, lin = ctx.store, ctx.tape, ctx.lin
+        store._stem_weights.restore_for(ctx.stem_generation, ctx.stem_master_version)
         dy = dy.contiguous()
         ops.colsum_bf16(dy, lin.gb)
         ops.gemm_tn(dy, ctx.a_final, lin.gw)

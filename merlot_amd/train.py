@@ -110,10 +110,15 @@ class Trainer(object):
             raise ValueError(f"token id out of range (training step {step})")
 
     def _defer_check(self, flag):
-        if flag is None:
-            return
         from .parallel import FORCE
-        if self.dist is not None and (self.dist.world_size > 1 or FORCE):
+        multi = self.dist is not None and (self.dist.world_size > 1 or FORCE)
+        if flag is None:
+            if not multi:
+                return
+            # a rank whose graph produced no flag still takes part in the collective below (a zero): returning early here while the
+            # other ranks reduce would deadlock them
+            flag = torch.zeros((), dtype=torch.bool, device=self.device)
+        if multi:
             # the reference's in-graph assertion fails the whole job: every rank has to see ANY rank's bad batch, or the
             # good ranks would apply an update that already contains the bad rank's gradients and then hang at the next
             # collective.  One 4-byte MAX all-reduce, queued right behind the forward like the copy below.
@@ -159,6 +164,8 @@ class Trainer(object):
                 return o.detach()
             if isinstance(o, dict):
                 return {k: values(v) for k, v in o.items()}
+            if isinstance(o, tuple) and hasattr(o, '_fields'):           # a namedtuple takes its fields positionally, not one iterable
+                return type(o)(*(values(v) for v in o))
             if isinstance(o, (list, tuple)):
                 return type(o)(values(v) for v in o)
             return o

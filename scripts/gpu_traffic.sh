@@ -1,8 +1,9 @@
 #!/bin/bash
 # HBM traffic of the dominant kernels from the TCC counters -- separate --pmc passes with --kernel-trace only, as
-# MI355X_MICROARCH.md prescribes -- over the PRODUCT library.  Writes gpurun_out/r04_traffic.txt; copy it to profiles/.
-# The file records the hash of the GEMM sources (bench.py refuses a file whose hash differs from the tree's) and the
-# sha256 of the measured libmerlot_hip.so.
+# MI355X_MICROARCH.md prescribes -- over the PRODUCT library.  Writes gpurun_out/r05_traffic.txt; copy it to profiles/.
+# The file records the hashes of the GEMM sources AND of the attention sources (bench.py refuses the rows of a family whose hash differs
+# from the tree's: round 4's file was measured before the attention kernels last changed and nothing said so) and the sha256 of the
+# measured libmerlot_hip.so.
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
@@ -13,7 +14,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   cp /tmp/pmc_$c/g_counter_collection.csv $R/gpurun_out/pmc_$c.csv
 done
 cd $R
-python - <<'PY' > gpurun_out/r04_traffic.txt
+python - <<'PY' > gpurun_out/r05_traffic.txt
 import csv, collections, hashlib, os, sys
 sys.path.insert(0, os.getcwd())
 import bench
@@ -21,6 +22,7 @@ print('# rocprofv3 --pmc <counter> --kernel-trace -- python scripts/pmc_gemm.py 
 print('# KB = TCC counter value per launch as reported (FETCH_SIZE / WRITE_SIZE in KiB); HBM bytes = (2*FETCH + WRITE) * 1024')
 print('#   (the gfx950 correction of MI355X_MICROARCH.md: FETCH_SIZE counts 64-B units as if they were 32-B)')
 print('gemm_source_hash', bench.gemm_source_hash())
+print('attention_source_hash', bench.source_hash(bench.ATTENTION_SOURCES))
 print('libmerlot_hip.so sha256', hashlib.sha256(open('merlot_amd/libmerlot_hip.so', 'rb').read()).hexdigest())
 vals = {}
 for c in ['FETCH_SIZE', 'WRITE_SIZE']:
@@ -41,4 +43,4 @@ for k, d in vals.items():
     if 'FETCH_SIZE' in d and 'WRITE_SIZE' in d:
         print('HBM_MB | %s | %.1f' % (k, (2 * d['FETCH_SIZE'] + d['WRITE_SIZE']) / 1024.0))
 PY
-cat gpurun_out/r04_traffic.txt
+cat gpurun_out/r05_traffic.txt

@@ -235,7 +235,7 @@ def test_config5_geometry_fp8_forward_loss_within_2e2_of_bf16():
     b = None
     for fp8 in (False, True, 'ln', 'all'):
         cfg = tiny_config(image_size=[384, 384], num_chunks_in_group=16, max_position_embeddings=1024, fp8_forward=fp8,
-                          masking_use_attn=False)      # MLM targets from the noise alone: identical in both runs
+                          masking_use_attn=False, attention_log_in_backward=True)      # MLM targets from the noise alone: identical in both runs
         if b is None:
             b = synth_batch(cfg, E=1, num_chunks=16, seed=3)
             w = mo.init_weights(cfg, 0)
@@ -250,6 +250,7 @@ def test_config5_geometry_fp8_forward_loss_within_2e2_of_bf16():
         (l1 + l2 + l3).backward()
         torch.cuda.synchronize()
         out[fp8] = dict(losses=[float(l1), float(l2), float(l3)], viz=pm.encoder_hidden_states['viz'].float().cpu(),
+                        log=torch.stack([pm.attention_log[k] for k in sorted(pm.attention_log)]).float().cpu(),
                         lang=pm.encoder_hidden_states['lang'].float().cpu(),
                         masked=pm.lang_mask_info['masked_idx'].cpu(), grads={k: v.float().cpu() for k, v in st.export_tf_grads().items()})
     for mode in (True, 'ln', 'all'):     # QKV + fc1 (per-row, from the LayerNorm) + fc2 (per-tensor) | without fc2 | + attention forward
@@ -257,6 +258,9 @@ def test_config5_geometry_fp8_forward_loss_within_2e2_of_bf16():
             assert abs(a - c) < 2e-2, (mode, out[False]['losses'], out[mode]['losses'])
         assert abs(sum(out[False]['losses']) - sum(out[mode]['losses'])) < 2e-2
         assert torch.equal(out[mode]['masked'], out[False]['masked'])
+        # the attention log is complete after the step in every mode (with attention_log_in_backward and fp8_forward = 'all'
+        # it stayed all zeros -- the fp8 attention has no log in its backward and nobody finished the forward's)
+        assert abs(float(out[mode]['log'].sum()) - 1.0) < 1e-3 and float((out[mode]['log'] - out[False]['log']).abs().max()) < 2e-2, (mode, out[mode]['log'])
         for k in ('viz', 'lang'):
             assert rel_l2(out[mode][k], out[False][k]) < 5e-2, (mode, k)
         assert all(torch.isfinite(g).all() for g in out[mode]['grads'].values())

@@ -238,6 +238,39 @@ def test_resnet_hybrid_stem_autograd_wiring_exact_in_fp32(emu, monkeypatch, impl
             assert rel_l2(gt[k], v.grad) < 2e-3, (k, rel_l2(gt[k], v.grad))
 
 
+def test_two_live_stem_graphs_share_the_standardised_kernels_safely(emu):
+    """StemWeights' buffers are one set per store and tape entries hold views of them.  (a) A second stem forward from the
+    SAME master weights between a graph's forward and its backward (an evaluation pass inside a training step) leaves the older
+    graph's gradients unchanged; (b) once the master weights have changed and another forward has re-standardised, the older
+    graph's backward refuses instead of back-propagating with the newer kernels."""
+    from merlot_amd import layers as L, ParamStore
+    cfg = tiny_config(resnet_layers=[1, 1, 2])
+    w = mo.init_weights(cfg, 2)
+    b = synth_batch(cfg, E=1, num_chunks=4, seed=4)
+    img = b['image'].to(torch.bfloat16)
+
+    def grads(second_forward, change_weights=False):
+        st = ParamStore(cfg, 'cpu', seed=0)
+        st.load_tf_weights(w)
+        st.refresh(True)
+        st.zero_grad()
+        tok = L.ResNetStemFn.apply(img, st, cfg, torch.zeros(1, requires_grad=True))
+        if change_weights:
+            st.master.mul_(1.01)
+            st.master_version += 1
+        if second_forward:
+            with torch.no_grad():
+                L.ResNetStemFn.apply(img, st, cfg, None)
+        cot = torch.randn(tok.shape, generator=torch.Generator().manual_seed(0)).to(tok.dtype)
+        (tok.float() * cot.float()).sum().backward()
+        return {k: v.clone() for k, v in st.export_tf_grads().items() if 'resnet50lite' in k}
+
+    g0, g1 = grads(False), grads(True)
+    assert len(g0) == 54 and all(torch.equal(g0[k], g1[k]) for k in g0)
+    with pytest.raises(RuntimeError, match='master weights changed'):
+        grads(True, change_weights=True)
+
+
 def test_clip_by_global_norm_matches_reference_rule():
     """utils/optimization.py:233-237 (tf.clip_by_global_norm): g * clip / max(||g||, clip) over ALL gradients at once."""
     from merlot_amd import ParamStore

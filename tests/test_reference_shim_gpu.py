@@ -1,7 +1,8 @@
 """GPU: the HIP path DIRECTLY against the fixtures produced by the reference's own program (run under
 oracle/tf_shim.py in the build container, tests/golden/make_reference_golden.py) -- no oracle in the comparison.
 Tolerances as everywhere (bf16 compute vs an fp32 reference): hidden states rel-L2 <= 2e-2, scalar
-losses <= 1e-2 abs (summed loss 2e-2), gradients rel-L2 <= 0.12 per sampled tensor / 0.2 contrastive head, integer
+losses <= 1e-2 abs (summed loss 2e-2), gradients per sampled tensor within the per-class rel-L2 bounds of
+tests/test_grad_classes_gpu.py (3e-2; dense kernels 4e-2; the contrastive head at 8 segments 6e-2 -- rounds 1-4 asserted 0.12 / 0.2), integer
 outputs exact; optimizer: bf16 states exact up to one bf16 ulp on <= 0.1 % of elements, parameters rtol 1e-5."""
 import os
 
@@ -10,10 +11,16 @@ import pytest
 import torch
 
 from common import tiny_config, synth_batch, rel_l2, head
+from grad_parity import tensor_class
 from oracle import merlot_oracle as mo           # weight generator only (init_weights is seeded and shared)
 from oracle import optimizer_oracle as oo
 
 pytestmark = pytest.mark.gpu
+GRAD_REL = {'bias': 3e-2, 'ln': 3e-2, 'pos': 3e-2, 'emb': 3e-2, 'kernel': 4e-2}
+
+
+def grad_bound(name):
+    return 6e-2 if name.startswith('contrastive/') else GRAD_REL[tensor_class(name)]
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
@@ -65,12 +72,12 @@ def test_hip_model_matches_reference_program_config1():
         if n.endswith('key_layer/bias'):
             continue
         rels.append(abs(float(gt[n].double().norm()) - ref_norm) / ref_norm)
-    assert np.median(rels) < 2e-2 and max(rels) < 0.15
+    assert np.median(rels) < 1e-2 and max(rels) < 5e-2, (np.median(rels), max(rels))
     for k in fx.files:
         if k.startswith('grad/'):
             n = k[5:]
             r = rel_l2(torch.from_numpy(head(gt[n].float().cpu().numpy())), torch.from_numpy(fx[k]))
-            assert r < (0.2 if n.startswith('contrastive/') else 0.12), (n, r)
+            assert r < grad_bound(n), (n, r)
 
 
 def test_hip_sort_story_matches_reference_model_fn():
@@ -204,6 +211,6 @@ def test_hip_config_variants_match_reference_program(name):
         for k in fx.files:
             if k.startswith(p + 'grad/'):
                 n = k[len(p) + 5:]
-                assert rel_l2(torch.from_numpy(head(gt[n].float().cpu().numpy())), torch.from_numpy(fx[k])) < 0.12, n
+                assert rel_l2(torch.from_numpy(head(gt[n].float().cpu().numpy())), torch.from_numpy(fx[k])) < grad_bound(n), n
     else:
         pytest.fail('masked_idx differs from the reference run (attention_summs tie?)')
