@@ -2,6 +2,10 @@
 // variance, eps inside the rsqrt, y = x*s - mean*s + beta with s = rstd*gamma.
 // HBM-bound: one wave per row, each lane owns 4 contiguous features per 256-wide slab (8-byte bf16 /
 // 16-byte f32 accesses, 512 B / 1 KiB coalesced per wave instruction); row statistics by wave shuffles.
+// (Round 5 measured the 16-byte variant for bf16 rows of 768 features -- every lane one 16-B chunk, the lower half-wave a second one: two
+// instructions per row and operand instead of three --: forward level (252 vs 254 us at 405 504 rows, 4.9 TB/s), backward SLOWER (512 vs
+// 450 - 467 us: half the wave idles in every second instruction and the per-lane partials double); not kept, scripts/exp_ln_wide.py's
+// numbers are in profiles/r05_q_ln_wide.txt.)
 #include "common.h"
 
 namespace {
