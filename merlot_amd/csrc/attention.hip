@@ -925,6 +925,15 @@ extern "C" int merlot_attention_fwd(const void* qkv, int64_t ld, void* out, int6
         rc = pp_fwd(a, (hipStream_t)stream);
         return rc ? rc : merlot_launch_status("merlot_attention_fwd");
     }
+    // ... and its masked sibling the plain forward of 257 .. 352 masked tokens: the joint encoder in a training step
+    bool ppm = ppm_fwd_ok(a, want_cs);
+#ifdef MERLOT_EXPERIMENTS
+    if (const char* e = getenv("MERLOT_ATTN_PP")) ppm = ppm && atoi(e) != 0;
+#endif
+    if (ppm) {
+        rc = ppm_fwd(a, (hipStream_t)stream);
+        return rc ? rc : merlot_launch_status("merlot_attention_fwd");
+    }
     if (S <= RES_MAX_S && (want_cs || res_plain)) {
         rc = res_fwd(a, (hipStream_t)stream);
         return rc ? rc : merlot_launch_status("merlot_attention_fwd");

@@ -82,3 +82,34 @@ for B, S in ((512 * SC, 198), (128 * SC, 198), (512 * SC, 129)):
         row.append(f'{ {"0": "fused", "1": "pp"}[k] }{ {"0": "", "1": "(data only)", "32": "(data only)", "64": "(no pass 2)", "128": "(no pass 1)", "512": "(setprio)"}[dbg] } {t:7.1f} us')
     os.environ['MERLOT_ATTN_DBG'] = '0'
     print(f'bwd B {B:5d} S {S:4d}: ' + ' | '.join(row), flush=True)
+
+# ---- the masked forward of 257 .. 352 tokens (joint encoder, training step): persistent two-half kernel against the tiled kernel
+from emu_ops import attention_fwd as emu_fwd  # noqa: E402  (fp32 restatement with the reference's masking semantics)
+for B, S in ((3, 328), (2, 257), (2, 300), (5, 352), (30, 328), (64, 289)):
+    qkv = (torch.randn(B * S, 2304, device='cuda') * 0.7).bfloat16()
+    valid = (torch.rand(B, S, device='cuda') > 0.2).to(torch.uint8)
+    valid[:, 0] = 1
+    valid[0, S // 2:] = 0                                 # a long padded tail
+    outs = {}
+    for k in ('0', '1'):
+        os.environ['MERLOT_ATTN_PP'] = k
+        outs[k] = ops.attention_fwd(qkv, B, S, 12, valid)
+    torch.cuda.synchronize()
+    o_ref, lse_ref = emu_fwd(qkv.cpu(), B, S, 12, valid.cpu())
+    e = [float((outs[k][0].float().cpu() - o_ref.float()).abs().max()) for k in ('0', '1')]
+    el = [float((outs[k][1].cpu() - lse_ref).abs().max()) for k in ('0', '1')]
+    d = float((outs['0'][0].float() - outs['1'][0].float()).abs().max())
+    print(f'masked fwd B {B:4d} S {S:4d}: |o - ref| tiled {e[0]:.2e} pp {e[1]:.2e} | |lse - ref| tiled {el[0]:.2e} pp {el[1]:.2e} | tiled vs pp {d:.2e}', flush=True)
+    assert e[1] < 2.5e-2 and el[1] < 2e-2, 'masked pp forward off'
+for B, S in ((128 * SC, 328), (128 * SC, 289)):
+    qkv = (torch.randn(B * S, 2304, device='cuda') * 0.7).bfloat16()
+    valid = (torch.rand(B, S, device='cuda') > 0.1).to(torch.uint8)
+    valid[:, 0] = 1
+    row = []
+    for k, dbg in (('0', '0'), ('1', '0'), ('0', '0'), ('1', '0'), ('1', '32')):
+        os.environ['MERLOT_ATTN_PP'] = k
+        os.environ['MERLOT_ATTN_DBG'] = dbg
+        t = timeit(lambda: ops.attention_fwd(qkv, B, S, 12, valid))
+        row.append(f'{ {"0": "tiled", "1": "pp"}[k] }{"(data only)" if dbg != "0" else ""} {t:7.1f} us')
+    os.environ['MERLOT_ATTN_DBG'] = '0'
+    print(f'masked fwd B {B:5d} S {S:4d}: ' + ' | '.join(row), flush=True)
