@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 export PYTHONPATH=$PWD:$PWD/scripts:$PWD/tests
-OUT=gpurun_out/r05_j_attn_pp_step_ab.txt
+OUT=gpurun_out/r05_s_attn_pp_step_ab.txt
 : > $OUT
 timeout 900 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "attention" 2>&1 | tail -3 | tee -a $OUT
 for pp in 0 1 0 1; do

@@ -329,9 +329,33 @@ def test_attention_persistent_kernels_many_items_per_workgroup(ops, B, S, heads)
     test_attention_fwd_bwd(ops, B, S, heads, False)
 
 
+@pytest.mark.parametrize("B,S,heads", [(30, 328, 12), (3, 257, 12), (40, 289, 7), (3, 352, 12), (2, 320, 3)])
+def test_attention_persistent_masked_forward_joint_lengths(ops, B, S, heads):
+    """Round 5: the plain forward of 257 .. 352 MASKED tokens (the joint encoder in a training step, S = 328) runs the persistent
+    two-half kernel of csrc/attention_pp.inc (K | V of half the keys resident at a time, an online softmax across the halves, the
+    validity bytes fetched by the loader wave an item ahead): 9 / 10 / 11 key chunks, a chunk boundary exactly at S, more items than
+    workgroups, against the fp32 restatement; the backward of the same call stays on the fused kernel."""
+    test_attention_fwd_bwd(ops, B, S, heads, True)
+
+
+def test_attention_persistent_masked_forward_padded_query_rows_are_uniform(ops):
+    """The reference's -1e10 semantics on the persistent masked path: a padded query row attends uniformly over ALL S keys
+    (utils/transformer.py:109-112), also where the padding spans whole 32-row blocks and a key half."""
+    B, S, heads = 2, 300, 12
+    qkv, _, g = _attn_inputs(B, S, heads, 5, False)
+    valid = torch.ones((B, S), dtype=torch.uint8)
+    valid[0, 100:] = 0
+    valid[1, 290:] = 0
+    o, lse = ops.attention_fwd(qkv.cuda(), B, S, heads, valid.cuda())
+    v = qkv[:, 2 * heads * 64:].float().view(B, S, -1)
+    assert rel_l2(o.float().cpu().view(B, S, -1)[0, 100:], v[0].mean(0, keepdim=True).expand(200, -1)) < 1e-2
+    assert rel_l2(o.float().cpu().view(B, S, -1)[1, 290:], v[1].mean(0, keepdim=True).expand(10, -1)) < 1e-2
+    assert float((lse[0, :, 100:].cpu() - float(np.log(S))).abs().max()) < 1e-4
+
+
 @pytest.mark.parametrize("B,S,heads,pad,pads", [(3, 198, 12, False, (64, 8, 16, 8)), (3, 198, 12, False, (64, 64, 128, 64)),
                                                  (2, 130, 5, True, (8, 24, 8, 16)),
-                                                 (2, 328, 3, True, (128, 8, 8, 8)), (1, 512, 2, True, (8, 8, 8, 8)),
+                                                 (2, 328, 3, True, (128, 8, 8, 8)), (2, 328, 3, True, (8, 8, 8, 8)), (1, 512, 2, True, (8, 8, 8, 8)),
                                                  (5, 77, 7, False, (16, 40, 8, 24))])
 def test_attention_nondefault_leading_dims(ops, B, S, heads, pad, pads):
     """The resident / persistent forward and the fused / persistent backward build their LDS-DMA source addresses from the leading
