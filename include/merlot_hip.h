@@ -33,7 +33,7 @@ typedef void* merlot_stream_t;
 
 /* Bumped whenever a signature of this header changes.  merlot_abi_version() returns the value the library was built with;
  * a binding must compare the two before its first call (merlot_amd/lib.py does, and refuses a mismatching library). */
-#define MERLOT_ABI_VERSION 6
+#define MERLOT_ABI_VERSION 7
 
 const char* merlot_last_error(void);
 int merlot_abi_version(void);
@@ -167,9 +167,15 @@ int merlot_ln_bwd(const void* dy, int dy_f32, const void* x, int x_f32, const fl
  * (score exactly -1e10) unless seg[q] == seg[k] or one of the two is 0. */
 /* colsum_lo / colsum_hi (optional, f32 [B,S], ACCUMULATED): the side outputs of merlot_attention_colsum below, produced by
  * the same launch (S <= 512: from the K tile still resident in LDS; longer sequences: a second pass); needs lse. */
+/* workspace (ABI v7; optional): merlot_attention_workspace_bytes() bytes, 4-byte aligned, ZERO on entry and left zero -- the item-claim
+ * counters of the persistent kernels (csrc/attention_pp.inc: one workgroup per CU walks the (batch, head) items with the next items'
+ * operands in flight; unmasked 65 .. 224 tokens forward and backward, masked 257 .. 352 tokens forward without side outputs).  Caller-owned
+ * like the GEMMs' (no library state): one block per concurrently used stream.  Without it (NULL) the one-launch-per-item kernels run. */
+int64_t merlot_attention_workspace_bytes(void);
 int merlot_attention_fwd(const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse, const uint8_t* valid,
                          const int32_t* seg, int B, int S, int heads, float scale, float* colsum_lo, float* colsum_hi,
-                         int qsplit, int valid_q_only, float weight, merlot_stream_t stream);
+                         int qsplit, int valid_q_only, float weight, void* workspace, int64_t workspace_bytes,
+                         merlot_stream_t stream);
 /* dqkv (bf16, same layout as qkv) from dout.  delta: f32 workspace [B*heads*S] (written by the dQ kernel, read by the dK/dV kernel).
  * log_lo / log_hi (optional, f32 [B,S], ACCUMULATED; ABI v5): merlot_attention_colsum's valid_q_only = 1 output (the attention LOG of
  * model/modeling.py:186-203: per-key sums of P over the valid query rows below / from log_qsplit, times log_weight) taken from the
@@ -179,7 +185,7 @@ int merlot_attention_fwd(const void* qkv, int64_t ld, void* out, int64_t ldo, fl
 int merlot_attention_bwd(const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout, int64_t lddo,
                          const float* lse, const uint8_t* valid, const int32_t* seg, void* dqkv, int64_t lddqkv,
                          float* delta, int B, int S, int heads, float scale, float* log_lo, float* log_hi, int log_qsplit,
-                         float log_weight, merlot_stream_t stream);
+                         float log_weight, void* workspace, int64_t workspace_bytes, merlot_stream_t stream);
 /* Side outputs the reference takes from its stacked [B,layers,S,S] head-mean probabilities, without
  * materialising SxS:  colsum_lo[b,key] += weight * sum_h sum_{q <  qsplit} P[b,h,q,key]
  *                     colsum_hi[b,key] += weight * sum_h sum_{q >= qsplit} P[b,h,q,key]

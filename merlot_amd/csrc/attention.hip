@@ -24,6 +24,7 @@
 
 namespace {
 
+constexpr int64_t ATTN_WORKSPACE_BYTES = 64;             // item-claim counters of the persistent kernels (attention_pp.inc)
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 constexpr float MASKED_T = -1.0e10f * LOG2E;  // -1e10 in log2 units
@@ -50,6 +51,7 @@ struct AttnArgs {
     int qsplit;
     int valid_q_only;
     float weight;
+    unsigned int* ctr;   // persistent kernels (attention_pp.inc): the caller's item-claim counters (zero on entry, left zero), or nullptr
     int dbg;             // experiments build only (MERLOT_ATTN_DBG): 1 = the streaming kernels move the data but skip the tile arithmetic
 };
 
@@ -895,10 +897,12 @@ int check_attn(const void* qkv, int64_t ld, int B, int S, int heads) {
 
 }  // namespace
 
+extern "C" int64_t merlot_attention_workspace_bytes(void) { return ATTN_WORKSPACE_BYTES; }
+
 extern "C" int merlot_attention_fwd(const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse,
                                     const uint8_t* valid, const int32_t* seg, int B, int S, int heads, float scale,
                                     float* colsum_lo, float* colsum_hi, int qsplit, int valid_q_only, float weight,
-                                    merlot_stream_t stream) {
+                                    void* workspace, int64_t workspace_bytes, merlot_stream_t stream) {
     int rc = check_attn(qkv, ld, B, S, heads);
     if (rc) return rc;
     MERLOT_CHECK(out && ldo >= heads * 64 && ldo % 4 == 0, MERLOT_ESHAPE, "attention_fwd: bad out/ldo");
@@ -909,6 +913,10 @@ extern "C" int merlot_attention_fwd(const void* qkv, int64_t ld, void* out, int6
     a.qkv = (const bf16*)qkv; a.ld = ld; a.out = (bf16*)out; a.ldo = ldo; a.lse = lse; a.valid = valid; a.seg = seg;
     a.B = B; a.S = S; a.heads = heads; a.scale = scale;
     a.colsum_lo = colsum_lo; a.colsum_hi = colsum_hi; a.qsplit = qsplit; a.valid_q_only = valid_q_only; a.weight = weight;
+    // the persistent kernels claim their items from the caller's counters (ABI v7); without a workspace the one-shot kernels run
+    MERLOT_CHECK(!workspace || (workspace_bytes >= ATTN_WORKSPACE_BYTES && ((uintptr_t)workspace & 3) == 0), MERLOT_ESHAPE,
+                 "attention_fwd: workspace must be merlot_attention_workspace_bytes() bytes, 4-byte aligned, zero on entry");
+    a.ctr = (unsigned int*)workspace;
     // K and V of one (batch, head) resident in LDS (attention_res.inc): with side outputs (they come from the same launch), and
     // for the plain forward of short unmasked sequences (the ViT pass: K | V through the CU's memory pipe once instead of once
     // per 128-row block, 685 vs 780 us at the bench shape, profiles/r03_j_attention_res.txt; masked sequences: level -> tiled)
@@ -978,7 +986,7 @@ extern "C" int merlot_attention_bwd(const void* qkv, int64_t ld, const void* out
                                     int64_t lddo, const float* lse, const uint8_t* valid, const int32_t* seg, void* dqkv,
                                     int64_t lddqkv, float* delta, int B, int S, int heads, float scale,
                                     float* log_lo, float* log_hi, int log_qsplit, float log_weight,
-                                    merlot_stream_t stream) {
+                                    void* workspace, int64_t workspace_bytes, merlot_stream_t stream) {
     int rc = check_attn(qkv, ld, B, S, heads);
     if (rc) return rc;
     MERLOT_CHECK(out && dout && lse && dqkv && delta, MERLOT_ESHAPE, "attention_bwd: null operand");
@@ -989,6 +997,9 @@ extern "C" int merlot_attention_bwd(const void* qkv, int64_t ld, const void* out
     MERLOT_CHECK(!seg || valid, MERLOT_ESHAPE, "attention: a segment mask needs the validity mask too");
     a.lse = (float*)lse; a.delta = delta; a.valid = valid; a.seg = seg; a.dqkv = (bf16*)dqkv; a.lddqkv = lddqkv;
     a.B = B; a.S = S; a.heads = heads; a.scale = scale;
+    MERLOT_CHECK(!workspace || (workspace_bytes >= ATTN_WORKSPACE_BYTES && ((uintptr_t)workspace & 3) == 0), MERLOT_ESHAPE,
+                 "attention_bwd: workspace must be merlot_attention_workspace_bytes() bytes, 4-byte aligned, zero on entry");
+    a.ctr = (unsigned int*)workspace;
     // the attention LOG side output (valid pairs only), taken from the backward instead of the forward: in the fused kernel it is
     // two lane accumulators of the dK / dV pass; on every other path the tiled column-sum kernel recomputes P (as the forward would)
     const bool want_log = log_lo != nullptr || log_hi != nullptr;

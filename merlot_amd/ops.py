@@ -59,6 +59,19 @@ def _nt_ws():
     return buf.data_ptr(), buf.numel() * 4
 
 
+_ATTN_WS = {}
+
+
+def _attn_ws():
+    """(pointer, bytes) of the item-claim counter block of the persistent attention kernels (include/merlot_hip.h, ABI v7: caller-owned, zero on
+    entry, left zero): one block per (device, stream), separate from the GEMMs'."""
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    buf = _ATTN_WS.get(key)
+    if buf is None:
+        buf = _ATTN_WS[key] = torch.zeros(LIB.query('merlot_attention_workspace_bytes') // 4, device='cuda', dtype=torch.int32)
+    return buf.data_ptr(), buf.numel() * 4
+
+
 def _chk(t, dtype, name):
     if t is None:
         return
@@ -249,7 +262,7 @@ def attention_fwd(qkv, B, S, heads, valid=None, need_lse=True, seg=None, colsum_
     lse = torch.empty((B, heads, S), device=qkv.device, dtype=F32) if need_lse else None
     call('merlot_attention_fwd', _p(qkv), qkv.stride(0), _p(out), out.stride(0), _p(lse), _p(valid), _p(seg), B, S,
          heads, 0.125, _p(colsum_lo), _p(colsum_hi), S if qsplit is None else qsplit, 1 if valid_q_only else 0, float(weight),
-         _stream())
+         *_attn_ws(), _stream())
     return out, lse
 
 
@@ -285,7 +298,7 @@ def attention_bwd(qkv, out, dout, lse, B, S, heads, valid=None, seg=None, log_lo
     delta = torch.empty((B, heads, S), device=qkv.device, dtype=F32)
     call('merlot_attention_bwd', _p(qkv), qkv.stride(0), _p(out), out.stride(0), _p(dout), dout.stride(0), _p(lse),
          _p(valid), _p(seg), _p(dqkv), dqkv.stride(0), _p(delta), B, S, heads, 0.125, _p(log_lo), _p(log_hi),
-         S if log_split is None else int(log_split), float(log_weight), _stream())
+         S if log_split is None else int(log_split), float(log_weight), *_attn_ws(), _stream())
     return dqkv
 
 

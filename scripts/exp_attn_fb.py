@@ -14,7 +14,7 @@ def bwd(qkv, o, do, lse, B, S, valid):
     dqkv = torch.full_like(qkv, float('nan'))
     delta = torch.full((B, 12, S), float('nan'), device='cuda')
     call('merlot_attention_bwd', _p(qkv), qkv.stride(0), _p(o), o.stride(0), _p(do), do.stride(0), _p(lse), _p(valid), None, _p(dqkv),
-         dqkv.stride(0), _p(delta), B, S, 12, 0.125, None, None, S, 1.0, ops._stream())
+         dqkv.stride(0), _p(delta), B, S, 12, 0.125, None, None, S, 1.0, *ops._attn_ws(), ops._stream())
     return dqkv, delta
 
 

@@ -29,7 +29,7 @@ for B, S, heads, masked, pads in ((3, 198, 12, False, (64, 8, 16, 8)), (2, 130, 
         o_full = torch.full((B * S, ldo), float('nan'), device='cuda', dtype=torch.bfloat16)
         lse = torch.empty(B, heads, S, device='cuda')
         call('merlot_attention_fwd', qkv_full.data_ptr(), ld, o_full.data_ptr(), ldo, lse.data_ptr(), vp, None, B, S, heads, 0.125,
-             None, None, S, 0, 1.0, ops._stream())
+             None, None, S, 0, 1.0, *ops._attn_ws(), ops._stream())
         outs[res] = (o_full[:, :D].float().clone(), lse.clone(), o_full)
     d_o = float((outs['0'][0] - outs['1'][0]).abs().max())
     d_l = float((outs['0'][1] - outs['1'][1]).abs().max())
@@ -44,7 +44,7 @@ for B, S, heads, masked, pads in ((3, 198, 12, False, (64, 8, 16, 8)), (2, 130, 
         dqkv = torch.full((B * S, lddq), float('nan'), device='cuda', dtype=torch.bfloat16)
         delta = torch.full((B, heads, S), float('nan'), device='cuda')
         call('merlot_attention_bwd', qkv_full.data_ptr(), ld, o_full.data_ptr(), ldo, do_full.data_ptr(), lddo, lse.data_ptr(), vp, None,
-             dqkv.data_ptr(), lddq, delta.data_ptr(), B, S, heads, 0.125, None, None, S, 1.0, ops._stream())
+             dqkv.data_ptr(), lddq, delta.data_ptr(), B, S, heads, 0.125, None, None, S, 1.0, *ops._attn_ws(), ops._stream())
         res_b[k] = (dqkv, delta)
     torch.cuda.synchronize()
     same = torch.equal(res_b['0'][0][:, :3 * D].view(torch.int16), res_b['1'][0][:, :3 * D].view(torch.int16))

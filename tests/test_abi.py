@@ -8,7 +8,7 @@ from merlot_amd import lib
 def test_header_declares_the_survey_export_list():
     protos = lib.parse_header()
     need = ['merlot_patch_embed_fwd', 'merlot_patch_embed_wgrad', 'merlot_gemm_bf16_nt', 'merlot_gemm_bf16_tn',
-            'merlot_ln_fwd', 'merlot_ln_bwd', 'merlot_attention_fwd', 'merlot_attention_bwd', 'merlot_attention_colsum',
+            'merlot_ln_fwd', 'merlot_ln_bwd', 'merlot_attention_fwd', 'merlot_attention_bwd', 'merlot_attention_colsum', 'merlot_attention_workspace_bytes',
             'merlot_gather_add4', 'merlot_scatter_add_rows', 'merlot_softmax_ce', 'merlot_cls_avgpool_fwd',
             'merlot_cls_avgpool_bwd', 'merlot_adamw_step', 'merlot_mask_inputs', 'merlot_temporal_labels',
             'merlot_shuffled_idx', 'merlot_last_error', 'merlot_gemm_bf16_nt_plan']
@@ -29,7 +29,7 @@ SURVEY_8B = {
     # epilogue enum {none, bias, bias_gelu, bias_residual, bias_dropout_residual} = merlot_epilogue + bias / dropout_p arguments
     'merlot_ln_residual_fwd': ['merlot_ln_fwd', 'merlot_gemm_bf16_nt'],     # the residual add lives in the producing GEMM's epilogue
     'merlot_ln_residual_bwd': ['merlot_ln_bwd'],                            # dres / branch gradient / bias column sums fused
-    'merlot_qkv_attention_fwd': ['merlot_attention_fwd'],                   # colsum_out / blocksum_out = colsum_lo / colsum_hi
+    'merlot_qkv_attention_fwd': ['merlot_attention_fwd', 'merlot_attention_workspace_bytes'],                   # colsum_out / blocksum_out = colsum_lo / colsum_hi
     'merlot_qkv_attention_bwd': ['merlot_attention_bwd'],
     'merlot_bias_gelu_fwd': ['merlot_gelu_fwd'],
     'merlot_bias_gelu_bwd': ['merlot_gelu_bwd'],
@@ -69,7 +69,7 @@ def test_library_exports_every_declared_symbol():
     for name in lib.parse_header():
         assert hasattr(dll, name), f"{name} declared in include/merlot_hip.h but not exported"
     d = lib.LIB.load()
-    assert d.merlot_abi_version() == 6
+    assert d.merlot_abi_version() == 7
     assert d.merlot_last_error() is not None
 
 
@@ -121,8 +121,12 @@ def test_argument_validation_happens_before_any_launch():
     assert rc == -1 and b'need 64' in d.merlot_last_error()
     rc = d.merlot_ln_fwd(1, 0, 1, 1, 1, None, None, None, 4, 700, 1e-5, None)
     assert rc == -1 and b'H=700' in d.merlot_last_error()
-    rc = d.merlot_attention_fwd(None, 2304, None, 768, None, None, None, 1, 4, 12, 0.125, None, None, 4, 0, 1.0, None)
+    rc = d.merlot_attention_fwd(None, 2304, None, 768, None, None, None, 1, 4, 12, 0.125, None, None, 4, 0, 1.0, None, 0, None)
     assert rc == -1
+    # ABI v7: the persistent attention kernels claim their items from CALLER-owned counters; a workspace of the wrong size is refused
+    assert d.merlot_attention_workspace_bytes() == 64
+    rc = d.merlot_attention_fwd(fake, 2304, fake, 768, fake, None, None, 1, 198, 12, 0.125, None, None, 198, 0, 1.0, fake, 16, None)
+    assert rc == -1 and b'workspace' in d.merlot_last_error()
     # the frame-kernel job table is checked on its HOST copy before anything is launched
     import numpy as np
     from merlot_amd.input_pipeline import JOB_DTYPE

@@ -4,7 +4,8 @@ vector-memory operations a wave issues per item.  That only holds while the COMP
 reads off the gfx950 assembly (CPU only: hipcc cross-compiles):
   1. no scratch: a spill is a vector-memory operation the counts do not know (and a reload is waited for with a drain);
   2. no compiler-inserted `s_waitcnt vmcnt` inside the kernels (hipcc drains the queue for a pending LDS-DMA it can see in front of
-     every ds_read_b64_tr_b16, and for any ordinary load beside one -- the reason the requests are assembly);
+     every ds_read_b64_tr_b16, and for any ordinary load beside one -- the reason the requests are assembly) -- except the loader
+     wave's waits for its own compiler-issued atomics (the two item claims of the prologue, the departure ticket at the end);
   3. the destination registers of a hand-issued load are neither read nor written between the load and the kernel's own wait
      (round 5: with issue and use on two sides of the loop's back edge hipcc moved the registers while the load was in flight)."""
 import os
@@ -35,6 +36,7 @@ def check_kernel(name, body):
     own_waits_only = 'ppm_kernel' not in name
     bad, in_asm, pending = [], False, {}
     n_dma = n_wait = 0
+    own_atomic = False                                   # a compiler-issued returning atomic since the last wait (claim / departure)
     for i, ln in enumerate(body):
         if '#ASMSTART' in ln:
             in_asm = True
@@ -47,11 +49,19 @@ def check_kernel(name, body):
             continue
         if 'scratch_' in code:
             bad.append(f'{name}: scratch access {code!r}')
+        if code.startswith('global_atomic_') and not in_asm:
+            own_atomic = True
         if 's_waitcnt' in code and 'vmcnt' in code:
-            if not in_asm and own_waits_only:
+            if not in_asm and own_waits_only and not own_atomic:
                 bad.append(f'{name}: compiler-inserted {code!r} (line {i})')
             n_wait += 1
             pending = {}
+            own_atomic = False
+            continue
+        m = re.match(r'global_atomic_add (v\d+), ', code)
+        if m and in_asm:                                 # the hand-issued item claim: its answer register is in flight until the next wait
+            for r in _regs(m.group(1)):
+                pending[r] = i
             continue
         if re.match(r'buffer_load_dword(x4)? ', code) and code.endswith('lds'):
             assert in_asm, f'{name}: an LDS-DMA the compiler can see: {code!r}'

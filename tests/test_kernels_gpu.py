@@ -8,6 +8,7 @@ import pytest
 import torch
 
 import emu_ops as E
+import merlot_amd.ops as ops_mod
 from common import rel_l2
 
 pytestmark = pytest.mark.gpu
@@ -313,7 +314,8 @@ def test_attention_bwd_fused_short_unmasked(ops, B, S, heads):
     dqkv = torch.full_like(qkv, float('nan'))
     delta = torch.full((B, heads, S), float('nan'), device='cuda')
     call('merlot_attention_bwd', qkv.data_ptr(), qkv.stride(0), o.data_ptr(), o.stride(0), do.data_ptr(), do.stride(0), lse.data_ptr(),
-         None, None, dqkv.data_ptr(), dqkv.stride(0), delta.data_ptr(), B, S, heads, 0.125, None, None, S, 1.0, torch.cuda.current_stream().cuda_stream)
+         None, None, dqkv.data_ptr(), dqkv.stride(0), delta.data_ptr(), B, S, heads, 0.125, None, None, S, 1.0, *ops_mod._attn_ws(),
+         torch.cuda.current_stream().cuda_stream)
     assert not bool(torch.isnan(dqkv.float()).any())
     want = (do.float() * o.float()).view(B, S, heads, 64).sum(-1).permute(0, 2, 1)
     assert float((delta - want).abs().max()) < 1e-3 * (1 + float(want.abs().max()))
@@ -327,6 +329,38 @@ def test_attention_persistent_kernels_many_items_per_workgroup(ops, B, S, heads)
     the list: forward and backward against the fp32 torch restatement."""
     assert B * heads > 256
     test_attention_fwd_bwd(ops, B, S, heads, False)
+
+
+def test_attention_persistent_kernels_leave_their_claim_counters_zero_and_fall_back_without_a_workspace(ops):
+    """ABI v7: the persistent kernels draw their items from CALLER-owned counters (zero on entry, left zero by the last workgroup out, so
+    that the next launch on the stream can use the same block); with workspace = NULL the entries run the one-launch-per-item kernels --
+    same forward within rounding, bit-identical backward."""
+    from merlot_amd.lib import call
+    ws_ptr, ws_bytes = ops_mod._attn_ws()
+    ws = next(v for v in ops_mod._ATTN_WS.values() if v.data_ptr() == ws_ptr)
+    stream = torch.cuda.current_stream().cuda_stream
+    for B, S, heads, pad in ((30, 198, 12, False), (25, 328, 12, True), (1, 100, 3, False)):
+        qkv, valid, g = _attn_inputs(B, S, heads, 77 + S, pad)
+        qkv = qkv.cuda()
+        vp = valid.cuda() if valid is not None else None
+        do = rnd((B * S, heads * 64), g).cuda()
+        res = []
+        for with_ws in (True, False):
+            o = torch.empty(B * S, heads * 64, device='cuda', dtype=BF16)
+            lse = torch.empty(B, heads, S, device='cuda')
+            dqkv = torch.full_like(qkv, float('nan'))
+            delta = torch.empty(B, heads, S, device='cuda')
+            w = (ws_ptr, ws_bytes) if with_ws else (None, 0)
+            call('merlot_attention_fwd', qkv.data_ptr(), qkv.stride(0), o.data_ptr(), o.stride(0), lse.data_ptr(), vp.data_ptr() if pad else None,
+                 None, B, S, heads, 0.125, None, None, S, 0, 1.0, *w, stream)
+            call('merlot_attention_bwd', qkv.data_ptr(), qkv.stride(0), o.data_ptr(), o.stride(0), do.data_ptr(), do.stride(0), lse.data_ptr(),
+                 vp.data_ptr() if pad else None, None, dqkv.data_ptr(), dqkv.stride(0), delta.data_ptr(), B, S, heads, 0.125, None, None, S, 1.0,
+                 *w, stream)
+            torch.cuda.synchronize()
+            assert int(ws.abs().sum()) == 0                  # claims and departures reset by the last workgroup out
+            res.append((o, lse, dqkv))
+        assert rel_l2(res[0][0], res[1][0]) < 4e-3 and float((res[0][1] - res[1][1]).abs().max()) < 1e-4
+        assert not bool(torch.isnan(res[0][2].float()).any()) and rel_l2(res[0][2], res[1][2]) < 8e-3
 
 
 @pytest.mark.parametrize("B,S,heads", [(30, 328, 12), (3, 257, 12), (40, 289, 7), (3, 352, 12), (2, 320, 3)])
@@ -373,7 +407,7 @@ def test_attention_nondefault_leading_dims(ops, B, S, heads, pad, pads):
     lse = torch.empty(B, heads, S, device='cuda')
     stream = torch.cuda.current_stream().cuda_stream
     call('merlot_attention_fwd', qkv_full.data_ptr(), ld, o_full.data_ptr(), ldo, lse.data_ptr(), vp.data_ptr() if pad else None, None, B, S,
-         heads, 0.125, None, None, S, 0, 1.0, stream)
+         heads, 0.125, None, None, S, 0, 1.0, *ops_mod._attn_ws(), stream)
     o_ref, lse_ref = E.attention_fwd(qkv, B, S, heads, valid)
     assert rel_l2(o_full[:, :D], o_ref) < 8e-3 and float((lse.cpu() - lse_ref).abs().max()) < 2e-2
     assert bool(torch.isnan(o_full[:, D:].float()).all())
@@ -386,7 +420,7 @@ def test_attention_nondefault_leading_dims(ops, B, S, heads, pad, pads):
     dqkv = torch.full((B * S, lddq), float('nan'), device='cuda', dtype=BF16)
     delta = torch.empty((B, heads, S), device='cuda')
     call('merlot_attention_bwd', qkv_full.data_ptr(), ld, o_full.data_ptr(), ldo, do_full.data_ptr(), lddo, lse.data_ptr(),
-         vp.data_ptr() if pad else None, None, dqkv.data_ptr(), lddq, delta.data_ptr(), B, S, heads, 0.125, None, None, S, 1.0, stream)
+         vp.data_ptr() if pad else None, None, dqkv.data_ptr(), lddq, delta.data_ptr(), B, S, heads, 0.125, None, None, S, 1.0, *ops_mod._attn_ws(), stream)
     dq_ref = E.attention_bwd(qkv, o_ref, do, lse_ref, B, S, heads, valid).float()
     got = dqkv[:, :3 * D].float().cpu()
     for name, sl in [('dq', slice(0, D)), ('dk', slice(D, 2 * D)), ('dv', slice(2 * D, 3 * D))]:
