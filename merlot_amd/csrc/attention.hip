@@ -1021,6 +1021,21 @@ extern "C" int merlot_attention_bwd(const void* qkv, int64_t ld, const void* out
         rc = pp_bwd(a, s);
         return rc ? rc : merlot_launch_status("merlot_attention_bwd");
     }
+    if (want_log && !valid) {
+        // an unmasked stack with the attention log (no product configuration): the log comes from the tiled column-sum kernel whichever kernel forms the
+        // gradients, so they are formed by the one the plain call uses -- the same values with and without the log
+        AttnArgs g = a;
+        g.colsum_lo = g.colsum_hi = nullptr;
+        bool ppg = pp_bwd_ok(g);
+#ifdef MERLOT_EXPERIMENTS
+        if (const char* e = getenv("MERLOT_ATTN_PP")) ppg = ppg && atoi(e) != 0;
+#endif
+        if (ppg) {
+            hipLaunchKernelGGL(attn_colsum_kernel, dim3(cdiv(S, 32), heads, B), dim3(64), 0, s, a);
+            rc = pp_bwd(g, s);
+            return rc ? rc : merlot_launch_status("merlot_attention_bwd");
+        }
+    }
     if (fb_mode) {
         if (want_log && !fb_log_ok(a)) hipLaunchKernelGGL(attn_colsum_kernel, dim3(cdiv(S, 32), heads, B), dim3(64), 0, s, a);
         rc = fb_bwd(a, s);

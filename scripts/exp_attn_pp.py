@@ -75,11 +75,15 @@ for B, S in ((512 * SC, 198), (128 * SC, 198), (512 * SC, 129)):
     o, lse = ops.attention_fwd(qkv, B, S, 12, None)
     do = torch.randn_like(o)
     row = []
-    for k, dbg in (('0', '0'), ('1', '0'), ('0', '0'), ('1', '0'), ('0', '1'), ('1', '32'), ('1', '64'), ('1', '128')):
+    PROBES = {1: 'p2 without dK / dV MFMAs + transposing reads', 2: 'p2 without transposing reads', 3: 'p2 without exp', 4: 'p2 without vector arithmetic',
+              5: 'p2 without row-vector reads', 6: 'p2 without S / dP MFMAs + fragment reads'}
+    for k, dbg in (('0', '0'), ('1', '0'), ('0', '0'), ('1', '0'), ('0', '1'), ('1', '32'), ('1', '64'), ('1', '128')) + \
+            (tuple(('1', str(q << 16)) for q in PROBES) + (('1', '0'),) if S == 198 else ()):
         os.environ['MERLOT_ATTN_PP'] = k
         os.environ['MERLOT_ATTN_DBG'] = dbg
         t = timeit(lambda: ops.attention_bwd(qkv, o, do, lse, B, S, 12, None))
-        row.append(f'{ {"0": "fused", "1": "pp"}[k] }{ {"0": "", "1": "(data only)", "32": "(data only)", "64": "(no pass 2)", "128": "(no pass 1)", "512": "(setprio)"}[dbg] } {t:7.1f} us')
+        tag = {"0": "", "1": "(data only)", "32": "(data only)", "64": "(no pass 2)", "128": "(no pass 1)"}.get(dbg) if int(dbg) < 65536 else f'({PROBES[int(dbg) >> 16]})'
+        row.append(f'{ {"0": "fused", "1": "pp"}[k] }{tag} {t:7.1f} us')
     os.environ['MERLOT_ATTN_DBG'] = '0'
     print(f'bwd B {B:5d} S {S:4d}: ' + ' | '.join(row), flush=True)
 

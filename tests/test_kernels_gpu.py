@@ -334,7 +334,8 @@ def test_attention_persistent_kernels_many_items_per_workgroup(ops, B, S, heads)
 def test_attention_persistent_kernels_leave_their_claim_counters_zero_and_fall_back_without_a_workspace(ops):
     """ABI v7: the persistent kernels draw their items from CALLER-owned counters (zero on entry, left zero by the last workgroup out, so
     that the next launch on the stream can use the same block); with workspace = NULL the entries run the one-launch-per-item kernels --
-    same forward within rounding, bit-identical backward."""
+    same forward and backward within rounding (until the end of round 5 the backward was the fused kernel's bit for bit; since its dK / dV pass starts the
+    accumulators from - lse / scale and - delta instead of subtracting them afterwards the two differ by an fp32 rounding here and there)."""
     from merlot_amd.lib import call
     ws_ptr, ws_bytes = ops_mod._attn_ws()
     ws = next(v for v in ops_mod._ATTN_WS.values() if v.data_ptr() == ws_ptr)
