@@ -76,6 +76,11 @@ def test_dp2_matches_single_process_oracle(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     res = [torch.load(os.path.join(str(tmp_path), f'rank{r}.pt')) for r in range(world)]
+    check_dp2(res)
+
+
+def check_dp2(res, world=2):
+    """What two replicas must have produced (shared with tests/test_dist_gpu.py, where the two ranks run the HIP kernels)."""
     # every replica ends with the same (summed) gradient arena
     for k in res[0]['grad']:
         assert torch.allclose(res[0]['grad'][k], res[1]['grad'][k], rtol=0, atol=0), k
