@@ -237,6 +237,7 @@ def main():
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--cpu-baseline-worker', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--cpu-emulate', action='store_true', help=argparse.SUPPRESS)   # tests only: gloo + torch-CPU emulated ops, tiny model
+    ap.add_argument('--one-device-gloo', action='store_true', help=argparse.SUPPRESS)   # tests only: every rank on cuda:0, gloo group (RCCL refuses two ranks on one device)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         cpu_baseline_worker(args.cpu_baseline_worker)
@@ -273,8 +274,10 @@ def main():
         ops.KernelTimer = None
         device = torch.device('cpu')
     else:
-        torch.cuda.set_device(local_rank)
-        device = torch.device('cuda', local_rank)
+        # (--one-device-gloo, tests/test_dist_gpu.py: this file's N > 1 code path on the PRODUCT kernels where only one GPU exists -- a plumbing run)
+        dev_idx = 0 if args.one_device_gloo else local_rank
+        torch.cuda.set_device(dev_idx)
+        device = torch.device('cuda', dev_idx)
     ctx = None
     force_dist = os.environ.get('MERLOT_FORCE_DIST', '0') == '1' and 'RANK' in os.environ
     if world > 1 or force_dist:
@@ -283,7 +286,7 @@ def main():
         # the channels so the overlapped gradient all-reduce takes at most 16 of the 256 CUs (the GEMMs claim their tiles
         # dynamically and absorb that, profiles/r02_c_dp_contention.txt).  Override by exporting NCCL_MAX_NCHANNELS.
         os.environ.setdefault('NCCL_MAX_NCHANNELS', '16')
-        if args.cpu_emulate:
+        if args.cpu_emulate or args.one_device_gloo:
             dist.init_process_group('gloo')
         else:
             dist.init_process_group('nccl', device_id=device)
@@ -378,7 +381,7 @@ def main():
                                     + ('fp8 forward GEMMs' if fp8 else 'all-bf16 comparison run')),
                        'baseline_config': args.config,
                        'segments_per_gpu_per_step': seg_per_gpu, 'examples_per_gpu': args.examples,
-                       'num_chunks': config.data['num_chunks'], 'parallelism': f'dp{world}', 'grad_reduce': 'sum',
+                       'num_chunks': config.data['num_chunks'], 'parallelism': f'dp{world}' + (' (all ranks on ONE device over gloo: a plumbing run, not a scaling number)' if args.one_device_gloo else ''), 'grad_reduce': 'sum',
                        'stem': 'resnet-hybrid [3,4,9] (merlot.yaml:30)' if args.resnet_stem else 'patch 16x16 (north_star)',
                        'image_size': list(config.model['image_size']), 'train_gflop_per_segment': train_gflop,
                        'final_loss': loss},

@@ -105,3 +105,27 @@ def test_train_loop_two_ranks_on_one_gpu_end_with_the_same_weights(tmp_path):
     assert torch.equal(r0['master'], r1['master']) and bool(torch.isfinite(r0['master']).all())
     prefix = ck.latest_checkpoint(str(tmp_path / 'out'))
     assert prefix.endswith('model.ckpt-2') and int(ck.load_variable(prefix, 'global_step')) == 2
+
+
+@pytest.mark.timeout(900)
+def test_bench_py_two_ranks_on_one_gpu(tmp_path):
+    """bench.py's OWN N > 1 code path (the torch.distributed.run launch contract, Trainer with the overlapped GradReducer and the contrastive
+    all-gather, barrier + max-over-ranks timing, ONE JSON line from rank 0 with the whole-job aggregate) on the product kernels and the full 12 + 12 + 12
+    layer model, two ranks of 4 examples sharing the one GPU of the box over gloo (`--one-device-gloo`, tests only).  A plumbing run: no throughput claim."""
+    import json
+    import subprocess
+    from test_dist_cpu import _free_port
+    root = os.path.dirname(HERE)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+           '--examples', '4', '--one-device-gloo', '--no-cpu-baseline']
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=850, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]                   # rank 0 only
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['steps'] == 2 and res['warmup'] == 1 and res['scaling'] == 'weak' and res['dtype'] == 'bf16'
+    assert res['config']['parallelism'].startswith('dp2 (all ranks on ONE device') and res['config']['segments_per_gpu_per_step'] == 64
+    assert abs(res['value'] - 2 * 64 * 2 / (res['ms_per_step'] * 2 / 1e3)) < 1e-6 * res['value']     # whole-job aggregate over both ranks
+    assert res['config']['final_loss'] == res['config']['final_loss'] and 5.0 < res['config']['final_loss'] < 30.0
+    assert res['roofline']['frac'] > 0.02
