@@ -842,10 +842,16 @@ __device__ __forceinline__ void fast_tile_epilogue(const GemmNTArgs& p, f32x16 (
             for (int e = 0; e < 4; ++e) bias_r[fp][0][e] = bias_r[fp][1][e] = 0.f;
         }
     }
-    // pass q = slab * 4 + ps, slab = fi * NFP + fp: rows m_base + fi*32 + ps*8 + rr, columns n_base + fp*64 + c0 .. +7
+    // pass q = slab * 4 + ps, slab = fi * NFP + fp: rows m_base + fi*32 + ps*8 + rr, columns n_base + fp*64 + c0 .. +7.
+    // (Round 5: every stream's address = ONE per-lane pointer formed here + a wave-uniform offset per pass.  As `base + (int64_t) m * ld + n` per pass
+    // the compiler rebuilt the 64-bit product in vector registers each time: a v_mul_lo, a v_mad_u64_u32 and three 64-bit adds per stream and pass.)
+    const int64_t lane_row = (int64_t)(m_base + rr);
+    const bf16* const aux_lane = HAS_AUX ? p.aux_in + lane_row * p.ld_aux_in + (n_base + c0) : nullptr;
+    bf16* const auxo_lane = (EPI == MERLOT_EPI_GELU && FLAG) ? p.aux_out + lane_row * p.ld_aux_out + (n_base + c0) : nullptr;
+    char* const c_lane = reinterpret_cast<char*>(p.C) + (lane_row * p.ldc + (n_base + c0)) * (OUT_F32 ? 4 : 2);
     auto aux_addr = [&](int q) {
         const int sl = q >> 2, ps = q & 3;
-        return p.aux_in + (int64_t)(m_base + (sl / NFP) * 32 + ps * 8 + rr) * p.ld_aux_in + (n_base + (sl % NFP) * 64 + c0);
+        return aux_lane + ((int64_t)((sl / NFP) * 32 + ps * 8) * p.ld_aux_in + (sl % NFP) * 64);
     };
     bf16x8 aux[PF];
     if (HAS_AUX) {
@@ -872,7 +878,7 @@ __device__ __forceinline__ void fast_tile_epilogue(const GemmNTArgs& p, f32x16 (
             for (int q4 = 0; q4 < 4; ++q4) {
                 f32x4 t;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) t[e] = acc[fi][2 * fp + fj][4 * q4 + e] * ra;
+                for (int e = 0; e < 4; ++e) t[e] = RS ? acc[fi][2 * fp + fj][4 * q4 + e] * ra : acc[fi][2 * fp + fj][4 * q4 + e];   // (!RS: alpha joins the bias below, one FMA)
                 const int chunk = fj * 8 + 2 * q4 + hi;
                 *reinterpret_cast<f32x4*>(slab + row * 256 + ((chunk ^ (row & 15)) << 4)) = t;
             }
@@ -888,8 +894,8 @@ __device__ __forceinline__ void fast_tile_epilogue(const GemmNTArgs& p, f32x16 (
             float v[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                v[e] = x0[e] + bias_r[fp][0][e];
-                v[4 + e] = x1[e] + bias_r[fp][1][e];
+                v[e] = RS ? x0[e] + bias_r[fp][0][e] : __builtin_fmaf(x0[e], p.alpha, bias_r[fp][0][e]);
+                v[4 + e] = RS ? x1[e] + bias_r[fp][1][e] : __builtin_fmaf(x1[e], p.alpha, bias_r[fp][1][e]);
             }
             const bool no_store = DBG_BIT(p, 8), no_math = DBG_BIT(p, 128);       // experiments only
             if (EPI == MERLOT_EPI_GELU) {
@@ -897,7 +903,7 @@ __device__ __forceinline__ void fast_tile_epilogue(const GemmNTArgs& p, f32x16 (
                     bf16x8 u8;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) u8[e] = (bf16)v[e];
-                    *reinterpret_cast<bf16x8*>(p.aux_out + (int64_t)m * p.ld_aux_out + n) = u8;
+                    *reinterpret_cast<bf16x8*>(auxo_lane + ((int64_t)(fi * 32 + ps * 8) * p.ld_aux_out + fp * 64)) = u8;
                 }
                 if (!no_math) {
 #pragma unroll
@@ -930,7 +936,7 @@ __device__ __forceinline__ void fast_tile_epilogue(const GemmNTArgs& p, f32x16 (
             if (no_store) {
                 if (v[0] == 12345.678f) *reinterpret_cast<float*>(p.C) = v[1];
             } else if (OUT_F32) {
-                float* c = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n;
+                float* c = reinterpret_cast<float*>(c_lane + ((int64_t)(fi * 32 + ps * 8) * p.ldc + fp * 64) * 4);
                 f32x4 o0, o1;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -943,7 +949,7 @@ __device__ __forceinline__ void fast_tile_epilogue(const GemmNTArgs& p, f32x16 (
                 bf16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-                *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + n) = o;
+                *reinterpret_cast<bf16x8*>(c_lane + ((int64_t)(fi * 32 + ps * 8) * p.ldc + fp * 64) * 2) = o;
                 if (want_cs) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) cacc[fp][e] += (float)o[e];

@@ -19,4 +19,4 @@ r=json.loads(sys.stdin.read())
 print('value %.1f seg/s  %.1f ms/step  nt %.3f  tn %.3f  fwd %.1f ms' % (r['value'], r['ms_per_step'], r['roofline']['frac'], r['roofline_wgrad']['frac'], r['forward_only']['ms_per_pass']))"
 done
 timeout 600 python -m pytest tests/test_gemm_persist_gpu.py -x -q -m gpu 2>&1 | tail -2
-) 2>&1 | tee gpurun_out/r05_x_nt_pinned_ab.txt | cut -c1-300
+) 2>&1 | tee gpurun_out/r05_x_nt_ab.txt | cut -c1-300
