@@ -1008,6 +1008,19 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* p) {
     }
     return r;
 }
+// the same from an absolute LDS address held in a register + a constant displacement (becomes the ds_read immediate)
+__device__ __forceinline__ bf16x8 tr_pair_lds(unsigned addr, int disp) {
+    typedef __attribute__((address_space(3))) bf16x4* lp_t;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp_t)(uintptr_t)(addr + (unsigned)disp));
+    const bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp_t)(uintptr_t)(addr + (unsigned)(disp + 4 * 64)));
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        r[e] = lo[e];
+        r[4 + e] = hi4[e];
+    }
+    return r;
+}
 
 // ------------------------------------------------------------------------------------------------
 // TN ring kernel (production weight-gradient path): ring-pipelined, big tiles, NO atomics.
