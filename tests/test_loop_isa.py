@@ -1,0 +1,111 @@
+"""The hot loops of the library, read off the compiled gfx950 code (CPU only: hipcc cross-compiles).  Round 5 found the same defect in four kernels: LDS
+addresses that the compiler rebuilt with a v_add_u32 per read (operands beyond the 64 KiB of a ds_read immediate; the LDS symbol's own address added per
+access), and, in the attention backward's dK / dV pass, row vectors held in 32 - 48 registers only to be subtracted.  The fixes are invisible in the
+results -- so this test pins what the compiled loops look like: instruction counts of the loop bodies and the register counts that go with them."""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+from collections import Counter
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, 'merlot_amd', 'csrc')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not available')
+
+
+def _compile(src):
+    tmp = tempfile.mkdtemp(prefix='loop_isa_')
+    out = os.path.join(tmp, 'k.s')
+    subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-w', '-S', '--cuda-device-only', os.path.join(CSRC, src), '-o', out],
+                          cwd=CSRC)
+    text = open(out).read().split('\n')
+    shutil.rmtree(tmp, ignore_errors=True)
+    return text
+
+
+def _kernel(lines, pattern):
+    """-> (body lines, vgpr count) of the ONE kernel whose mangled name matches."""
+    starts = [i for i, l in enumerate(lines) if re.match(r'^_ZN\S*' + pattern + r'\S*:', l)]
+    assert len(starts) == 1, (pattern, len(starts))
+    body = []
+    for l in lines[starts[0] + 1:]:
+        body.append(l)
+        if l.startswith('.Lfunc_end'):
+            break
+    name = lines[starts[0]].split(':')[0]
+    vg = None
+    for i, l in enumerate(lines):
+        if l.strip().startswith('.amdhsa_kernel ' + name):
+            for m in lines[i:i + 80]:
+                mm = re.match(r'\s*\.amdhsa_next_free_vgpr (\d+)', m)
+                if mm:
+                    vg = int(mm.group(1))
+                    break
+    assert vg is not None, name
+    return body, vg
+
+
+def _loops(body, n_mfma, inner_labels=False, max_len=400):
+    """loops (label ... backward branch to the same label; inner_labels: other labels -- skipped-over side blocks -- may lie inside) that hold exactly
+    n_mfma MFMAs in at most max_len instructions -> [Counter of mnemonics]"""
+    out = []
+    labels = [(k, b.split(':')[0]) for k, b in enumerate(body) if re.match(r'^\.LBB\d+_\d+:', b)]
+    for k, lab in labels:
+        code, closed = [], False
+        for b in body[k + 1:]:
+            c = b.split(';')[0].strip()
+            if re.match(r'^\.LBB', c):
+                if inner_labels:
+                    continue
+                break
+            if not c or c.startswith('.'):
+                continue
+            code.append(c)
+            if (c.startswith('s_cbranch') or c.startswith('s_branch')) and c.endswith(lab):
+                closed = True
+                break
+            if len(code) > max_len:
+                break
+        if closed and sum('v_mfma' in c for c in code) == n_mfma:
+            out.append(Counter(c.split()[0] for c in code))
+    return out
+
+
+def _valu(c):
+    return sum(v for k, v in c.items() if k.startswith('v_') and 'mfma' not in k)
+
+
+def test_attention_backward_loops():
+    lines = _compile('attention.hip')
+    # the persistent ViT backward: pass 2 (16 MFMAs per chunk) and pass 1 (12)
+    body, vg = _kernel(lines, r'attn_bwd_pp_kernelILi7ELi0E')
+    assert vg <= 224, vg                                         # 248 before the row vectors became the accumulators' initial value
+    p2 = _loops(body, 16)
+    assert len(p2) == 1 and _valu(p2[0]) <= 76 and p2[0]['v_add_u32_e32'] <= 10, p2       # 115 vector-ALU / 38 address additions before
+    assert p2[0]['ds_read_b128'] == 16 and p2[0]['ds_read_b64_tr_b16'] == 16
+    # the fused backward of the joint encoder (masked + attention log): two copies of the dK / dV chunk loop (the wave's two key blocks)
+    body, vg = _kernel(lines, r'attn_bwd_fused_kernelILi512ELb1ELb1E')
+    assert vg <= 244, vg
+    p2 = _loops(body, 16)
+    assert len(p2) == 2 and all(_valu(c) <= 145 and c['v_add_u32_e32'] <= 10 for c in p2), p2      # 164 / 187 and 34 address additions before
+    body, vg = _kernel(lines, r'attn_bwd_fused_kernelILi512ELb1ELb0E')
+    p2 = _loops(body, 16)
+    assert len(p2) == 2 and all(_valu(c) <= 108 and c['v_add_u32_e32'] <= 10 for c in p2), p2      # 131 / 156 before
+
+
+def test_gemm_main_loops():
+    lines = _compile('gemm.hip')
+    # ping-pong NT kernel, two phases per K-tile: 32 MFMAs per wave and K-tile, 24 fragment reads; 56 vector-ALU instructions before the bases were pinned
+    for epi in range(4):
+        body, vg = _kernel(lines, r'gemm_nt_p8_kernelILi%dELb0ELb0ELb1E' % epi)
+        steady = _loops(body, 32, inner_labels=True)
+        assert len(steady) == 1 and _valu(steady[0]) <= 50 and steady[0]['ds_read_b128'] == 24, (epi, steady)
+        assert 'scratch_load_dwordx4' not in steady[0] and 'scratch_store_dwordx4' not in steady[0]
+    # one-phase TN kernel: 48 transposing reads, 32 MFMAs; 18 vector-ALU instructions before the B base was pinned
+    body, vg = _kernel(lines, r'gemm_tn_p1_kernel')
+    steady = [c for c in _loops(body, 32, inner_labels=True) if c['ds_read_b64_tr_b16'] == 48 and sum(c.values()) < 200]
+    assert len(steady) == 1 and _valu(steady[0]) <= 6, steady
