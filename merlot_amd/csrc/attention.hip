@@ -933,7 +933,7 @@ extern "C" int merlot_attention_fwd(const void* qkv, int64_t ld, void* out, int6
         rc = pp_fwd(a, (hipStream_t)stream);
         return rc ? rc : merlot_launch_status("merlot_attention_fwd");
     }
-    // ... and its masked sibling the plain forward of 257 .. 352 masked tokens: the joint encoder in a training step
+    // ... and its two-half sibling the plain forward of 257 .. 352 tokens, masked (the joint encoder in a training step) or not (the ViT of a 192 x 352 frame)
     bool ppm = ppm_fwd_ok(a, want_cs);
 #ifdef MERLOT_EXPERIMENTS
     if (const char* e = getenv("MERLOT_ATTN_PP")) ppm = ppm && atoi(e) != 0;

@@ -373,6 +373,13 @@ def test_attention_persistent_masked_forward_joint_lengths(ops, B, S, heads):
     test_attention_fwd_bwd(ops, B, S, heads, True)
 
 
+@pytest.mark.parametrize("B,S,heads", [(40, 266, 12), (3, 257, 5), (30, 352, 12), (2, 300, 1)])
+def test_attention_persistent_two_half_forward_without_a_mask(ops, B, S, heads):
+    """The same kernel without a validity mask (the ViT of the as-shipped 192 x 352 frame: 266 tokens per frame, above the 224 of the single-pass
+    kernel): every key below S valid, the ragged last chunk still cut off; more items than workgroups; backward of the same call on the fused kernel."""
+    test_attention_fwd_bwd(ops, B, S, heads, False)
+
+
 def test_attention_persistent_masked_forward_padded_query_rows_are_uniform(ops):
     """The reference's -1e10 semantics on the persistent masked path: a padded query row attends uniformly over ALL S keys
     (utils/transformer.py:109-112), also where the padding spans whole 32-row blocks and a key half."""
