@@ -177,7 +177,7 @@ def gemm_source_hash():
 
 def measured_traffic():
     """HBM-side bytes per launch of the representative dominant launch (M=101376 N=3072 K=768, bias epilogue), from the
-    TCC counters collected in separate rocprofv3 --pmc passes over THIS kernel (profiles/' + TRAFFIC_FILE + ', written by
+    TCC counters collected in separate rocprofv3 --pmc passes over THIS kernel (profiles/<TRAFFIC_FILE>, written by
     scripts/gpu_traffic.sh): 2 * FETCH_SIZE (gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE, in bytes.  The
     file records the hash of the GEMM sources it was measured on; if the sources changed since, the figure is STALE and
     is not reported (traffic: null, with the reason)."""
@@ -200,9 +200,9 @@ def measured_traffic():
             else:
                 write = kb
     if fetch is None or write is None:
-        return {'bytes_per_launch': None, 'why': 'profiles/' + TRAFFIC_FILE + ' holds no gemm_nt_p8_kernel<0, false, false, true> rows'}
+        return {'bytes_per_launch': None, 'why': f'profiles/{TRAFFIC_FILE} holds no gemm_nt_p8_kernel<0, false, false, true> rows'}
     if src != gemm_source_hash():
-        return {'bytes_per_launch': None, 'why': f'profiles/' + TRAFFIC_FILE + ' was measured on GEMM sources {src}, the tree has '
+        return {'bytes_per_launch': None, 'why': f'profiles/{TRAFFIC_FILE} was measured on GEMM sources {src}, the tree has '
                                                  f'{gemm_source_hash()}: stale, re-run scripts/gpu_traffic.sh'}
     # the attention rows of the same file carry their own hash: reported only while the attention sources are the measured ones
     if asrc == source_hash(ATTENTION_SOURCES):
@@ -211,7 +211,7 @@ def measured_traffic():
         attention = {'hbm_bytes_per_launch': None, 'why': f'attention rows measured on sources {asrc}, the tree has {source_hash(ATTENTION_SOURCES)}: stale'}
     return {'bytes_per_launch': (2.0 * fetch + write) * 1024.0, 'algorithmic_bytes_per_launch': 3119.0e6, 'attention': attention,
             'launch': 'forward Linear M=405504 (= 128 examples x 16 frames x 198 tokens) N=3072 K=768, bias epilogue, bf16 out (gemm_nt_p8_kernel<0,false,false,true>)',
-            'source': 'profiles/' + TRAFFIC_FILE + '', 'gemm_source_hash': src}
+            'source': f'profiles/{TRAFFIC_FILE}', 'gemm_source_hash': src}
 
 
 def main():

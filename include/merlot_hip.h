@@ -43,6 +43,8 @@ int merlot_abi_version(void);
  * 67-82,98,120,130-135,149-161 and their tf.gradients backward (utils/optimization.py:176).
  * ---------------------------------------------------------------------------------------------- */
 enum merlot_epilogue {
+    /* alpha * acc + bias is ONE fused multiply-add of the fp32 accumulator in the persistent (ping-pong) bf16 kernel -- interior and
+     * boundary tiles alike (round 6) --; the ring kernels and the fp8 kernels round alpha * acc first.  With alpha == 1 all agree. */
     MERLOT_EPI_NONE = 0,          /* C = alpha*acc (+bias)                                         */
     MERLOT_EPI_GELU = 1,          /* u = alpha*acc+bias ; aux_out = u (optional) ; C = gelu(u)     */
     MERLOT_EPI_RESIDUAL = 2,      /* C = aux_in + dropout(alpha*acc+bias)                          */
@@ -170,7 +172,10 @@ int merlot_ln_bwd(const void* dy, int dy_f32, const void* x, int x_f32, const fl
 /* workspace (ABI v7; optional): merlot_attention_workspace_bytes() bytes, 4-byte aligned, ZERO on entry and left zero -- the item-claim
  * counters of the persistent kernels (csrc/attention_pp.inc: one workgroup per CU walks the (batch, head) items with the next items'
  * operands in flight; unmasked 65 .. 224 tokens forward and backward, masked 257 .. 352 tokens forward without side outputs).  Caller-owned
- * like the GEMMs' (no library state): one block per concurrently used stream.  Without it (NULL) the one-launch-per-item kernels run. */
+ * like the GEMMs' (no library state): one block per concurrently used stream -- two launches in flight on ONE block are undefined
+ * behaviour (the kernels carry no launch epoch: a non-zero counter makes a launch skip its first items, silently).  A launch that returns
+ * MERLOT_ELAUNCH has had its block cleared again by the library (a memset on `stream`); after a device fault the caller clears it.
+ * Without it (NULL) the one-launch-per-item kernels run. */
 int64_t merlot_attention_workspace_bytes(void);
 int merlot_attention_fwd(const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse, const uint8_t* valid,
                          const int32_t* seg, int B, int S, int heads, float scale, float* colsum_lo, float* colsum_hi,

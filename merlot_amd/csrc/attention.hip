@@ -25,6 +25,14 @@
 namespace {
 
 constexpr int64_t ATTN_WORKSPACE_BYTES = 64;             // item-claim counters of the persistent kernels (attention_pp.inc)
+
+// a persistent launch that failed may have left the caller's claim counters non-zero ("zero on entry, left zero" is the kernels' whole
+// protocol -- they carry no launch epoch): clear the block on the same stream before reporting the failure
+static inline int pp_status(int rc, const char* what, void* workspace, hipStream_t s) {
+    if (!rc) rc = merlot_launch_status(what);
+    if (rc && workspace) (void)hipMemsetAsync(workspace, 0, (size_t)ATTN_WORKSPACE_BYTES, s);
+    return rc;
+}
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 constexpr float MASKED_T = -1.0e10f * LOG2E;  // -1e10 in log2 units
@@ -931,7 +939,7 @@ extern "C" int merlot_attention_fwd(const void* qkv, int64_t ld, void* out, int6
 #endif
     if (pp) {
         rc = pp_fwd(a, (hipStream_t)stream);
-        return rc ? rc : merlot_launch_status("merlot_attention_fwd");
+        return pp_status(rc, "merlot_attention_fwd", workspace, (hipStream_t)stream);
     }
     // ... and its two-half sibling the plain forward of 257 .. 352 tokens, masked (the joint encoder in a training step) or not (the ViT of a 192 x 352 frame)
     bool ppm = ppm_fwd_ok(a, want_cs);
@@ -940,7 +948,7 @@ extern "C" int merlot_attention_fwd(const void* qkv, int64_t ld, void* out, int6
 #endif
     if (ppm) {
         rc = ppm_fwd(a, (hipStream_t)stream);
-        return rc ? rc : merlot_launch_status("merlot_attention_fwd");
+        return pp_status(rc, "merlot_attention_fwd", workspace, (hipStream_t)stream);
     }
     if (S <= RES_MAX_S && (want_cs || res_plain)) {
         rc = res_fwd(a, (hipStream_t)stream);
@@ -1019,7 +1027,7 @@ extern "C" int merlot_attention_bwd(const void* qkv, int64_t ld, const void* out
 #endif
     if (pp) {
         rc = pp_bwd(a, s);
-        return rc ? rc : merlot_launch_status("merlot_attention_bwd");
+        return pp_status(rc, "merlot_attention_bwd", workspace, s);
     }
     if (want_log && !valid) {
         // an unmasked stack with the attention log (no product configuration): the log comes from the tiled column-sum kernel whichever kernel forms the

@@ -104,12 +104,21 @@ __device__ __forceinline__ void compute_tile(const char* la, const char* lb, con
     }
 }
 
-// epilogue for 4 consecutive output columns n..n+3 of row m (v = alpha * accumulator)
-template <int EPI, bool OUT_F32>
+// epilogue for 4 consecutive output columns n..n+3 of row m (v = alpha * accumulator; FOLD: v = the raw accumulator, alpha joins the bias as ONE
+// fused multiply-add -- the rounding of the ping-pong kernel's interior-tile epilogue, so that an output's bits do not depend on whether an element
+// lies in an interior or a boundary tile)
+template <int EPI, bool OUT_F32, bool FOLD = false>
 __device__ __forceinline__ void nt_epilogue_quad(const GemmNTArgs& p, int m, int n, float (&v)[4], bool vec_ok) {
         const bool full = vec_ok && (n + 3 < p.N);
         const int ne = full ? 4 : min(4, p.N - n);
-        if (p.bias) {
+        if (FOLD) {
+            float b[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) {
+                for (int e = 0; e < ne; ++e) b[e] = p.bias[n + e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], p.alpha, b[e]);
+        } else if (p.bias) {
             if (full) {
                 const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
@@ -402,14 +411,26 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTNArgs p) {
 // and then works on whole row segments: a lane owns 8 consecutive columns, so the output store, the residual /
 // pre-activation loads and the bias loads are all 16-32 B per lane and 128-512 contiguous bytes per row.
 // ------------------------------------------------------------------------------------------------
-template <int EPI, bool OUT_F32>
+template <int EPI, bool OUT_F32, bool FOLD = false>
 __device__ __forceinline__ void epilogue_row8(const GemmNTArgs& p, int m, int n, float (&v)[8], float* cacc = nullptr) {
-    // v = alpha * acc for columns n..n+7 of row m; n + 7 < N guaranteed, 16-B alignment guaranteed by the caller
+    // v = alpha * acc for columns n..n+7 of row m (FOLD: the raw accumulators, see nt_epilogue_quad); n + 7 < N guaranteed, 16-B alignment
+    // guaranteed by the caller
     if DBG_BIT(p, 8) {                                     // experiments: epilogue arithmetic + staging, no memory ops
         if (v[0] == 12345.678f) *reinterpret_cast<float*>(p.C) = v[1];
         return;
     }
-    if (p.bias) {
+    if (FOLD) {
+        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+            b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
+            b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = __builtin_fmaf(v[e], p.alpha, b0[e]);
+            v[4 + e] = __builtin_fmaf(v[4 + e], p.alpha, b1[e]);
+        }
+    } else if (p.bias) {
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
         const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
 #pragma unroll
@@ -773,8 +794,8 @@ __device__ __forceinline__ void slab_epilogue(const GemmNTArgs& p, const f32x16&
         for (int q = 0; q < 4; ++q) {
             f32x4 t;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) t[e] = (fj ? acc1[4 * q + e] : acc0[4 * q + e]) * ra;
-            const int chunk = fj * 8 + 2 * q + hi;
+            for (int e = 0; e < 4; ++e) t[e] = RS ? (fj ? acc1[4 * q + e] : acc0[4 * q + e]) * ra : (fj ? acc1[4 * q + e] : acc0[4 * q + e]);
+            const int chunk = fj * 8 + 2 * q + hi;      // (!RS: raw accumulators; alpha joins the bias below as one FMA, as in fast_tile_epilogue)
             *reinterpret_cast<f32x4*>(slab + row * 256 + ((chunk ^ (row & 15)) << 4)) = t;
         }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -798,12 +819,12 @@ __device__ __forceinline__ void slab_epilogue(const GemmNTArgs& p, const f32x16&
                 v[e] = x0[e];
                 v[4 + e] = x1[e];
             }
-            epilogue_row8<EPI, OUT_F32>(p, m, n, v, (!OUT_F32 && p.colsum) ? cacc : nullptr);
+            epilogue_row8<EPI, OUT_F32, !RS>(p, m, n, v, (!OUT_F32 && p.colsum) ? cacc : nullptr);
         } else {
             float q0[4] = {x0[0], x0[1], x0[2], x0[3]}, q1[4] = {x1[0], x1[1], x1[2], x1[3]};
             const bool vec_ok = ((p.ldc & 3) == 0) && ((p.ld_aux_in & 3) == 0) && ((p.ld_aux_out & 3) == 0);
-            nt_epilogue_quad<EPI, OUT_F32>(p, m, n, q0, vec_ok);
-            if (n + 4 < p.N) nt_epilogue_quad<EPI, OUT_F32>(p, m, n + 4, q1, vec_ok);
+            nt_epilogue_quad<EPI, OUT_F32, !RS>(p, m, n, q0, vec_ok);
+            if (n + 4 < p.N) nt_epilogue_quad<EPI, OUT_F32, !RS>(p, m, n + 4, q1, vec_ok);
         }
     }
     // (the host only passes `colsum` to this path when N % 8 == 0 and everything is 16-B aligned: row8 branch above)

@@ -56,6 +56,7 @@ class _Lib(object):
         self.header = header
         self.check_abi = True             # scripts/ab_lib.py loads an OLDER build beside the current one and switches this off
         self.protos = parse_header(header)
+        self.on_error = []                # callables run before a failed call raises
 
     def load(self):
         if self._dll is not None:
@@ -91,6 +92,11 @@ class _Lib(object):
         rc = getattr(dll, name)(*args)
         if rc != 0:
             msg = dll.merlot_last_error()
+            for hook in self.on_error:                   # e.g. ops.reset_workspaces: claim counters a failed launch may have left non-zero
+                try:
+                    hook()
+                except Exception:
+                    pass
             raise MerlotHipError(f"{name} failed ({rc}): {msg.decode() if msg else '?'}")
 
 

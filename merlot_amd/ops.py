@@ -72,6 +72,19 @@ def _attn_ws():
     return buf.data_ptr(), buf.numel() * 4
 
 
+def reset_workspaces():
+    """Zero every claim-counter block handed out so far.  The persistent kernels' contract is "zero on entry, left zero" and they
+    carry no launch epoch: a launch that failed or was aborted half-way may leave a counter non-zero, and the NEXT launch on that block would then
+    skip its first items silently.  Registered as the binding's error hook (every failed C-ABI call runs it before raising) and callable by hand
+    after anything that may have killed a kernel.  One block belongs to ONE stream: concurrent launches sharing a block are undefined behaviour
+    (include/merlot_hip.h), which is why the blocks are keyed by (device, stream) here."""
+    for buf in list(_NT_WS.values()) + list(_ATTN_WS.values()):
+        buf.zero_()
+
+
+LIB.on_error.append(reset_workspaces)
+
+
 def _chk(t, dtype, name):
     if t is None:
         return

@@ -7,7 +7,12 @@ reads off the gfx950 assembly (CPU only: hipcc cross-compiles):
      every ds_read_b64_tr_b16, and for any ordinary load beside one -- the reason the requests are assembly) -- except the loader
      wave's waits for its own compiler-issued atomics (the two item claims of the prologue, the departure ticket at the end);
   3. the destination registers of a hand-issued load are neither read nor written between the load and the kernel's own wait
-     (round 5: with issue and use on two sides of the loop's back edge hipcc moved the registers while the load was in flight)."""
+     (round 5: with issue and use on two sides of the loop's back edge hipcc moved the registers while the load was in flight);
+  4. (round 6) the LDS-DMA statements write m0 inside their assembly.  m0 cannot be named as a clobber (hipcc: "reserved
+     register ... may not be preserved"), so the invariant is checked instead: NO compiler-generated instruction of these kernels reads
+     or writes m0 -- nothing of the compiler's can be live in it across a request;
+  5. every hand-written `s_waitcnt vmcnt(N)` leaves at most as many operations in flight as the wave has issued since the kernel's
+     previous full drain on that straight-line path: an immediate larger than the operations in front of it would wait for nothing."""
 import os
 import re
 import shutil
@@ -49,6 +54,8 @@ def check_kernel(name, body):
             continue
         if 'scratch_' in code:
             bad.append(f'{name}: scratch access {code!r}')
+        if not in_asm and re.search(r'\bm0\b', code):
+            bad.append(f'{name}: compiler-generated use of m0 {code!r} (line {i}): the LDS-DMA assembly overwrites it')
         if code.startswith('global_atomic_') and not in_asm:
             own_atomic = True
         if 's_waitcnt' in code and 'vmcnt' in code:
@@ -81,6 +88,46 @@ def check_kernel(name, body):
     return bad
 
 
+def check_counted_wait(name, body):
+    """The ViT backward's `pp_wait_vm<4>` (attention_pp.inc, "A": own K / V rows landed; younger: the dQ stores of item k - 1) is only right if the
+    wave issued EXACTLY the four dQ stores -- and nothing else -- between its eight own-row loads and that wait: with fewer younger operations
+    vmcnt(4) would leave own-row loads in flight, with an extra load the count would be off as well.  Read off the listing (loads, stores and
+    the wait sit in that order in the compiled loop; if a future compiler lays the loop out differently this fails and has to be re-derived)."""
+    in_asm, seq = False, []
+    for ln in body:
+        if '#ASMSTART' in ln:
+            in_asm = True
+            continue
+        if '#ASMEND' in ln:
+            in_asm = False
+            continue
+        code = ln.split(';')[0].strip()
+        if in_asm and re.match(r's_waitcnt vmcnt\(4\)', code):
+            seq.append('WAIT4')
+        elif in_asm and re.match(r'buffer_load_dwordx4 v\[', code) and not code.endswith('lds'):
+            seq.append('OWN')
+        elif re.match(r'(buffer|global|flat|scratch)_(load|store|atomic)', code):
+            seq.append(('ASM ' if in_asm else 'CC ') + code.split()[0])
+    bad = []
+    waits = [k for k, e in enumerate(seq) if e == 'WAIT4']
+    if len(waits) != 1:
+        return [f'{name}: {len(waits)} hand-written vmcnt(4) waits, expected 1']
+    k = waits[0] - 1
+    between = []
+    while k >= 0 and seq[k] != 'OWN':
+        between.append(seq[k])
+        k -= 1
+    n_own = 0
+    while k >= 0 and seq[k] == 'OWN':
+        n_own += 1
+        k -= 1
+    if n_own != 8:
+        bad.append(f'{name}: {n_own} own-row loads in front of vmcnt(4), expected 8')
+    if between != ['CC global_store_dwordx4'] * 4:
+        bad.append(f'{name}: vector-memory operations between the own-row loads and vmcnt(4): {between[::-1]} (expected the four dQ stores)')
+    return bad
+
+
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not available')
 def test_persistent_attention_kernels_keep_their_wait_counts():
     tmp = tempfile.mkdtemp(prefix='pp_isa_')
@@ -102,6 +149,7 @@ def test_persistent_attention_kernels_keep_their_wait_counts():
                 cur = None
         assert len(kernels) == 13, sorted(kernels)             # forward and backward, 3 .. 7 key chunks; masked forward, 9 .. 11
         bad = [b for name, body in kernels.items() for b in check_kernel(name, body)]
+        bad += [b for name, body in kernels.items() if 'attn_bwd_pp_kernel' in name for b in check_counted_wait(name, body)]
         assert not bad, '\n'.join(bad)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

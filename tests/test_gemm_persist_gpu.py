@@ -253,3 +253,33 @@ def test_two_k_tiles_per_tile_many_tiles_per_workgroup(ops):
         assert rel_l2(out[rows].float(), ref) < 6e-3
         first = out if first is None else first
         assert torch.equal(out, first)
+
+
+@pytest.mark.parametrize("epi", ['none', 'gelu', 'residual', 'dgelu'])
+def test_alpha_is_folded_the_same_way_in_interior_and_boundary_tiles(ops, epi):
+    """the interior-tile epilogue computes fma(acc, alpha, bias); the boundary-tile epilogues rounded acc * alpha and then added the
+    bias, so with alpha != 1 an element's bits depended on the tile it fell into.  Same A rows in an interior row tile and in the ragged last
+    one (M % 256 = 100), ragged last column tile as well (N % 256 = 128): every copy must be bit-identical."""
+    M, N, K = 256 * 300 + 100, 768 + 128, 768
+    assert plan(M, N, K) == PERSIST_DYN
+    a, bt = dev_rand((M, K), 51), dev_rand((N, K), 52, 0.05)
+    a[M - 100:] = a[256:356]                                 # rows of tile row 1 again in the ragged tile row
+    bt[768:] = bt[:128]                                      # columns 0 .. 127 again in the ragged tile column
+    bias = dev_rand((N,), 53, 0.1, F32)
+    bias[768:] = bias[:128]
+    aux = dev_rand((M, N), 54)
+    aux[M - 100:] = aux[256:356]
+    aux[:, 768:] = aux[:, :128]
+    kw = dict(alpha=0.37)
+    if epi == 'none':
+        got = ops.gemm_nt(a, bt, bias=bias, **kw)
+    elif epi == 'gelu':
+        u = torch.empty((M, N), device='cuda', dtype=BF16)
+        got = ops.gemm_nt(a, bt, bias=bias, epilogue=ops.EPI_GELU, aux_out=u, **kw)
+        assert torch.equal(u[M - 100:], u[256:356]) and torch.equal(u[:, 768:], u[:, :128])
+    elif epi == 'residual':
+        got = ops.gemm_nt(a, bt, bias=bias, epilogue=ops.EPI_RESIDUAL, aux_in=aux, **kw)
+    else:
+        got = ops.gemm_nt(a, bt, epilogue=ops.EPI_DGELU, aux_in=aux, **kw)
+    assert torch.equal(got[M - 100:], got[256:356])
+    assert torch.equal(got[:, 768:], got[:, :128])
