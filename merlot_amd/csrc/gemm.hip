@@ -660,8 +660,14 @@ __device__ __forceinline__ void staged_epilogue(const GemmNTArgs& p, f32x16 (&ac
 // ------------------------------------------------------------------------------------------------
 // NT kernel, ring-pipelined (production path; the 2-buffer kernel above is kept as the small-shape fallback)
 // ------------------------------------------------------------------------------------------------
+// waves per SIMD a configuration is compiled for (register budget 512 / OCC): 1 unless the configuration says otherwise
+template <typename C, typename = void>
+struct ring_occ { static constexpr int value = 1; };
+template <typename C>
+struct ring_occ<C, std::void_t<decltype(C::OCC)>> { static constexpr int value = C::OCC; };
+
 template <typename C, int EPI, bool OUT_F32>
-__global__ __launch_bounds__(C::NT) void gemm_nt_ring_kernel(const GemmNTArgs p) {
+__global__ __launch_bounds__(C::NT, ring_occ<C>::value) void gemm_nt_ring_kernel(const GemmNTArgs p) {
     extern __shared__ __attribute__((aligned(1024))) char dsm[];
     constexpr int BK = C::BK, S = C::STAGES;
     const int tid = threadIdx.x;
@@ -1233,6 +1239,12 @@ using RingC = ring::Cfg<4, 2, 2, 4, 32, 4>;   // 256x256, BK 32, 4 stages, 128 K
 using RingK = ring::Cfg<2, 4, 2, 2, 32, 3>;   // 128x256, BK 32, 3 stages, 72 KB (2 blocks/CU)
 using RingN64 = ring::Cfg<4, 1, 2, 2, 32, 3>;   // 256x64,  4 waves, 60 KB: narrow outputs (ResNet-stem 1x1 / 3x3 with 32..64 filters)
 using RingN128 = ring::Cfg<4, 1, 2, 4, 32, 3>;  // 256x128, 4 waves, 72 KB
+#ifdef MERLOT_EXPERIMENTS
+// Round 6 (VERDICT r5 #1b): TWO co-resident 4-wave workgroups per CU on 128 x 256 tiles -- the wave tile of the ping-pong kernel (128 x 64), BK 32,
+// three stages = 72 KiB, 256 registers per wave.  One workgroup's epilogue then runs beside the other's main loop; what is given up is the
+// barrier-locked pairing of the two waves of a SIMD and B's sharing between the row halves (+50 % LDS-DMA bytes per MFMA).  id 23.
+struct RingQ : ring::Cfg<1, 4, 4, 2, 32, 3> { static constexpr int OCC = 2; };
+#endif
 
 #include "gemm_p8.inc"
 
@@ -1311,6 +1323,7 @@ int gemm_nt_dispatch(GemmNTArgs& a, int epilogue, int out_f32, hipStream_t s) {
         case MERLOT_NT_KERNEL_P8: return launch_p8(a, epilogue, out_f32, s);
 #ifdef MERLOT_EXPERIMENTS
         case 3: return launch_ring<RingC>(a, epilogue, out_f32, s);
+        case 23: return launch_ring<RingQ>(a, epilogue, out_f32, s);
 #endif
         default: break;
     }

@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM traffic of the dominant kernels from the TCC counters -- separate --pmc passes with --kernel-trace only, as
-# MI355X_MICROARCH.md prescribes -- over the PRODUCT library.  Writes gpurun_out/r05_traffic.txt; copy it to profiles/.
+# MI355X_MICROARCH.md prescribes -- over the PRODUCT library.  Writes gpurun_out/${TRAFFIC_OUT:-r06_traffic.txt}; copy it to profiles/.
 # The file records the hashes of the GEMM sources AND of the attention sources (bench.py refuses the rows of a family whose hash differs
 # from the tree's: round 4's file was measured before the attention kernels last changed and nothing said so) and the sha256 of the
 # measured libmerlot_hip.so.
@@ -14,7 +14,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   cp /tmp/pmc_$c/g_counter_collection.csv $R/gpurun_out/pmc_$c.csv
 done
 cd $R
-python - <<'PY' > gpurun_out/r05_traffic.txt
+python - <<'PY' > gpurun_out/r06_traffic.txt
 import csv, collections, hashlib, os, sys
 sys.path.insert(0, os.getcwd())
 import bench
@@ -30,7 +30,7 @@ for c in ['FETCH_SIZE', 'WRITE_SIZE']:
     agg = collections.OrderedDict()
     for r in rows:
         k = r['Kernel_Name']
-        if not any(t in k for t in ('gemm', 'attn', 'quantize', 'amax', 'tn_reduce')):
+        if not any(t in k for t in ('gemm', 'attn', 'quantize', 'amax', 'tn_reduce', 'ln_fwd', 'ln_bwd')):
             continue
         k = k.replace('(anonymous namespace)::', '').split('(')[0][:90]
         d = agg.setdefault(k, [0.0, 0])
@@ -43,4 +43,4 @@ for k, d in vals.items():
     if 'FETCH_SIZE' in d and 'WRITE_SIZE' in d:
         print('HBM_MB | %s | %.1f' % (k, (2 * d['FETCH_SIZE'] + d['WRITE_SIZE']) / 1024.0))
 PY
-cat gpurun_out/r05_traffic.txt
+cat gpurun_out/r06_traffic.txt

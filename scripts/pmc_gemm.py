@@ -31,4 +31,30 @@ for _ in range(2):
     o, lse = ops.attention_fwd(qkv, 2048, 198, 12)
     do = rnd(2048 * 198, 768)
     ops.attention_bwd(qkv, o, do, lse, 2048, 198, 12)
+del qkv, o, do
+# round 6: the kernels round 5's file had no rows for -- the joint encoder's masked attention (512 sequences of 328: training forward
+# attn_fwd_ppm_kernel, backward attn_bwd_fused_kernel<512, true, true> with the attention log), the text-only pass (128 sequences of 512: forward with
+# the column sums attn_fwd_res_kernel<true, 16>, backward attn_bwd_fused_kernel<512, true, false>) and the two LayerNorm kernels at the ViT's row count
+for (B, S, side) in ((512, 328, 'log'), (128, 512, 'colsum')):
+    qkv = rnd(B * S, 2304)
+    valid = torch.ones(B, S, device='cuda', dtype=torch.uint8)
+    valid[:, S - 7:] = 0                                                    # a few padded keys per sequence, as the captions have
+    for _ in range(2):
+        if side == 'colsum':
+            cs = torch.zeros(B, S, device='cuda')
+            o, lse = ops.attention_fwd(qkv, B, S, 12, valid=valid, colsum_lo=cs, valid_q_only=True)
+            do = rnd(B * S, 768)
+            ops.attention_bwd(qkv, o, do, lse, B, S, 12, valid=valid)
+        else:
+            o, lse = ops.attention_fwd(qkv, B, S, 12, valid=valid)
+            do = rnd(B * S, 768)
+            lo, hi = torch.zeros(B, S, device='cuda'), torch.zeros(B, S, device='cuda')
+            ops.attention_bwd(qkv, o, do, lse, B, S, 12, valid=valid, log_lo=lo, log_hi=hi, log_split=200, log_weight=1.0 / 12)
+    del qkv, o, do
+h = rnd(T, 768)
+gam, bet = torch.ones(768, device='cuda'), torch.zeros(768, device='cuda')
+dgam, dbet = torch.zeros(768, device='cuda'), torch.zeros(768, device='cuda')
+for _ in range(2):
+    y16, _, mean, rstd = ops.ln_fwd(h, gam, bet)
+    ops.ln_bwd(y16, h, mean, rstd, gam, dgam, dbet, dres=h)
 torch.cuda.synchronize()
