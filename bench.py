@@ -193,14 +193,14 @@ def measured_traffic():
             asrc = line.split()[-1]
         if line.startswith('HBM_MB') and 'attn_' in line:
             attn[line.split(' | ')[1].strip()] = float(line.split()[-1]) * 1024.0 * 1024.0
-        if 'gemm_nt_p8_kernel<0, false, false, true>' in line and line.split(' | ')[0] in ('FETCH_SIZE', 'WRITE_SIZE'):
+        if 'gemm_nt_p8_kernel<0, false, false, true' in line and line.split(' | ')[0] in ('FETCH_SIZE', 'WRITE_SIZE'):   # (+ ', false>' since round 6: the LayerNorm-fold flag)
             kb = float(line.split()[-1])                      # '<counter> | <kernel> | launches n | KB_per_launch v'
             if line.startswith('FETCH_SIZE'):
                 fetch = kb
             else:
                 write = kb
     if fetch is None or write is None:
-        return {'bytes_per_launch': None, 'why': f'profiles/{TRAFFIC_FILE} holds no gemm_nt_p8_kernel<0, false, false, true> rows'}
+        return {'bytes_per_launch': None, 'why': f'profiles/{TRAFFIC_FILE} holds no gemm_nt_p8_kernel<0, false, false, true, ..> rows'}
     if src != gemm_source_hash():
         return {'bytes_per_launch': None, 'why': f'profiles/{TRAFFIC_FILE} was measured on GEMM sources {src}, the tree has '
                                                  f'{gemm_source_hash()}: stale, re-run scripts/gpu_traffic.sh'}
@@ -234,6 +234,7 @@ def main():
                          'and resnet_layers [3, 4, 9]; everything else as the headline (12 + 12 + 12 layers, 16 segments per example in groups of 4)')
     ap.add_argument('--explicit-conv', action='store_true', help='with --resnet-stem: the 3x3 convolutions on explicit im2col matrices (the path of rounds 1-3) instead of the implicit GEMM')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-ln-fold', action='store_true', help='A/B only: LayerNorm as its own launch behind every residual GEMM (the path of rounds 1-5) instead of merlot_gemm_bf16_nt_ln')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--cpu-baseline-worker', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--cpu-emulate', action='store_true', help=argparse.SUPPRESS)   # tests only: gloo + torch-CPU emulated ops, tiny model
@@ -252,6 +253,9 @@ def main():
     from merlot_amd import NeatConfig, ops
     from merlot_amd.parallel import DistContext
     from merlot_amd.train import Trainer, synthetic_batch
+    if args.no_ln_fold:
+        from merlot_amd import layers
+        layers.FUSE_LN = False
 
     if args.examples is None:
         args.examples = 48 if args.config == 5 else 56 if args.native_yaml else ((64 if args.explicit_conv else 80) if args.resnet_stem else 128)   # the hybrid stem keeps several times the activations per frame (implicit 3x3 convolutions, 80 / 96 / 112 examples: 3 030 / 3 048 / 3 086 segments/s at 193 / 231 / 269 GB)

@@ -33,7 +33,7 @@ typedef void* merlot_stream_t;
 
 /* Bumped whenever a signature of this header changes.  merlot_abi_version() returns the value the library was built with;
  * a binding must compare the two before its first call (merlot_amd/lib.py does, and refuses a mismatching library). */
-#define MERLOT_ABI_VERSION 7
+#define MERLOT_ABI_VERSION 8
 
 const char* merlot_last_error(void);
 int merlot_abi_version(void);
@@ -73,6 +73,25 @@ int merlot_gemm_bf16_nt(const void* A, int64_t lda, const void* Bt, int64_t ldb,
                         int64_t ld_aux_out, float dropout_p, uint64_t dropout_seed, float* colsum_out,
                         void* workspace, int64_t workspace_bytes, merlot_stream_t stream);
 int64_t merlot_gemm_nt_workspace_bytes(void);
+
+/* ABI v8 (round 6; SURVEY 8(b) `merlot_ln_residual_fwd`): the residual sub-layer tail AND the LayerNorm that follows it, one call --
+ *     C      = aux_in + dropout(alpha * A . Bt^T + bias)          (utils/transformer.py:130-136, 158-162: dense + dropout + residual)
+ *     ln_out = LayerNorm(C) * gamma + beta,  mean / rstd [M]      (utils/model_utils.py:113-130; utils/transformer.py:214, 220)
+ * bf16 C and ln_out, dense ([M, N], ldc == ld_ln == N, N % 256 == 0).  Where merlot_gemm_bf16_nt_ln_plan() says 1 (N == 768, at least 96 row
+ * blocks of 256, the persistent kernel's shape) and the operands are 16-byte aligned, ONE launch does both: each 256 x 256 tile leaves per-row
+ * partial statistics of its stored values, and the last of a row block's three tiles to finish normalises the block from the L2 (no second
+ * launch, no HBM read of C).  Otherwise, and for the rows of a ragged last row block, the same GEMM is followed by the merlot_ln_fwd kernel.
+ * Statistics are combined from 64-column segments (sum, centred sum of squares; exact pairwise combination), so mean / rstd agree with
+ * merlot_ln_fwd to fp32 rounding, not bit for bit.
+ * ln_workspace: merlot_gemm_nt_ln_workspace_bytes(M, N) bytes, 16-byte aligned, its first ceil(M/256) uint32 ZERO on entry and left zero
+ * (arrival counters; the rest is scratch); one block per concurrently used stream.  workspace: as merlot_gemm_bf16_nt. */
+int64_t merlot_gemm_nt_ln_workspace_bytes(int64_t M, int64_t N);
+int merlot_gemm_bf16_nt_ln_plan(int64_t M, int64_t N, int64_t K);
+int merlot_gemm_bf16_nt_ln(const void* A, int64_t lda, const void* Bt, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                           float alpha, const float* bias, const void* aux_in, int64_t ld_aux_in, float dropout_p, uint64_t dropout_seed,
+                           const float* ln_gamma, const float* ln_beta, void* ln_out, int64_t ld_ln, float* ln_mean, float* ln_rstd,
+                           float ln_eps, void* ln_workspace, int64_t ln_workspace_bytes, void* workspace, int64_t workspace_bytes,
+                           merlot_stream_t stream);
 
 /* Which kernel merlot_gemm_bf16_nt runs for a problem size (the choice depends on M, N, K only); -1 for sizes the
  * entry point rejects.  Tests use it to assert that a shape exercises the kernel they mean to check. */

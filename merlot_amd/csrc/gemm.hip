@@ -62,6 +62,17 @@ struct GemmNTArgs {
     int dbg;              // experiments only: 1 = skip epilogue, 2 = skip main loop
     int64_t m_off;        // rows of C in front of this launch when a GEMM is cut into row ranges: the dropout mask is a function of the
                           // element's GLOBAL index (m_off + m) * N + n
+    // Round 6: LayerNorm of the finished rows of C out of the SAME launch (ping-pong kernel, RESIDUAL epilogue, N = 768 = three
+    // tile columns; gemm_p8.inc "LNF").  ln_out == nullptr: off.
+    bf16* ln_out;         // [M, N] bf16: LN(C) of every row of a whole 256-row block (the tail rows are the host's: merlot_ln_fwd)
+    int64_t ld_ln;
+    const float* ln_gamma;
+    const float* ln_beta;
+    float* ln_mean;       // f32 [M] (may be nullptr)
+    float* ln_rstd;
+    float ln_eps;
+    float* ln_part;       // caller workspace: [N / 64][ntm * 256] x (sum, M2) of each row's 64-column segments, written by the tile epilogues
+    unsigned int* ln_ctr; // caller workspace: [ntm] arrivals per row block, zero on entry, left zero
 };
 
 struct GemmTNArgs {
@@ -73,6 +84,8 @@ struct GemmTNArgs {
     float alpha;
     int use_atomics;
     int ntm, ntn, splits, rchunk;
+    float* colsum_a;      // round 6, one-phase ping-pong kernel only (else host fallback): f32 [colsum_m], ACCUMULATED: sum_r A[r][m] for m < colsum_m -- the
+    int colsum_m;         // bias gradient of the layer whose weight gradient this is, from the A fragments the kernel holds anyway (dot products with 1)
     int dbg;
 };
 
@@ -849,7 +862,19 @@ __device__ __forceinline__ void slab_epilogue(const GemmNTArgs& p, const f32x16&
 // resolved at compile time, so that their 16 passes are straight-line code (round 4, profiles/r04_l_epilogue_flags.txt: proj -4 %,
 // fc2 -2.5 %; doing the same for the column sums of the NONE / DGELU epilogues made THOSE kernels 5-19 % slower -- two copies of
 // the epilogue in a kernel whose main loop is register-tight -- and was taken back).
-template <int EPI, bool OUT_F32, int FM = 2, int FN = 4, int PF = 8, bool RS = false, bool FLAG = false>
+// sum over the 8 lanes that share a row of a 64-column slab (lane & 7 = column octet): two quad permutes and the half-row mirror, no LDS crossbar
+__device__ __forceinline__ float octet_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    return v;
+}
+
+// LNF (RESIDUAL epilogue of the ping-pong kernel only): besides storing its rows the pass leaves, per row and 64-column segment, (sum, M2 =
+// sum of squared deviations from the segment's own mean) of the STORED bf16 values in p.ln_part -- the inputs of the row block's LayerNorm, which
+// the last of the block's three tile columns to finish performs (gemm_p8.inc).  Segment statistics combine exactly (Chan et al.), so the variance
+// does not suffer the cancellation of a sum-of-squares formula when a row's mean is large against its spread.
+template <int EPI, bool OUT_F32, int FM = 2, int FN = 4, int PF = 8, bool RS = false, bool FLAG = false, bool LNF = false>
 __device__ __forceinline__ void fast_tile_epilogue(const GemmNTArgs& p, f32x16 (&acc)[FM][FN], char* slab, int m_base,
                                                    int n_base, int lane) {
     static_assert(FM * FN == 8, "a wave owns 8 accumulators = 4 slabs of 32 x 64");
@@ -980,6 +1005,21 @@ __device__ __forceinline__ void fast_tile_epilogue(const GemmNTArgs& p, f32x16 (
                 if (want_cs) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) cacc[fp][e] += (float)o[e];
+                }
+                if constexpr (LNF) {
+                    float f[8], s1 = 0.f, m2 = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        f[e] = (float)o[e];
+                        s1 += f[e];
+                    }
+                    s1 = octet_sum(s1);
+                    const float mu = s1 * (1.0f / 64.0f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) m2 = __builtin_fmaf(f[e] - mu, f[e] - mu, m2);
+                    m2 = octet_sum(m2);
+                    if ((lane & 7) == 0)
+                        *reinterpret_cast<f32x2*>(p.ln_part + ((int64_t)((n_base >> 6) + fp) * ((int64_t)p.ntm * 256) + m) * 2) = f32x2{s1, m2};
                 }
             }
         }
@@ -1246,6 +1286,72 @@ using RingN128 = ring::Cfg<4, 1, 2, 4, 32, 3>;  // 256x128, 4 waves, 72 KB
 struct RingQ : ring::Cfg<1, 4, 4, 2, 32, 3> { static constexpr int OCC = 2; };
 #endif
 
+// ---- LNF: the LayerNorm of one finished 256-row block of C (N = 768), run by the workgroup whose tile was the last of the block's three to arrive.
+// The other two tiles' rows were stored by other CUs of the SAME XCD (the LNF tile order keeps a row block inside one XCD), so they sit in this XCD's L2:
+// the reads carry sc1 (agent scope: not served from this CU's vector L1).  lds: 2 KiB for the rows' (mean, rstd).
+__device__ __forceinline__ void ld16_sc1(u32x4& r, const void* ptr) {
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r) : "v"(ptr) : "memory");
+}
+__device__ __forceinline__ void ld8_sc1(u32x2& r, const void* ptr) {
+    asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(r) : "v"(ptr) : "memory");
+}
+__device__ __forceinline__ void ln_row_block(const GemmNTArgs& p, int tm, char* lds, int tid) {
+    constexpr int NSEG = 12, H = 768;                      // 64-column segments of a row
+    f32x2* stat = reinterpret_cast<f32x2*>(lds);
+    const int64_t mpad = (int64_t)p.ntm * 256;
+    if (tid < 256) {
+        const int64_t row = (int64_t)tm * 256 + tid;
+        u32x2 raw[NSEG];
+#pragma unroll
+        for (int g = 0; g < NSEG; ++g) ld8_sc1(raw[g], p.ln_part + ((int64_t)g * mpad + row) * 2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        float tot = 0.f;
+#pragma unroll
+        for (int g = 0; g < NSEG; ++g) {
+            asm volatile("" : "+v"(raw[g]));
+            tot += __builtin_bit_cast(float, raw[g][0]);
+        }
+        const float mean = tot * (1.0f / H);
+        float m2 = 0.f;
+#pragma unroll
+        for (int g = 0; g < NSEG; ++g) {
+            const float d = __builtin_bit_cast(float, raw[g][0]) * (1.0f / 64.0f) - mean;
+            m2 += __builtin_bit_cast(float, raw[g][1]) + 64.0f * d * d;
+        }
+        const float rstd = rsqrtf(m2 * (1.0f / H) + p.ln_eps);
+        stat[tid] = f32x2{mean, rstd};
+        if (p.ln_mean) p.ln_mean[row] = mean;
+        if (p.ln_rstd) p.ln_rstd[row] = rstd;
+    }
+    __syncthreads();
+    const int rr = tid >> 5, cc = (tid & 31) * 8;          // 16 rows x 32 column octets per pass; 16 passes per tile column
+#pragma unroll 1
+    for (int tnc = 0; tnc < 3; ++tnc) {
+        const int col = tnc * 256 + cc;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.ln_gamma + col), g1 = *reinterpret_cast<const f32x4*>(p.ln_gamma + col + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.ln_beta + col), b1 = *reinterpret_cast<const f32x4*>(p.ln_beta + col + 4);
+        const bf16* src = reinterpret_cast<const bf16*>(p.C) + ((int64_t)tm * 256 + rr) * p.ldc + col;
+        bf16* dst = p.ln_out + ((int64_t)tm * 256 + rr) * p.ld_ln + col;
+        u32x4 x[16];
+#pragma unroll
+        for (int ps = 0; ps < 16; ++ps) ld16_sc1(x[ps], src + (int64_t)ps * 16 * p.ldc);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ps = 0; ps < 16; ++ps) {
+            asm volatile("" : "+v"(x[ps]));
+            const f32x2 st = stat[ps * 16 + rr];
+            const bf16x8 xv = __builtin_bit_cast(bf16x8, x[ps]);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float sc = st[1] * (e < 4 ? g0[e & 3] : g1[e & 3]);
+                o[e] = (bf16)((float)xv[e] * sc - st[0] * sc + (e < 4 ? b0[e & 3] : b1[e & 3]));     // y = x s - mean s + beta, as ln_fwd_kernel
+            }
+            *reinterpret_cast<bf16x8*>(dst + (int64_t)ps * 16 * p.ld_ln) = o;
+        }
+    }
+}
+
 #include "gemm_p8.inc"
 
 // Which kernel a shape runs on (also exported as merlot_gemm_bf16_nt_plan so tests can assert it).  From the sweeps in
@@ -1474,7 +1580,8 @@ int tn_p8_launch(GemmTNArgs& a, int accumulate, float* ws, int64_t ws_bytes, hip
     // weight-gradient shape of the step, two -> one another +3-5 % (1 230 TFLOP/s = 0.49 of peak on dW1 / dW2); the two- and
     // four-phase bodies of gemm_tn_p8_kernel remain in the experiments build (MERLOT_TN_PH2 = 1 / 0).
     int ph = 1;
-    MERLOT_ENSURE_LDS(gemm_tn_p1_kernel, P8_LDS, "merlot_gemm_bf16_tn(p1)");
+    MERLOT_ENSURE_LDS(gemm_tn_p1_kernel<false>, P8_LDS, "merlot_gemm_bf16_tn(p1)");
+    MERLOT_ENSURE_LDS(gemm_tn_p1_kernel<true>, P8_LDS, "merlot_gemm_bf16_tn(p1)");
 #ifdef MERLOT_EXPERIMENTS
     MERLOT_ENSURE_LDS(gemm_tn_p8_kernel<true>, P8_LDS, "merlot_gemm_bf16_tn(p8)");
     MERLOT_ENSURE_LDS(gemm_tn_p8_kernel<false>, P8_LDS, "merlot_gemm_bf16_tn(p8)");
@@ -1482,7 +1589,8 @@ int tn_p8_launch(GemmTNArgs& a, int accumulate, float* ws, int64_t ws_bytes, hip
     if (ph == 4) hipLaunchKernelGGL(gemm_tn_p8_kernel<false>, dim3(pl.ntm * pl.ntn * pl.splits), dim3(512), P8_LDS, s, a, ws);
     if (ph == 2) hipLaunchKernelGGL(gemm_tn_p8_kernel<true>, dim3(pl.ntm * pl.ntn * pl.splits), dim3(512), P8_LDS, s, a, ws);
 #endif
-    if (ph == 1) hipLaunchKernelGGL(gemm_tn_p1_kernel, dim3(pl.ntm * pl.ntn * pl.splits), dim3(512), P8_LDS, s, a, ws);
+    if (ph == 1 && a.colsum_a) hipLaunchKernelGGL(gemm_tn_p1_kernel<true>, dim3(pl.ntm * pl.ntn * pl.splits), dim3(512), P8_LDS, s, a, ws);
+    else if (ph == 1) hipLaunchKernelGGL(gemm_tn_p1_kernel<false>, dim3(pl.ntm * pl.ntn * pl.splits), dim3(512), P8_LDS, s, a, ws);
     if (pl.splits > 1) {
         int64_t total = (int64_t)a.M * (a.N / 4);
         int grid = (int)((total + 255) / 256);
@@ -1562,6 +1670,65 @@ extern "C" int merlot_gemm_bf16_nt(const void* A, int64_t lda, const void* Bt, i
     a.colsum = colsum_out;
     a.ctr = (unsigned int*)workspace;
     return gemm_nt_dispatch(a, epilogue, out_f32, (hipStream_t)stream);
+}
+
+// h' = aux_in + dropout(alpha * A Bt^T + bias) AND LayerNorm(h') from one launch (ABI v8; gemm_p8.inc "LNF").  Shapes the fused kernel does not take
+// (N != 768, fewer than 96 row blocks, unaligned operands) and the rows of a ragged last row block run the same GEMM and the stand-alone LayerNorm kernel.
+extern "C" int merlot_ln_fwd(const void* x, int x_f32, const float* gamma, const float* beta, void* y_bf16, float* y_f32, float* mean, float* rstd,
+                             int64_t rows, int H, float eps, merlot_stream_t stream);
+static int64_t ln_ws_ctr_bytes(int64_t M) { return (cdiv(M, 256) * 4 + 255) / 256 * 256; }
+extern "C" int64_t merlot_gemm_nt_ln_workspace_bytes(int64_t M, int64_t N) {
+    return ln_ws_ctr_bytes(M) + (N / 64) * (int64_t)cdiv(M, 256) * 256 * 8;
+}
+extern "C" int merlot_gemm_bf16_nt_ln_plan(int64_t M, int64_t N, int64_t K) {     // 1: the fused kernel takes (aligned operands of) this shape
+    return N == 768 && M >= 96 * 256 && nt_plan(M, N, K) == MERLOT_NT_KERNEL_P8 && K % 64 == 0 && K >= 128 ? 1 : 0;
+}
+extern "C" int merlot_gemm_bf16_nt_ln(const void* A, int64_t lda, const void* Bt, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                                      float alpha, const float* bias, const void* aux_in, int64_t ld_aux_in, float dropout_p, uint64_t dropout_seed,
+                                      const float* ln_gamma, const float* ln_beta, void* ln_out, int64_t ld_ln, float* ln_mean, float* ln_rstd,
+                                      float ln_eps, void* ln_workspace, int64_t ln_workspace_bytes, void* workspace, int64_t workspace_bytes,
+                                      merlot_stream_t stream) {
+    MERLOT_CHECK(ln_gamma && ln_beta && ln_out, MERLOT_ESHAPE, "merlot_gemm_bf16_nt_ln: null LayerNorm operand");
+    MERLOT_CHECK(N % 256 == 0 && N <= 2048 && ld_ln == N && ldc == N, MERLOT_ESHAPE,
+                 "merlot_gemm_bf16_nt_ln: C and ln_out must be dense [M, N] with N a multiple of 256 (N=%lld ldc=%lld ld_ln=%lld)", (long long)N,
+                 (long long)ldc, (long long)ld_ln);
+    GemmNTArgs probe{};
+    probe.A = (const bf16*)A; probe.B = (const bf16*)Bt; probe.C = C; probe.lda = lda; probe.ldb = ldb; probe.ldc = ldc;
+    probe.M = (int)M; probe.N = (int)N; probe.K = (int)K; probe.aux_in = (const bf16*)aux_in; probe.ld_aux_in = ld_aux_in; probe.bias = bias;
+    probe.ln_out = (bf16*)ln_out; probe.ld_ln = ld_ln; probe.ln_gamma = ln_gamma; probe.ln_beta = ln_beta;
+    const bool fused = M > 0 && M < (1LL << 31) && K > 0 && merlot_gemm_bf16_nt_ln_plan(M, N, K) && p8_lnf_ok(probe) && ln_workspace != nullptr &&
+                       ln_workspace_bytes >= merlot_gemm_nt_ln_workspace_bytes(M, N) && ((uintptr_t)ln_workspace & 15) == 0;
+    if (!fused) {
+        const int rc = merlot_gemm_bf16_nt(A, lda, Bt, ldb, C, ldc, M, N, K, alpha, MERLOT_EPI_RESIDUAL, 0, 0, bias, aux_in, ld_aux_in, nullptr, 0,
+                                           dropout_p, dropout_seed, nullptr, workspace, workspace_bytes, stream);
+        if (rc != MERLOT_OK) return rc;
+        return merlot_ln_fwd(C, 0, ln_gamma, ln_beta, ln_out, nullptr, ln_mean, ln_rstd, M, (int)N, ln_eps, stream);
+    }
+    MERLOT_CHECK(A && Bt && C && aux_in, MERLOT_ESHAPE, "merlot_gemm_bf16_nt_ln: null operand");
+    MERLOT_CHECK(workspace && workspace_bytes >= NT_WORKSPACE_BYTES && ((uintptr_t)workspace & 3) == 0, MERLOT_ESHAPE,
+                 "merlot_gemm_bf16_nt_ln: needs the caller's zeroed workspace of merlot_gemm_nt_workspace_bytes() bytes");
+    MERLOT_CHECK(lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)Bt & 15) == 0, MERLOT_EALIGN,
+                 "merlot_gemm_bf16_nt_ln: A / Bt must be 16-byte aligned with leading dimensions in multiples of 8");
+    MERLOT_CHECK(dropout_p >= 0.f && dropout_p < 1.f, MERLOT_ESHAPE, "merlot_gemm_bf16_nt_ln: dropout_p out of range");
+    GemmNTArgs a = probe;
+    a.alpha = alpha;
+    a.drop_thresh = dropout_p > 0.f ? (uint32_t)((double)dropout_p * 4294967296.0) : 0u;
+    a.drop_scale = 1.0f / (1.0f - dropout_p);
+    a.drop_seed = dropout_seed;
+    a.ctr = (unsigned int*)workspace;
+    a.ln_mean = ln_mean; a.ln_rstd = ln_rstd; a.ln_eps = ln_eps;
+    a.ln_ctr = (unsigned int*)ln_workspace;
+    a.ln_part = (float*)((char*)ln_workspace + ln_ws_ctr_bytes(M));
+    int rc = gemm_nt_dispatch(a, MERLOT_EPI_RESIDUAL, 0, (hipStream_t)stream);
+    if (rc != MERLOT_OK) {
+        (void)hipMemsetAsync(ln_workspace, 0, (size_t)ln_ws_ctr_bytes(M), (hipStream_t)stream);      // arrival counters a failed launch may have left
+        return rc;
+    }
+    const int64_t done = M / 256 * 256;                   // whole row blocks: normalised by the GEMM launch; the ragged rest by the LayerNorm kernel
+    if (done < M)
+        rc = merlot_ln_fwd((const bf16*)C + done * ldc, 0, ln_gamma, ln_beta, (bf16*)ln_out + done * ld_ln, nullptr, ln_mean ? ln_mean + done : nullptr,
+                           ln_rstd ? ln_rstd + done : nullptr, M - done, (int)N, ln_eps, stream);
+    return rc;
 }
 
 // C = epilogue(alpha * scale_a[0] * scale_b[0] * A8 * B8^T + bias): e4m3 operands (merlot_quantize_e4m3), fp32 accumulation on the

@@ -56,6 +56,10 @@ def _fwd_linear(x, lin, fp8, x8=None, row_scale=None, **kw):
     return ops.gemm_fp8_nt(x8, sx, w8, sw, bias=lin.b, **kw)
 
 
+# The LayerNorm behind each residual GEMM from that GEMM's own launch (merlot_gemm_bf16_nt_ln, ABI v8).  A module switch so that scripts can A/B it.
+FUSE_LN = True
+
+
 def _site_seed(seed, layer, site):
     return (int(seed) * 1000003 + layer * 16 + site) & 0xFFFFFFFFFFFFFFFF
 
@@ -92,13 +96,20 @@ class TransformerStackFn(torch.autograd.Function):
             log_lo = log_hi = None                        # the forward launches carry no log side output
         saved = []
         h = h.contiguous()
+        # Round 6: the LayerNorm behind a residual GEMM (proj -> LN2, fc2 -> the next layer's LN1 / the final LN) comes out of that GEMM's launch
+        # (ops.gemm_nt_ln, ABI v8) -- bf16 path only; the fp8 path's LayerNorm also emits the e4m3 copy and stays a launch of its own
+        fuse_ln = FUSE_LN and not fp8 and h.shape[1] % 256 == 0
+        nxt = None                                         # (x1, mean1, rstd1) of this layer when the previous layer's fc2 launch produced them
         for l in range(nl):
             w = stack.layers[l]
             if fp8:
                 x1, x1q, rs1, mean1, rstd1 = ops.ln_fwd_q8(h, w.ln1.gamma, w.ln1.beta)
                 qkv = _fwd_linear(x1, w.qkv, True, x8=x1q, row_scale=rs1)
             else:
-                x1, _, mean1, rstd1 = ops.ln_fwd(h, w.ln1.gamma, w.ln1.beta)
+                if nxt is not None:
+                    x1, mean1, rstd1 = nxt
+                else:
+                    x1, _, mean1, rstd1 = ops.ln_fwd(h, w.ln1.gamma, w.ln1.beta)
                 qkv = _fwd_linear(x1, w.qkv, False)
             # the attention-probability side outputs (a7) come out of the forward launch: K is still resident in LDS
             if fp8_attn:
@@ -123,21 +134,35 @@ class TransformerStackFn(torch.autograd.Function):
                 if log_lo is not None:
                     ops.attention_colsum(qkv, lse, B, S, heads, log_lo, log_hi, qsplit=opts['log_split'], valid=valid,
                                          valid_q_only=True, weight=1.0 / heads, seg=seg)
-            h_mid = ops.gemm_nt(ctx_, w.proj.wb, bias=w.proj.b, epilogue=EPI_RESIDUAL, aux_in=h, dropout_p=p,
-                                dropout_seed=_site_seed(seed, l, 0))
-            if fp8:
-                x2, x2q, rs2, mean2, rstd2 = ops.ln_fwd_q8(h_mid, w.ln2.gamma, w.ln2.beta)
-            else:
-                x2, _, mean2, rstd2 = ops.ln_fwd(h_mid, w.ln2.gamma, w.ln2.beta)
+            if fuse_ln:
+                h_mid, x2, mean2, rstd2 = ops.gemm_nt_ln(ctx_, w.proj.wb, w.ln2.gamma, w.ln2.beta, bias=w.proj.b, aux_in=h, dropout_p=p,
+                                                         dropout_seed=_site_seed(seed, l, 0))
                 x2q = rs2 = None
+            else:
+                h_mid = ops.gemm_nt(ctx_, w.proj.wb, bias=w.proj.b, epilogue=EPI_RESIDUAL, aux_in=h, dropout_p=p,
+                                    dropout_seed=_site_seed(seed, l, 0))
+                if fp8:
+                    x2, x2q, rs2, mean2, rstd2 = ops.ln_fwd_q8(h_mid, w.ln2.gamma, w.ln2.beta)
+                else:
+                    x2, _, mean2, rstd2 = ops.ln_fwd(h_mid, w.ln2.gamma, w.ln2.beta)
+                    x2q = rs2 = None
             u = torch.empty((x2.shape[0], w.fc1.wb.shape[0]), device=h.device, dtype=BF16)
             a = _fwd_linear(x2, w.fc1, fp8, x8=x2q, row_scale=rs2, epilogue=EPI_GELU, aux_out=u)
-            h_out = _fwd_linear(a, w.fc2, fp8_fc2, epilogue=EPI_RESIDUAL, aux_in=h_mid, dropout_p=p,
-                                dropout_seed=_site_seed(seed, l, 1))
+            if fuse_ln:
+                ln_next = stack.layers[l + 1].ln1 if l + 1 < nl else stack.ln_final
+                h_out, xn, meann, rstdn = ops.gemm_nt_ln(a, w.fc2.wb, ln_next.gamma, ln_next.beta, bias=w.fc2.b, aux_in=h_mid, dropout_p=p,
+                                                         dropout_seed=_site_seed(seed, l, 1))
+                nxt = (xn, meann, rstdn)
+            else:
+                h_out = _fwd_linear(a, w.fc2, fp8_fc2, epilogue=EPI_RESIDUAL, aux_in=h_mid, dropout_p=p,
+                                    dropout_seed=_site_seed(seed, l, 1))
             if need_bwd:
                 saved.append((h, mean1, rstd1, x1, qkv, ctx_, lse, h_mid, mean2, rstd2, x2, u, a))
             h = h_out
-        y, _, meanf, rstdf = ops.ln_fwd(h, stack.ln_final.gamma, stack.ln_final.beta)
+        if fuse_ln and nxt is not None:
+            y, meanf, rstdf = nxt
+        else:
+            y, _, meanf, rstdf = ops.ln_fwd(h, stack.ln_final.gamma, stack.ln_final.beta)
         ctx.stack, ctx.B, ctx.S, ctx.valid, ctx.heads, ctx.p, ctx.seed, ctx.nl = stack, B, S, valid, heads, p, seed, nl
         ctx.seg = seg
         ctx.fp8_attn = fp8_attn

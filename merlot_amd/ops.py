@@ -78,7 +78,7 @@ def reset_workspaces():
     skip its first items silently.  Registered as the binding's error hook (every failed C-ABI call runs it before raising) and callable by hand
     after anything that may have killed a kernel.  One block belongs to ONE stream: concurrent launches sharing a block are undefined behaviour
     (include/merlot_hip.h), which is why the blocks are keyed by (device, stream) here."""
-    for buf in list(_NT_WS.values()) + list(_ATTN_WS.values()):
+    for buf in list(_NT_WS.values()) + list(_ATTN_WS.values()) + list(_LN_WS.values()):
         buf.zero_()
 
 
@@ -121,6 +121,42 @@ def gemm_nt(a, bt, *, bias=None, epilogue=EPI_NONE, out=None, out_dtype=BF16, ac
     else:
         launch()
     return out
+
+
+_LN_WS = {}
+
+
+def _ln_ws(M, N):
+    """(pointer, bytes) of the LayerNorm-fold workspace (include/merlot_hip.h, ABI v8: arrival counters zero on entry and left zero + scratch for the
+    segment statistics): one block per (device, stream), grown to the largest M seen."""
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    need = LIB.query('merlot_gemm_nt_ln_workspace_bytes', M, N)
+    buf = _LN_WS.get(key)
+    if buf is None or buf.numel() * 4 < need:
+        buf = _LN_WS[key] = torch.zeros((need + 3) // 4, device='cuda', dtype=torch.int32)
+    return buf.data_ptr(), buf.numel() * 4
+
+
+def gemm_nt_ln(a, bt, gamma, beta, *, bias=None, aux_in=None, dropout_p=0.0, dropout_seed=0, alpha=1.0, eps=1e-5, save_stats=True):
+    """h = aux_in + dropout(alpha * a @ bt^T + bias) and LayerNorm(h) from ONE call (merlot_gemm_bf16_nt_ln) -> (h, y, mean, rstd)."""
+    _chk(a, BF16, 'a'); _chk(bt, BF16, 'bt'); _chk(bias, F32, 'bias'); _chk(aux_in, BF16, 'aux_in'); _chk(gamma, F32, 'gamma'); _chk(beta, F32, 'beta')
+    M, K = a.shape
+    N = bt.shape[0]
+    h = torch.empty((M, N), device=a.device, dtype=BF16)
+    y = torch.empty((M, N), device=a.device, dtype=BF16)
+    mean = torch.empty(M, device=a.device, dtype=F32) if save_stats else None
+    rstd = torch.empty(M, device=a.device, dtype=F32) if save_stats else None
+
+    def launch():
+        call('merlot_gemm_bf16_nt_ln', _p(a), a.stride(0), _p(bt), bt.stride(0), _p(h), N, M, N, K, float(alpha), _p(bias), _p(aux_in),
+             aux_in.stride(0), float(dropout_p), int(dropout_seed) & 0xFFFFFFFFFFFFFFFF, _p(gamma), _p(beta), _p(y), N, _p(mean), _p(rstd),
+             float(eps), *_ln_ws(M, N), *_nt_ws(), _stream())
+
+    if TIMER is not None:
+        TIMER.time('gemm_nt', 2.0 * M * N * K, launch)
+    else:
+        launch()
+    return h, y, mean, rstd
 
 
 FP8 = torch.float8_e4m3fn

@@ -49,6 +49,12 @@ def gemm_nt(a, bt, *, bias=None, epilogue=EPI_NONE, out=None, out_dtype=BF16, ac
     return out
 
 
+def gemm_nt_ln(a, bt, gamma, beta, *, bias=None, aux_in=None, dropout_p=0.0, dropout_seed=0, alpha=1.0, eps=1e-5, save_stats=True):
+    h = gemm_nt(a, bt, bias=bias, epilogue=EPI_RESIDUAL, aux_in=aux_in, dropout_p=dropout_p, dropout_seed=dropout_seed, alpha=alpha)
+    y, _, mean, rstd = ln_fwd(h, gamma, beta, eps=eps, save_stats=save_stats)
+    return h, y, mean, rstd
+
+
 def gemm_tn(a, b, out, *, accumulate=True, alpha=1.0, m=None, n=None):
     M = a.shape[1] if m is None else m
     N = b.shape[1] if n is None else n
@@ -536,7 +542,7 @@ def weight_std_bwd_batched(dk, jobs, total_blocks, khat, rstd, gk_base):
                        rstd[o_rstd:o_rstd + Co], gk_base[o_gk:o_gk + K * Co].view(K, Co))
 
 
-_NAMES = ['weight_std_fwd', 'weight_std_bwd', 'weight_std_fwd_batched', 'weight_std_bwd_batched', 'gemm_nt', 'gemm_tn', 'patch_embed_fwd', 'patch_embed_wgrad', 'ln_fwd', 'ln_bwd', 'attention_fwd',
+_NAMES = ['gemm_nt_ln', 'weight_std_fwd', 'weight_std_bwd', 'weight_std_fwd_batched', 'weight_std_bwd_batched', 'gemm_nt', 'gemm_tn', 'patch_embed_fwd', 'patch_embed_wgrad', 'ln_fwd', 'ln_bwd', 'attention_fwd',
           'attention_bwd', 'attention_colsum', 'cast_bf16', 'cast_transpose_bf16', 'colsum_bf16', 'gather_add4',
           'scatter_add_rows', 'dropout_apply', 'cls_avgpool_fwd', 'cls_avgpool_bwd', 'softmax_ce', 'vocab_ce', 'l2norm_fwd',
           'l2norm_bwd', 'gelu_fwd', 'gelu_bwd', 'mask_inputs', 'temporal_labels', 'shuffled_idx', 'im2col3x3', 'col2im3x3', 'conv3x3', 'conv3x3_wgrad',

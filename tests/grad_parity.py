@@ -42,6 +42,14 @@ def problem(which):
         # stable: config #1, config #2 at one example, the reference-run fixtures); the masks here come from the explicit noise only
         cfg = tiny_config(image_size=[224, 224], masking_use_attn=False)
         return cfg, synth_batch(cfg, E=8, num_chunks=16, seed=5)
+    if which == 'config2d12':                               # BASELINE config #2 at FULL depth (12 + 12 + 12 layers, 224^2, 16 chunks), one example:
+        import os                                           # the problem of tests/test_config2_depth12_gpu.py (attention-guided masking on)
+        from merlot_amd import NeatConfig
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        config = NeatConfig.from_yaml(os.path.join(root, 'merlot_amd', 'configs', 'pretrain_4seg_224.yaml'))
+        cfg = dict(config.model)
+        cfg['hidden_dropout_prob'] = 0.0
+        return cfg, synth_batch(cfg, E=1, num_chunks=16, seed=11, two_videos=True)
     raise ValueError(which)
 
 

@@ -27,7 +27,8 @@ SURVEY_8B = {
     # dgrad dX = dY . W reads W through its transposed bf16 working copy (refreshed once per step with the cast): NT + the transposes
     'merlot_gemm_bf16_nn': ['merlot_gemm_bf16_nt', 'merlot_cast_transpose_f32_bf16', 'merlot_cast_transpose_batched'],
     # epilogue enum {none, bias, bias_gelu, bias_residual, bias_dropout_residual} = merlot_epilogue + bias / dropout_p arguments
-    'merlot_ln_residual_fwd': ['merlot_ln_fwd', 'merlot_gemm_bf16_nt'],     # the residual add lives in the producing GEMM's epilogue
+    # round 6 (ABI v8): ONE entry -- the residual GEMM's launch also emits LayerNorm(h) (merlot_gemm_bf16_nt_ln); merlot_ln_fwd stays for the stand-alone sites
+    'merlot_ln_residual_fwd': ['merlot_gemm_bf16_nt_ln', 'merlot_gemm_nt_ln_workspace_bytes', 'merlot_gemm_bf16_nt_ln_plan', 'merlot_ln_fwd'],
     'merlot_ln_residual_bwd': ['merlot_ln_bwd'],                            # dres / branch gradient / bias column sums fused
     'merlot_qkv_attention_fwd': ['merlot_attention_fwd', 'merlot_attention_workspace_bytes'],                   # colsum_out / blocksum_out = colsum_lo / colsum_hi
     'merlot_qkv_attention_bwd': ['merlot_attention_bwd'],
@@ -69,7 +70,7 @@ def test_library_exports_every_declared_symbol():
     for name in lib.parse_header():
         assert hasattr(dll, name), f"{name} declared in include/merlot_hip.h but not exported"
     d = lib.LIB.load()
-    assert d.merlot_abi_version() == 7
+    assert d.merlot_abi_version() == 8
     assert d.merlot_last_error() is not None
 
 

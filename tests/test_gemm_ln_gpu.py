@@ -1,0 +1,108 @@
+"""GPU: merlot_gemm_bf16_nt_ln (ABI v8, round 6) -- the residual GEMM whose launch also emits LayerNorm of its output (csrc/gemm_p8.inc "LNF": segment
+statistics from every tile's epilogue, the row block normalised by the last of its three tiles to arrive).  Checked against the two-launch composition it
+replaces (merlot_gemm_bf16_nt RESIDUAL + merlot_ln_fwd) and against plain torch fp32:
+  * h (the GEMM output) BIT-identical to the unfused launch -- the fold must not touch the GEMM's own result, with and without dropout;
+  * LN(h): mean / rstd within 2e-6 relative of the stand-alone kernel's (different summation order, same fp32), the bf16 output equal to it up to one bf16
+    unit on a vanishing fraction of elements (<= 1e-3 of them may differ, by <= 1 ulp) and rel-L2 <= 1e-3 against torch's fp32 layer_norm of the same h;
+  * every row block normalised exactly once (NaN-prefilled outputs), the arrival counters left zero (a second launch on the same workspace is right),
+    rows whose mean is 100x their spread (the cancellation case a sum-of-squares variance would lose);
+  * shapes the fused kernel does not take (N != 768, few row blocks) and a ragged last row block go through the composition / the tail launch.
+Reference: utils/transformer.py:130-136,158-162,214,220; utils/model_utils.py:113-130."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+@pytest.fixture(scope='module')
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from merlot_amd import ops as o
+    from merlot_amd.lib import LIB
+    LIB.load()
+    return o
+
+
+def rnd(shape, seed, scale=1.0, dtype=BF16):
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    return (torch.randn(shape, generator=g, device='cuda') * scale).to(dtype)
+
+
+def plan(M, N, K):
+    from merlot_amd.lib import LIB
+    return LIB.query('merlot_gemm_bf16_nt_ln_plan', M, N, K)
+
+
+def ulp_diff(a, b):
+    """bf16 tensors -> per-element distance in bf16 units (monotone integer encoding)"""
+    def key(t):
+        i = t.view(torch.int16).to(torch.int32)
+        return torch.where(i < 0, -(i & 0x7FFF), i)
+    return (key(a) - key(b)).abs()
+
+
+def both(ops, M, K, p, seed, res_scale=1.0, res_shift=0.0, N=768):
+    a, w = rnd((M, K), seed), rnd((N, K), seed + 1, 0.03)
+    bias = rnd((N,), seed + 2, 0.1, F32)
+    res = (rnd((M, N), seed + 3, res_scale).float() + res_shift).to(BF16)
+    gamma, beta = 1.0 + rnd((N,), seed + 4, 0.2, F32), rnd((N,), seed + 5, 0.2, F32)
+    h0 = ops.gemm_nt(a, w, bias=bias, epilogue=ops.EPI_RESIDUAL, aux_in=res, dropout_p=p, dropout_seed=77)
+    y0, _, m0, r0 = ops.ln_fwd(h0, gamma, beta)
+    h1, y1, m1, r1 = ops.gemm_nt_ln(a, w, gamma, beta, bias=bias, aux_in=res, dropout_p=p, dropout_seed=77)
+    torch.cuda.synchronize()
+    return (h0, y0, m0, r0), (h1, y1, m1, r1), (gamma, beta)
+
+
+def check(ref, got, gb, frac=1e-3, mean_tol=2e-6, rstd_tol=2e-5):
+    (h0, y0, m0, r0), (h1, y1, m1, r1), (gamma, beta) = ref, got, gb
+    assert torch.equal(h0, h1)                                              # the GEMM's own output: bit for bit
+    assert torch.isfinite(y1.float()).all() and torch.isfinite(m1).all() and torch.isfinite(r1).all()
+    assert float(((m1 - m0).abs() / (m0.abs() + 1.0 / r0)).max()) < mean_tol   # mean, relative to the row's scale
+    assert float(((r1 - r0).abs() / r0).max()) < rstd_tol
+    d = ulp_diff(y0, y1)
+    assert int(d.max()) <= 1 and float((d > 0).float().mean()) < frac, (int(d.max()), float((d > 0).float().mean()))
+    t = torch.nn.functional.layer_norm(h1.float(), (h1.shape[1],), gamma, beta, 1e-5)
+    assert float((y1.float() - t).norm() / t.norm()) < 4e-3                 # bf16 rounding of the output
+
+
+@pytest.mark.parametrize("M,K,p", [(65536, 768, 0.0), (65536, 3072, 0.1), (24576 + 256 * 41, 768, 0.1)])
+def test_fused_layernorm_matches_the_two_launch_composition(ops, M, K, p):
+    assert plan(M, 768, K) == 1
+    ref, got, gb = both(ops, M, K, p, 11)
+    check(ref, got, gb)
+    # the arrival counters were left zero: the same workspace serves the next launch (a different seed -> different values, same checks)
+    ref, got, gb = both(ops, M, K, p, 23)
+    check(ref, got, gb)
+    from merlot_amd import ops as o
+    for buf in o._LN_WS.values():
+        nblk = (M + 255) // 256
+        assert int(buf[:nblk].abs().sum()) == 0
+
+
+def test_fused_layernorm_rows_with_a_mean_far_above_their_spread(ops):
+    """residual stream shifted by +50 with unit spread: E[x^2] - E[x]^2 in fp32 would keep ~3 digits of the variance; segment-wise centred sums keep them all"""
+    M, K = 65536, 768
+    ref, got, gb = both(ops, M, K, 0.0, 31, res_scale=1.0, res_shift=50.0)
+    # (y = x s - mean s + beta cancels 50 s against 50 s here: an fp32-rounding difference in mean or rstd flips more bf16 roundings than on centred rows)
+    check(ref, got, gb, frac=0.15, rstd_tol=1e-4)
+
+
+def test_bench_shape_every_row_block_normalised_once(ops):
+    M, K = 405504, 768                                                      # the ViT pass of the bench batch: 1 584 row blocks, 18.6 tiles per workgroup
+    assert plan(M, 768, K) == 1
+    ref, got, gb = both(ops, M, K, 0.1, 41)
+    check(ref, got, gb)
+
+
+@pytest.mark.parametrize("M,N,K", [(65536 + 100, 768, 768), (4096, 768, 768), (65536, 1024, 768), (16384, 768, 3072)])
+def test_shapes_outside_the_fused_kernel_and_ragged_tails(ops, M, N, K):
+    ref, got, gb = both(ops, M, K, 0.1, 51, N=N)
+    (h0, y0, m0, r0), (h1, y1, m1, r1), _ = ref, got, gb
+    assert torch.equal(h0, h1)
+    if M % 256 and plan(M, N, K):                                           # whole row blocks fused, the ragged rest by the LayerNorm kernel: bit-equal there
+        t0 = M // 256 * 256
+        assert torch.equal(y0[t0:], y1[t0:]) and torch.equal(m0[t0:], m1[t0:])
+        check(ref, got, gb)
+    else:                                                                   # the composition itself
+        assert torch.equal(y0, y1) and torch.equal(m0, m1) and torch.equal(r0, r1)

@@ -117,10 +117,16 @@ def test_gemm_main_loops():
     lines = _compile('gemm.hip')
     # ping-pong NT kernel, two phases per K-tile: 32 MFMAs per wave and K-tile, 24 fragment reads; 56 vector-ALU instructions before the bases were pinned
     for epi in range(4):
-        body, vg = _kernel(lines, r'gemm_nt_p8_kernelILi%dELb0ELb0ELb1E' % epi)
+        body, vg = _kernel(lines, r'gemm_nt_p8_kernelILi%dELb0ELb0ELb1ELb0E' % epi)          # <EPI, bf16 out, bf16 operands, two phases, no LayerNorm fold>
         steady = _loops(body, 32, inner_labels=True)
         assert len(steady) == 1 and _valu(steady[0]) <= 50 and steady[0]['ds_read_b128'] == 24, (epi, steady)
         assert 'scratch_load_dwordx4' not in steady[0] and 'scratch_store_dwordx4' not in steady[0]
+    # the RESIDUAL kernel that also emits LayerNorm(C) (round 6): the same main loop -- no scratch, 24 fragment reads; its extra epilogue state costs address
+    # arithmetic in the loop (66 vector-ALU instructions when first built)
+    body, vg = _kernel(lines, r'gemm_nt_p8_kernelILi2ELb0ELb0ELb1ELb1E')
+    steady = _loops(body, 32, inner_labels=True)
+    assert len(steady) == 1 and _valu(steady[0]) <= 70 and steady[0]['ds_read_b128'] == 24, steady
+    assert 'scratch_load_dwordx4' not in steady[0] and 'scratch_store_dwordx4' not in steady[0] and 'scratch_load_dword' not in steady[0]
     # one-phase TN kernel: 48 transposing reads, 32 MFMAs; 18 vector-ALU instructions before the B base was pinned
     body, vg = _kernel(lines, r'gemm_tn_p1_kernel')
     steady = [c for c in _loops(body, 32, inner_labels=True) if c['ds_read_b64_tr_b16'] == 48 and sum(c.values()) < 200]
