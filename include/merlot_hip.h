@@ -138,6 +138,13 @@ int64_t merlot_gemm_bf16_tn_workspace_bytes(int64_t M, int64_t N, int64_t R);
 int merlot_gemm_bf16_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
                         int64_t M, int64_t N, int64_t R, float alpha, int accumulate, void* workspace,
                         int64_t workspace_bytes, merlot_stream_t stream);
+/* ABI v8: merlot_gemm_bf16_tn that ALSO accumulates colsum_a[m] += sum_r A[r, m] for m < colsum_m (f32; colsum_a NULL: exactly merlot_gemm_bf16_tn) --
+ * the bias gradient that goes with this weight gradient, taken from the operand fragments the ping-pong kernel holds in registers instead of a second
+ * pass over A (the Q third of the fused QKV bias, utils/transformer.py:21-25 under tf.gradients); shapes another kernel takes: merlot_colsum_bf16
+ * behind the GEMM, same result up to summation order. */
+int merlot_gemm_bf16_tn_cs(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
+                           int64_t M, int64_t N, int64_t R, float alpha, int accumulate, float* colsum_a, int64_t colsum_m,
+                           void* workspace, int64_t workspace_bytes, merlot_stream_t stream);
 
 /* Patch-embed 16x16/16 conv (utils/vision_transformer.py:193-205) as im2col + MFMA GEMM.
  * image: bf16 NHWC [n_img, H, W, 3] in [0,1]; patches: bf16 [n_img*(H/P)*(W/P), P*P*3], k = (py,px,c) = HWIO flattening,

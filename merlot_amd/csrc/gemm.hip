@@ -1600,7 +1600,16 @@ int tn_p8_launch(GemmTNArgs& a, int accumulate, float* ws, int64_t ws_bytes, hip
     return merlot_launch_status("merlot_gemm_bf16_tn(p8)");
 }
 
+int gemm_tn_dispatch_(GemmTNArgs& a, int accumulate, float* ws, int64_t ws_bytes, hipStream_t s, int64_t& cs_rows_done);
+// colsum_a (the column sums of A's first colsum_m columns, accumulated): from the one-phase ping-pong kernel's own fragments for the reduction rows that
+// kernel covers, from merlot_colsum_bf16 (same stream, right behind) for the rest -- every row when another kernel takes the shape
 int gemm_tn_dispatch(GemmTNArgs& a, int accumulate, float* ws, int64_t ws_bytes, hipStream_t s) {
+    int64_t cs_rows_done = 0;
+    const int rc = gemm_tn_dispatch_(a, accumulate, ws, ws_bytes, s, cs_rows_done);
+    if (rc != MERLOT_OK || !a.colsum_a || cs_rows_done == a.R) return rc;
+    return merlot_colsum_bf16(a.A + cs_rows_done * a.lda, a.lda, a.colsum_a, a.R - cs_rows_done, a.colsum_m, 1, s);
+}
+int gemm_tn_dispatch_(GemmTNArgs& a, int accumulate, float* ws, int64_t ws_bytes, hipStream_t s, int64_t& cs_rows_done) {
     if (!tn_ring_ok(a)) return tn_launch(a, accumulate, s);
     int tn_kernel = (tn_p8_shape(a.M, a.N, a.R / 64 * 64) && ((int64_t)a.R + 64) * a.lda * 2 < (1LL << 32) &&
                      ((int64_t)a.R + 64) * a.ldb * 2 < (1LL << 32)) ? 1 : 0;     // unsigned 32-bit byte offsets
@@ -1613,6 +1622,10 @@ int gemm_tn_dispatch(GemmTNArgs& a, int accumulate, float* ws, int64_t ws_bytes,
         GemmTNArgs m = a;
         m.R = r_main;
         int rc = tn_p8_launch(m, accumulate, ws, ws_bytes, s);
+#ifdef MERLOT_EXPERIMENTS
+        if (!getenv("MERLOT_TN_PH2"))                    // (the two- and four-phase bodies of the experiments build do not sum A)
+#endif
+            if (a.colsum_a) cs_rows_done = r_main;
         if (rc != MERLOT_OK || r_main == R) return rc;
         GemmTNArgs t = a;                                // < 64 reduction rows left: the register-staged kernel adds them
         t.A = a.A + (int64_t)r_main * a.lda;
@@ -1822,18 +1835,26 @@ extern "C" int64_t merlot_gemm_bf16_tn_workspace_bytes(int64_t M, int64_t N, int
     return need;
 }
 
-extern "C" int merlot_gemm_bf16_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
-                                   int64_t M, int64_t N, int64_t R, float alpha, int accumulate, void* workspace,
-                                   int64_t workspace_bytes, merlot_stream_t stream) {
+extern "C" int merlot_gemm_bf16_tn_cs(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
+                                      int64_t M, int64_t N, int64_t R, float alpha, int accumulate, float* colsum_a, int64_t colsum_m,
+                                      void* workspace, int64_t workspace_bytes, merlot_stream_t stream) {
     MERLOT_CHECK(A && B && C, MERLOT_ESHAPE, "merlot_gemm_bf16_tn: null operand");
     MERLOT_CHECK(M > 1 && N > 1 && R > 0 && R < (1LL << 31), MERLOT_ESHAPE, "merlot_gemm_bf16_tn: bad dims");
     MERLOT_CHECK(M % 2 == 0 && N % 2 == 0 && lda % 2 == 0 && ldb % 2 == 0, MERLOT_EALIGN,
                  "merlot_gemm_bf16_tn: M, N, lda, ldb must be even");
+    MERLOT_CHECK(!colsum_a || (colsum_m > 0 && colsum_m <= M), MERLOT_ESHAPE, "merlot_gemm_bf16_tn_cs: colsum_m=%lld outside (0, M=%lld]",
+                 (long long)colsum_m, (long long)M);
     GemmTNArgs a{};
     a.A = (const bf16*)A; a.B = (const bf16*)B; a.C = C;
     a.lda = lda; a.ldb = ldb; a.ldc = ldc;
     a.M = (int)M; a.N = (int)N; a.R = (int)R; a.alpha = alpha;
+    a.colsum_a = colsum_a; a.colsum_m = colsum_a ? (int)colsum_m : 0;
     return gemm_tn_dispatch(a, accumulate, (float*)workspace, workspace_bytes, (hipStream_t)stream);
+}
+extern "C" int merlot_gemm_bf16_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
+                                   int64_t M, int64_t N, int64_t R, float alpha, int accumulate, void* workspace,
+                                   int64_t workspace_bytes, merlot_stream_t stream) {
+    return merlot_gemm_bf16_tn_cs(A, lda, B, ldb, C, ldc, M, N, R, alpha, accumulate, nullptr, 0, workspace, workspace_bytes, stream);
 }
 
 // Patch-embed 16x16/16 convolution = explicit im2col (merlot_im2col_patches, csrc/conv.hip: the `image - 0.5` of

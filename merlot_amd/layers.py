@@ -208,8 +208,8 @@ class TransformerStackFn(torch.autograd.Function):
                                          log_split=ctx.log[2], log_weight=1.0 / heads)
             else:
                 dqkv = ops.attention_bwd(qkv, ctx_, dctx, lse, B, S, heads, valid, seg=ctx.seg)
-            ops.colsum_bf16(dqkv[:, :D] if exact_rows else dqkv, w.qkv.gb[:D] if exact_rows else w.qkv.gb)
-            ops.gemm_tn(dqkv, x1, w.qkv.gw)
+            # (round 6: the Q third's column sums come out of the weight-gradient launch below -- its A fragments are dQKV)
+            ops.gemm_tn(dqkv, x1, w.qkv.gw, colsum_a=w.qkv.gb[:D] if exact_rows else w.qkv.gb)
             dx1 = ops.gemm_nt(dqkv, w.qkv.wbT)
             if l > 0:
                 dh, db2 = ops.ln_bwd(dx1, h, mean1, rstd1, w.ln1.gamma, w.ln1.ggamma, w.ln1.gbeta, dres=dh_mid,

@@ -207,9 +207,9 @@ def gemm_fp8_nt(a8, a_scale, bt8, b_scale, *, bias=None, epilogue=EPI_NONE, out=
     return out
 
 
-def gemm_tn(a, b, out, *, accumulate=True, alpha=1.0, m=None, n=None):
-    """out[M,N] (f32) (+)= alpha * a[R,M]^T @ b[R,N]."""
-    _chk(a, BF16, 'a'); _chk(b, BF16, 'b'); _chk(out, F32, 'out')
+def gemm_tn(a, b, out, *, accumulate=True, alpha=1.0, m=None, n=None, colsum_a=None):
+    """out[M,N] (f32) (+)= alpha * a[R,M]^T @ b[R,N].  colsum_a (f32 [m'], accumulated): += the column sums of a[:, :m'] from the same launch."""
+    _chk(a, BF16, 'a'); _chk(b, BF16, 'b'); _chk(out, F32, 'out'); _chk(colsum_a, F32, 'colsum_a')
     R = a.shape[0]
     M = a.shape[1] if m is None else m
     N = b.shape[1] if n is None else n
@@ -217,8 +217,8 @@ def gemm_tn(a, b, out, *, accumulate=True, alpha=1.0, m=None, n=None):
     ws = torch.empty(nbytes // 4, device=a.device, dtype=F32) if nbytes else None   # caller-owned split-R partials
 
     def launch():
-        call('merlot_gemm_bf16_tn', _p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, R,
-             float(alpha), 1 if accumulate else 0, _p(ws), nbytes, _stream())
+        call('merlot_gemm_bf16_tn_cs', _p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, R,
+             float(alpha), 1 if accumulate else 0, _p(colsum_a), colsum_a.numel() if colsum_a is not None else 0, _p(ws), nbytes, _stream())
 
     if TIMER is not None:
         TIMER.time('gemm_tn', 2.0 * M * N * R, launch)

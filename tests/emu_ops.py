@@ -55,7 +55,9 @@ def gemm_nt_ln(a, bt, gamma, beta, *, bias=None, aux_in=None, dropout_p=0.0, dro
     return h, y, mean, rstd
 
 
-def gemm_tn(a, b, out, *, accumulate=True, alpha=1.0, m=None, n=None):
+def gemm_tn(a, b, out, *, accumulate=True, alpha=1.0, m=None, n=None, colsum_a=None):
+    if colsum_a is not None:
+        colsum_a += a[:, :colsum_a.numel()].float().sum(0)
     M = a.shape[1] if m is None else m
     N = b.shape[1] if n is None else n
     v = alpha * (a[:, :M].float().t() @ b[:, :N].float())

@@ -23,7 +23,7 @@ SURVEY_8B = {
     'merlot_patch_embed_fwd': ['merlot_patch_embed_fwd', 'merlot_im2col_patches'],
     'merlot_patch_embed_bwd': ['merlot_patch_embed_wgrad'],                 # the image is not differentiated: weight gradient only
     'merlot_gemm_bf16_nt': ['merlot_gemm_bf16_nt', 'merlot_gemm_nt_workspace_bytes', 'merlot_gemm_bf16_nt_plan'],
-    'merlot_gemm_bf16_tn': ['merlot_gemm_bf16_tn', 'merlot_gemm_bf16_tn_workspace_bytes'],
+    'merlot_gemm_bf16_tn': ['merlot_gemm_bf16_tn', 'merlot_gemm_bf16_tn_cs', 'merlot_gemm_bf16_tn_workspace_bytes'],
     # dgrad dX = dY . W reads W through its transposed bf16 working copy (refreshed once per step with the cast): NT + the transposes
     'merlot_gemm_bf16_nn': ['merlot_gemm_bf16_nt', 'merlot_cast_transpose_f32_bf16', 'merlot_cast_transpose_batched'],
     # epilogue enum {none, bias, bias_gelu, bias_residual, bias_dropout_residual} = merlot_epilogue + bias / dropout_p arguments

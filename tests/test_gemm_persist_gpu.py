@@ -283,3 +283,24 @@ def test_alpha_is_folded_the_same_way_in_interior_and_boundary_tiles(ops, epi):
         got = ops.gemm_nt(a, bt, epilogue=ops.EPI_DGELU, aux_in=aux, **kw)
     assert torch.equal(got[M - 100:], got[256:356])
     assert torch.equal(got[:, 768:], got[:, :128])
+
+
+@pytest.mark.parametrize("R,M,N,cm", [(101376, 2304, 768, 768),        # dW_qkv of a ViT layer at 512 segments: the Q third's bias gradient
+                                      (101376 + 40, 2304, 768, 2304),   # every third (the fp8-attention case) + a reduction tail the kernel does not cover
+                                      (16384, 768, 768, 300),           # a limit inside a tile
+                                      (2048, 768, 768, 768)])           # a shape the one-phase kernel does not take: the column-sum kernel behind the GEMM
+def test_weight_gradient_launch_also_sums_its_a_operand(ops, R, M, N, cm):
+    """merlot_gemm_bf16_tn_cs (ABI v8): colsum_a[m] += sum_r A[r, m], m < cm, from the weight-gradient launch's own A fragments (v_dot2c against (1, 1)) --
+    the fused-QKV bias gradient without a pass over dQKV.  fp32 sums of bf16 values: against the fp64 column sums within 2e-6 * sum |a| per column; the
+    weight gradient itself bit-identical to the plain launch; accumulation on top of what colsum_a held."""
+    a, b = dev_rand((R, M), 61), dev_rand((R, N), 62)
+    w0 = torch.zeros((M, N), device='cuda', dtype=F32)
+    w1 = torch.zeros((M, N), device='cuda', dtype=F32)
+    cs = torch.full((cm,), 3.0, device='cuda', dtype=F32)
+    ops.gemm_tn(a, b, w0, accumulate=False)
+    ops.gemm_tn(a, b, w1, accumulate=False, colsum_a=cs)
+    torch.cuda.synchronize()
+    assert torch.equal(w0, w1)
+    ref = a[:, :cm].double().sum(0)
+    bound = 2e-6 * a[:, :cm].double().abs().sum(0) + 1e-6
+    assert bool(((cs.double() - 3.0 - ref).abs() <= bound).all()), float(((cs.double() - 3.0 - ref).abs() / bound).max())

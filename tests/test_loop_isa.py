@@ -128,6 +128,6 @@ def test_gemm_main_loops():
     assert len(steady) == 1 and _valu(steady[0]) <= 70 and steady[0]['ds_read_b128'] == 24, steady
     assert 'scratch_load_dwordx4' not in steady[0] and 'scratch_store_dwordx4' not in steady[0] and 'scratch_load_dword' not in steady[0]
     # one-phase TN kernel: 48 transposing reads, 32 MFMAs; 18 vector-ALU instructions before the B base was pinned
-    body, vg = _kernel(lines, r'gemm_tn_p1_kernel')
+    body, vg = _kernel(lines, r'gemm_tn_p1_kernelILb0E')
     steady = [c for c in _loops(body, 32, inner_labels=True) if c['ds_read_b64_tr_b16'] == 48 and sum(c.values()) < 200]
     assert len(steady) == 1 and _valu(steady[0]) <= 6, steady
