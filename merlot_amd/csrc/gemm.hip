@@ -1301,9 +1301,13 @@ __device__ __forceinline__ void ln_row_block(const GemmNTArgs& p, int tm, char* 
         float s1[NSEG], q[NSEG];
 #pragma unroll
         for (int g = 0; g < NSEG; ++g) {
-            const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(rs_part, (int)(((int64_t)g * mpad + row) * 8), 0, SC1);
-            s1[g] = __builtin_bit_cast(float, raw[0]);
-            q[g] = __builtin_bit_cast(float, raw[1]);
+            // (the builtin's result type is a GCC-style vector: converted IMPLICITLY to an ext_vector type hipcc kept element 0 only -- every row's M2 read back
+            // as its sum, rstd NaN, profiles/r06_d_ln_fold_debug.txt; hence auto + bit_cast)
+            const auto raw = __builtin_amdgcn_raw_buffer_load_b64(rs_part, (int)(((int64_t)g * mpad + row) * 8), 0, SC1);
+            static_assert(sizeof(raw) == 8, "two dwords");
+            const f32x2 sq = __builtin_bit_cast(f32x2, raw);
+            s1[g] = sq[0];
+            q[g] = sq[1];
         }
         float tot = 0.f;
 #pragma unroll
@@ -1332,7 +1336,11 @@ __device__ __forceinline__ void ln_row_block(const GemmNTArgs& p, int tm, char* 
         bf16* dst = p.ln_out + ((int64_t)tm * 256 + rr) * p.ld_ln + col;
         u32x4 x[16];
 #pragma unroll
-        for (int ps = 0; ps < 16; ++ps) x[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_c, (int)(src + (unsigned)ps * row_step), 0, SC1);
+        for (int ps = 0; ps < 16; ++ps) {
+            const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rs_c, (int)(src + (unsigned)ps * row_step), 0, SC1);
+            static_assert(sizeof(raw) == 16, "four dwords");
+            x[ps] = __builtin_bit_cast(u32x4, raw);
+        }
 #pragma unroll
         for (int ps = 0; ps < 16; ++ps) {
             const f32x2 st = stat[ps * 16 + rr];
