@@ -84,7 +84,8 @@ int64_t merlot_gemm_nt_workspace_bytes(void);
  * Statistics are combined from 64-column segments (sum, centred sum of squares; exact pairwise combination), so mean / rstd agree with
  * merlot_ln_fwd to fp32 rounding, not bit for bit.
  * ln_workspace: merlot_gemm_nt_ln_workspace_bytes(M, N) bytes, 16-byte aligned, its first ceil(M/256) uint32 ZERO on entry and left zero
- * (arrival counters; the rest is scratch); one block per concurrently used stream.  workspace: as merlot_gemm_bf16_nt. */
+ * (arrival counters; the rest is scratch).  The layout is a function of M: a block serves launches of ONE M (and N) on one stream at a time -- reuse it for
+ * another M only after clearing it again.  workspace: as merlot_gemm_bf16_nt. */
 int64_t merlot_gemm_nt_ln_workspace_bytes(int64_t M, int64_t N);
 int merlot_gemm_bf16_nt_ln_plan(int64_t M, int64_t N, int64_t K);
 int merlot_gemm_bf16_nt_ln(const void* A, int64_t lda, const void* Bt, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,

@@ -1296,6 +1296,19 @@ __device__ __forceinline__ void ln_row_block(const GemmNTArgs& p, int tm, char* 
     const int64_t mpad = (int64_t)p.ntm * 256;
     const __amdgpu_buffer_rsrc_t rs_part = __builtin_amdgcn_make_buffer_rsrc(p.ln_part, 0, (int)(NSEG * mpad * 8), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)(((int64_t)(p.M - 1) * p.ldc + p.N) * 2), 0x00020000);
+    const int rr = tid >> 5, cc = (tid & 31) * 8;          // 16 rows x 32 column octets per pass; 16 passes per tile column
+    const unsigned row_step = (unsigned)(16 * p.ldc * 2);
+    u32x4 xa[16], xb[16];
+    auto load_round = [&](u32x4 (&x)[16], const int tnc) {
+        const unsigned src = (unsigned)((((int64_t)tm * 256 + rr) * p.ldc + tnc * 256 + cc) * 2);     // byte offset into C (< 4 GiB: p8_lnf_ok)
+#pragma unroll
+        for (int ps = 0; ps < 16; ++ps) {
+            const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rs_c, (int)(src + (unsigned)ps * row_step), 0, SC1);
+            static_assert(sizeof(raw) == 16, "four dwords");
+            x[ps] = __builtin_bit_cast(u32x4, raw);
+        }
+    };
+    load_round(xa, 0);
     if (tid < 256) {
         const int64_t row = (int64_t)tm * 256 + tid;
         float s1[NSEG], q[NSEG];
@@ -1324,36 +1337,34 @@ __device__ __forceinline__ void ln_row_block(const GemmNTArgs& p, int tm, char* 
         if (p.ln_mean) p.ln_mean[row] = mean;
         if (p.ln_rstd) p.ln_rstd[row] = rstd;
     }
+    // (phase B's first reads do not depend on the statistics: they were issued above, in front of this barrier)
     __syncthreads();
-    const int rr = tid >> 5, cc = (tid & 31) * 8;          // 16 rows x 32 column octets per pass; 16 passes per tile column
-#pragma unroll 1
-    for (int tnc = 0; tnc < 3; ++tnc) {
+    // Three rounds (tile columns) of 16 passes; round r + 1's sixteen 16-byte reads are in flight while round r is normalised and stored (the first version
+    // waited for each round's reads, then stored, then read again: 80 k cycles per row block, profiles/r06_d_ln_fold_trace.txt)
+    auto process = [&](const u32x4 (&x)[16], const int tnc) {
         const int col = tnc * 256 + cc;
         const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.ln_gamma + col), g1 = *reinterpret_cast<const f32x4*>(p.ln_gamma + col + 4);
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.ln_beta + col), b1 = *reinterpret_cast<const f32x4*>(p.ln_beta + col + 4);
-        const unsigned src = (unsigned)((((int64_t)tm * 256 + rr) * p.ldc + col) * 2);      // byte offset into C (< 4 GiB: p8_lnf_ok)
-        const unsigned row_step = (unsigned)(16 * p.ldc * 2);
         bf16* dst = p.ln_out + ((int64_t)tm * 256 + rr) * p.ld_ln + col;
-        u32x4 x[16];
 #pragma unroll
         for (int ps = 0; ps < 16; ++ps) {
-            const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rs_c, (int)(src + (unsigned)ps * row_step), 0, SC1);
-            static_assert(sizeof(raw) == 16, "four dwords");
-            x[ps] = __builtin_bit_cast(u32x4, raw);
-        }
-#pragma unroll
-        for (int ps = 0; ps < 16; ++ps) {
-            const f32x2 st = stat[ps * 16 + rr];
+            const f32x2 st = stat[ps * 16 + rr];             // (mean, rstd)
+            const float mr = -st[0] * st[1];
             const bf16x8 xv = __builtin_bit_cast(bf16x8, x[ps]);
             bf16x8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float sc = st[1] * (e < 4 ? g0[e & 3] : g1[e & 3]);
-                o[e] = (bf16)((float)xv[e] * sc - st[0] * sc + (e < 4 ? b0[e & 3] : b1[e & 3]));     // y = x s - mean s + beta, as ln_fwd_kernel
+                const float t = __builtin_fmaf((float)xv[e], st[1], mr);                                   // (x - mean) rstd
+                o[e] = (bf16)__builtin_fmaf(t, e < 4 ? g0[e & 3] : g1[e & 3], e < 4 ? b0[e & 3] : b1[e & 3]);
             }
             *reinterpret_cast<bf16x8*>(dst + (int64_t)ps * 16 * p.ld_ln) = o;
         }
-    }
+    };
+    load_round(xb, 1);
+    process(xa, 0);
+    load_round(xa, 2);
+    process(xb, 1);
+    process(xa, 2);
 }
 
 #include "gemm_p8.inc"

@@ -128,11 +128,13 @@ _LN_WS = {}
 
 def _ln_ws(M, N):
     """(pointer, bytes) of the LayerNorm-fold workspace (include/merlot_hip.h, ABI v8: arrival counters zero on entry and left zero + scratch for the
-    segment statistics): one block per (device, stream), grown to the largest M seen."""
-    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
-    need = LIB.query('merlot_gemm_nt_ln_workspace_bytes', M, N)
+    segment statistics)."""
+    # one block per (device, stream, M): the block's layout depends on M (ceil(M / 256) arrival counters, then the scratch), so a block that served another M
+    # holds scratch where this launch expects zeroed counters (the first model-level run did exactly that: LayerNorm passes that never ran, NaN activations)
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream, int(M), int(N))
     buf = _LN_WS.get(key)
-    if buf is None or buf.numel() * 4 < need:
+    if buf is None:
+        need = LIB.query('merlot_gemm_nt_ln_workspace_bytes', M, N)
         buf = _LN_WS[key] = torch.zeros((need + 3) // 4, device='cuda', dtype=torch.int32)
     return buf.data_ptr(), buf.numel() * 4
 

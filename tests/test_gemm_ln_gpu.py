@@ -3,7 +3,7 @@ statistics from every tile's epilogue, the row block normalised by the last of i
 replaces (merlot_gemm_bf16_nt RESIDUAL + merlot_ln_fwd) and against plain torch fp32:
   * h (the GEMM output) BIT-identical to the unfused launch -- the fold must not touch the GEMM's own result, with and without dropout;
   * LN(h): mean / rstd within 2e-6 relative of the stand-alone kernel's (different summation order, same fp32), the bf16 output equal to it up to one bf16
-    unit on a vanishing fraction of elements (<= 1e-3 of them may differ, by <= 1 ulp) and rel-L2 <= 1e-3 against torch's fp32 layer_norm of the same h;
+    unit on a vanishing fraction of elements (<= 1e-3 of them may differ, by <= 2^-7 |y| + 1e-5) and rel-L2 <= 1e-3 against torch's fp32 layer_norm of the same h;
   * every row block normalised exactly once (NaN-prefilled outputs), the arrival counters left zero (a second launch on the same workspace is right),
     rows whose mean is 100x their spread (the cancellation case a sum-of-squares variance would lose);
   * shapes the fused kernel does not take (N != 768, few row blocks) and a ragged last row block go through the composition / the tail launch.
@@ -34,12 +34,11 @@ def plan(M, N, K):
     return LIB.query('merlot_gemm_bf16_nt_ln_plan', M, N, K)
 
 
-def ulp_diff(a, b):
-    """bf16 tensors -> per-element distance in bf16 units (monotone integer encoding)"""
-    def key(t):
-        i = t.view(torch.int16).to(torch.int32)
-        return torch.where(i < 0, -(i & 0x7FFF), i)
-    return (key(a) - key(b)).abs()
+def differs(y0, y1):
+    """-> (fraction of elements that differ at all, max of |y1 - y0| / (2^-7 |y0| + 1e-5)): the second must stay <= 1 -- one bf16 unit where the value has
+    one, a few fp32 roundings where it is near zero (an ulp count would explode there: +1e-5 and -1e-5 are thousands of bf16 codes apart)"""
+    d = (y1.float() - y0.float()).abs()
+    return float((d > 0).float().mean()), float((d / (y0.float().abs() * 2.0 ** -7 + 1e-5)).max())
 
 
 def both(ops, M, K, p, seed, res_scale=1.0, res_shift=0.0, N=768):
@@ -60,13 +59,13 @@ def check(ref, got, gb, frac=1e-3, mean_tol=2e-6, rstd_tol=2e-5):
     assert torch.isfinite(y1.float()).all() and torch.isfinite(m1).all() and torch.isfinite(r1).all()
     assert float(((m1 - m0).abs() / (m0.abs() + 1.0 / r0)).max()) < mean_tol   # mean, relative to the row's scale
     assert float(((r1 - r0).abs() / r0).max()) < rstd_tol
-    d = ulp_diff(y0, y1)
-    assert int(d.max()) <= 1 and float((d > 0).float().mean()) < frac, (int(d.max()), float((d > 0).float().mean()))
+    f, worst = differs(y0, y1)
+    assert worst <= 1.0 and f < frac, (f, worst)
     t = torch.nn.functional.layer_norm(h1.float(), (h1.shape[1],), gamma, beta, 1e-5)
     assert float((y1.float() - t).norm() / t.norm()) < 4e-3                 # bf16 rounding of the output
 
 
-@pytest.mark.parametrize("M,K,p", [(65536, 768, 0.0), (65536, 3072, 0.1), (24576 + 256 * 41, 768, 0.1)])
+@pytest.mark.parametrize("M,K,p", [(65536, 768, 0.0), (65536, 3072, 0.1), (256 * 300, 768, 0.1)])
 def test_fused_layernorm_matches_the_two_launch_composition(ops, M, K, p):
     assert plan(M, 768, K) == 1
     ref, got, gb = both(ops, M, K, p, 11)
@@ -75,8 +74,8 @@ def test_fused_layernorm_matches_the_two_launch_composition(ops, M, K, p):
     ref, got, gb = both(ops, M, K, p, 23)
     check(ref, got, gb)
     from merlot_amd import ops as o
-    for buf in o._LN_WS.values():
-        nblk = (M + 255) // 256
+    for key, buf in o._LN_WS.items():
+        nblk = (key[2] + 255) // 256
         assert int(buf[:nblk].abs().sum()) == 0
 
 
@@ -106,3 +105,44 @@ def test_shapes_outside_the_fused_kernel_and_ragged_tails(ops, M, N, K):
         check(ref, got, gb)
     else:                                                                   # the composition itself
         assert torch.equal(y0, y1) and torch.equal(m0, m1) and torch.equal(r0, r1)
+
+
+def test_model_with_and_without_the_fold_agree():
+    """The whole model, 24 examples x 16 frames of 224^2 (ViT rows 76 032 = 297 row blocks: the fused launch runs in the ViT stack; the joint and text-only
+    stacks at this batch take the composition), 2 + 2 + 2 layers, dropout 0.1 (same counter-hash masks either way): forward values, losses and every gradient
+    with layers.FUSE_LN on against off.  The fold changes LayerNorm outputs by at most one bf16 unit on ~1e-5 of their elements (the statistics are summed in
+    another order) -- rel-L2 <= 2e-3 on hidden states and gradients, losses within 2e-3, everything finite.  Also guards the workspace contract: three stacks
+    with three different row counts alternate within one step (a block that served another M once poisoned the arrival counters)."""
+    import os
+    from merlot_amd import MerlotModel, NeatConfig, ParamStore, layers
+    from merlot_amd.train import synthetic_batch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    config = NeatConfig.from_yaml(os.path.join(root, 'merlot_amd', 'configs', 'pretrain_4seg_224.yaml'))
+    cfg = config.model
+    cfg.update(hidden_dropout_prob=0.1, num_hidden_layers=2, num_vision_transformer_hidden_layers=2, num_lang_transformer_hidden_layers=2)
+    from merlot_amd.lib import LIB
+    assert LIB.query('merlot_gemm_bf16_nt_ln_plan', 24 * 16 * 198, 768, 768) == 1
+    b = synthetic_batch(config, 24, torch.device('cuda', 0), seed=5)
+    out = {}
+    keep = layers.FUSE_LN
+    try:
+        for fuse in (False, True, True):                    # twice with the fold: the second pass reuses every workspace block
+            layers.FUSE_LN = fuse
+            st = ParamStore(cfg, torch.device('cuda', 0), seed=0)
+            st.zero_grad()
+            pm = MerlotModel(cfg, True, False, b['images'], b['input_ids'], mask_input=True, shuffled_idx_img=b['shuffled_idx_img'], params=st,
+                             noise=b['noise'], seed=123)
+            l1, l2, l3 = pm.mask_loss()[0], pm.contrastive_loss()[0], pm.temporal_loss(b['shuffled_idx_img'], b['video_src_ids'])[0]
+            (l1 + l2 + l3).backward()
+            torch.cuda.synchronize()
+            out[fuse] = (pm.encoder_hidden_states['viz'].float().clone(), pm.encoder_hidden_states['lang'].float().clone(), pm.img_trg_h.float().clone(),
+                         torch.stack([l1.detach(), l2.detach(), l3.detach()]).float(), st.grad.clone())
+    finally:
+        layers.FUSE_LN = keep
+    off, on = out[False], out[True]
+    for a, c in zip(off, on):
+        assert torch.isfinite(a).all() and torch.isfinite(c).all()
+    rel = lambda x, y: float((x - y).norm() / (y.norm() + 1e-30))      # noqa: E731
+    assert rel(on[0], off[0]) < 2e-3 and rel(on[1], off[1]) < 2e-3 and rel(on[2], off[2]) < 2e-3, (rel(on[0], off[0]), rel(on[1], off[1]), rel(on[2], off[2]))
+    assert float((on[3] - off[3]).abs().max()) < 2e-3, (on[3], off[3])
+    assert rel(on[4], off[4]) < 5e-3, rel(on[4], off[4])
