@@ -1289,12 +1289,38 @@ struct RingQ : ring::Cfg<1, 4, 4, 2, 32, 3> { static constexpr int OCC = 2; };
 // ---- LNF: the LayerNorm of one finished 256-row block of C (N = 768), run by the workgroup whose tile was the last of the block's three to arrive.
 // The other two tiles' rows were stored by other CUs of the SAME XCD (the LNF tile order keeps a row block inside one XCD), so they sit in this XCD's L2:
 // the reads carry sc1 (agent scope: not served from this CU's vector L1).  lds: 2 KiB for the rows' (mean, rstd).
-__device__ __forceinline__ void ln_row_block(const GemmNTArgs& p, int tm, char* lds, int tid) {
+// The LayerNorm operands of an LNF launch, read from the kernel-argument segment WHERE THEY ARE USED (gemm_p8.inc): as ordinary by-value arguments they were
+// loaded at kernel entry and held in scalar registers through the main loop -- the loop then restored spilled scalars with 21 v_readlane per K-tile, +8.6 % on
+// the K = 3 072 main loop (profiles/r06_e_ln_fold_trace.txt).
+struct LnArgs {
+    bf16* out;
+    int64_t ld;
+    const float* gamma;
+    const float* beta;
+    float* mean;
+    float* rstd;
+    float eps;
+    float* part;
+    unsigned int* ctr;
+};
+__device__ __forceinline__ LnArgs ln_args_from_kernarg() {
+    typedef const GemmNTArgs __attribute__((address_space(4)))* kargp_t;
+    kargp_t kp = (kargp_t)__builtin_amdgcn_kernarg_segment_ptr();      // the kernel's one by-value argument sits at offset 0
+    asm volatile("" : "+s"(kp));                                        // (a fresh scalar load per use: nothing to keep live across the tile loop)
+    LnArgs a;
+    a.out = kp->ln_out; a.ld = kp->ld_ln; a.gamma = kp->ln_gamma; a.beta = kp->ln_beta; a.mean = kp->ln_mean; a.rstd = kp->ln_rstd;
+    a.eps = kp->ln_eps; a.part = kp->ln_part; a.ctr = kp->ln_ctr;
+    return a;
+}
+
+__device__ __forceinline__ void ln_row_block(const GemmNTArgs& p, const LnArgs& ln, int tm, char* lds, int tid_) {
     constexpr int NSEG = 12, H = 768;                      // 64-column segments of a row
+    int tid = tid_;
+    asm volatile("" : "+v"(tid));                          // laundered: the per-lane offsets below are formed here, not hoisted above the tile loop
     constexpr int SC1 = 16;                                // cache policy bit 4 on gfx94x / gfx950: sc1 = agent scope (compiler-visible loads: it places the waits)
     f32x2* stat = reinterpret_cast<f32x2*>(lds);
     const int64_t mpad = (int64_t)p.ntm * 256;
-    const __amdgpu_buffer_rsrc_t rs_part = __builtin_amdgcn_make_buffer_rsrc(p.ln_part, 0, (int)(NSEG * mpad * 8), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_part = __builtin_amdgcn_make_buffer_rsrc(ln.part, 0, (int)(NSEG * mpad * 8), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)(((int64_t)(p.M - 1) * p.ldc + p.N) * 2), 0x00020000);
     const int rr = tid >> 5, cc = (tid & 31) * 8;          // 16 rows x 32 column octets per pass; 16 passes per tile column
     const unsigned row_step = (unsigned)(16 * p.ldc * 2);
@@ -1332,10 +1358,10 @@ __device__ __forceinline__ void ln_row_block(const GemmNTArgs& p, int tm, char* 
             const float d = s1[g] * (1.0f / 64.0f) - mean;
             m2 += q[g] + 64.0f * d * d;
         }
-        const float rstd = rsqrtf(m2 * (1.0f / H) + p.ln_eps);
+        const float rstd = rsqrtf(m2 * (1.0f / H) + ln.eps);
         stat[tid] = f32x2{mean, rstd};
-        if (p.ln_mean) p.ln_mean[row] = mean;
-        if (p.ln_rstd) p.ln_rstd[row] = rstd;
+        if (ln.mean) ln.mean[row] = mean;
+        if (ln.rstd) ln.rstd[row] = rstd;
     }
     // (phase B's first reads do not depend on the statistics: they were issued above, in front of this barrier)
     __syncthreads();
@@ -1343,9 +1369,9 @@ __device__ __forceinline__ void ln_row_block(const GemmNTArgs& p, int tm, char* 
     // waited for each round's reads, then stored, then read again: 80 k cycles per row block, profiles/r06_d_ln_fold_trace.txt)
     auto process = [&](const u32x4 (&x)[16], const int tnc) {
         const int col = tnc * 256 + cc;
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.ln_gamma + col), g1 = *reinterpret_cast<const f32x4*>(p.ln_gamma + col + 4);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.ln_beta + col), b1 = *reinterpret_cast<const f32x4*>(p.ln_beta + col + 4);
-        bf16* dst = p.ln_out + ((int64_t)tm * 256 + rr) * p.ld_ln + col;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(ln.gamma + col), g1 = *reinterpret_cast<const f32x4*>(ln.gamma + col + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(ln.beta + col), b1 = *reinterpret_cast<const f32x4*>(ln.beta + col + 4);
+        bf16* dst = ln.out + ((int64_t)tm * 256 + rr) * ln.ld + col;
 #pragma unroll
         for (int ps = 0; ps < 16; ++ps) {
             const f32x2 st = stat[ps * 16 + rr];             // (mean, rstd)
@@ -1357,7 +1383,7 @@ __device__ __forceinline__ void ln_row_block(const GemmNTArgs& p, int tm, char* 
                 const float t = __builtin_fmaf((float)xv[e], st[1], mr);                                   // (x - mean) rstd
                 o[e] = (bf16)__builtin_fmaf(t, e < 4 ? g0[e & 3] : g1[e & 3], e < 4 ? b0[e & 3] : b1[e & 3]);
             }
-            *reinterpret_cast<bf16x8*>(dst + (int64_t)ps * 16 * p.ld_ln) = o;
+            *reinterpret_cast<bf16x8*>(dst + (int64_t)ps * 16 * ln.ld) = o;
         }
     };
     load_round(xb, 1);

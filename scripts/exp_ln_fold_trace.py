@@ -1,6 +1,7 @@
 """Round 6: per-tile timeline of the LayerNorm-fold launch (experiments build, MERLOT_DBG=512): thread 0 of every workgroup stamps s_memtime at tile start (0),
 K-loop end (1), after the un-stagger barrier (2), after the epilogue issued its stores (3), after their wait (4), after the arrival count came back (6), at tile end (5).
-4 -> 6 = the arrival atomic's round trip + two barriers, paid by EVERY tile; 6 -> 5 = the row block's LayerNorm pass, paid by the last arriver of each row block."""
+4 -> 5 = the closing barrier and, fused, the look at the previous tile's arrival count (issued at the epilogue's start) + the row block's LayerNorm pass where this
+workgroup's tile was the last of the three."""
 import _exp_lib  # noqa: F401
 import os
 import sys
@@ -35,18 +36,14 @@ for name, K in (('proj', 768), ('fc2', 3072)):
         per = min(TT, (T // 256) * 3 // 256)
         use = tr[:, 1:per - 1]
         seg = {'loop': use[..., 1] - use[..., 0], 'unstagger': use[..., 2] - use[..., 1], 'epilogue': use[..., 3] - use[..., 2], 'store wait': use[..., 4] - use[..., 3]}
-        if fused and (use[..., 6] == 0).all():
-            seg['tail (arrival + LayerNorm pass, stamp 6 missing)'] = use[..., 5] - use[..., 4]
-            frac = float('nan')
-        elif fused:
-            seg['arrival (every tile)'] = use[..., 6] - use[..., 4]
-            tail = (use[..., 5] - use[..., 6]).reshape(-1)
-            big = tail > 2000
-            seg['tail, not the last arriver'] = tail[~big]
-            seg['tail, LayerNorm pass'] = tail[big] if big.any() else np.zeros(1)
+        tail = (use[..., 5] - use[..., 4]).reshape(-1)      # closing barrier (+ fused: the previous tile's arrival looked at, its row block normalised if this workgroup closed it)
+        if fused:
+            big = tail > 12000
+            seg['tail, no LayerNorm pass'] = tail[~big]
+            seg['tail, with a LayerNorm pass'] = tail[big] if big.any() else np.zeros(1)
             frac = big.mean()
         else:
-            seg['closing barrier'] = use[..., 5] - use[..., 4]
+            seg['closing barrier'] = tail
             frac = 0.0
         gap = tr[:, 2:per - 1, 0] - tr[:, 1:per - 2, 5]
         print(f'{name} K={K} fused={fused}: ' + ' | '.join(f'{k} {np.mean(v):7.0f}' for k, v in seg.items()) + f' | next-tile gap {gap.mean():5.0f} | tiles that ran the LayerNorm pass {frac:.2f}',
