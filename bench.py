@@ -234,6 +234,7 @@ def main():
                          'and resnet_layers [3, 4, 9]; everything else as the headline (12 + 12 + 12 layers, 16 segments per example in groups of 4)')
     ap.add_argument('--explicit-conv', action='store_true', help='with --resnet-stem: the 3x3 convolutions on explicit im2col matrices (the path of rounds 1-3) instead of the implicit GEMM')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-tn-colsum', action='store_true', help='A/B only: the Q-third bias gradient as a stand-alone column-sum pass over dQKV (rounds 1-5) instead of merlot_gemm_bf16_tn_cs')
     ap.add_argument('--no-ln-fold', action='store_true', help='A/B only: LayerNorm as its own launch behind every residual GEMM (the path of rounds 1-5) instead of merlot_gemm_bf16_nt_ln')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--cpu-baseline-worker', type=int, default=0, help=argparse.SUPPRESS)
@@ -253,9 +254,10 @@ def main():
     from merlot_amd import NeatConfig, ops
     from merlot_amd.parallel import DistContext
     from merlot_amd.train import Trainer, synthetic_batch
-    if args.no_ln_fold:
+    if args.no_ln_fold or args.no_tn_colsum:
         from merlot_amd import layers
-        layers.FUSE_LN = False
+        layers.FUSE_LN = not args.no_ln_fold
+        layers.TN_COLSUM = not args.no_tn_colsum
 
     if args.examples is None:
         args.examples = 48 if args.config == 5 else 56 if args.native_yaml else ((64 if args.explicit_conv else 80) if args.resnet_stem else 128)   # the hybrid stem keeps several times the activations per frame (implicit 3x3 convolutions, 80 / 96 / 112 examples: 3 030 / 3 048 / 3 086 segments/s at 193 / 231 / 269 GB)

@@ -58,6 +58,8 @@ def _fwd_linear(x, lin, fp8, x8=None, row_scale=None, **kw):
 
 # The LayerNorm behind each residual GEMM from that GEMM's own launch (merlot_gemm_bf16_nt_ln, ABI v8).  A module switch so that scripts can A/B it.
 FUSE_LN = True
+# The fused-QKV bias gradient (its Q third) from the weight-gradient launch's own A fragments (merlot_gemm_bf16_tn_cs) instead of a pass over dQKV.
+TN_COLSUM = True
 
 
 def _site_seed(seed, layer, site):
@@ -209,7 +211,11 @@ class TransformerStackFn(torch.autograd.Function):
             else:
                 dqkv = ops.attention_bwd(qkv, ctx_, dctx, lse, B, S, heads, valid, seg=ctx.seg)
             # (round 6: the Q third's column sums come out of the weight-gradient launch below -- its A fragments are dQKV)
-            ops.gemm_tn(dqkv, x1, w.qkv.gw, colsum_a=w.qkv.gb[:D] if exact_rows else w.qkv.gb)
+            if TN_COLSUM:
+                ops.gemm_tn(dqkv, x1, w.qkv.gw, colsum_a=w.qkv.gb[:D] if exact_rows else w.qkv.gb)
+            else:
+                ops.colsum_bf16(dqkv[:, :D] if exact_rows else dqkv, w.qkv.gb[:D] if exact_rows else w.qkv.gb)
+                ops.gemm_tn(dqkv, x1, w.qkv.gw)
             dx1 = ops.gemm_nt(dqkv, w.qkv.wbT)
             if l > 0:
                 dh, db2 = ops.ln_bwd(dx1, h, mean1, rstd1, w.ln1.gamma, w.ln1.ggamma, w.ln1.gbeta, dres=dh_mid,
