@@ -37,6 +37,24 @@ __device__ __forceinline__ void store4(float* p, const float (&v)[4]) {
     *reinterpret_cast<f32x4*>(p) = t;
 }
 
+// 4 elements as they lie in memory (bf16: 8 bytes, f32: 16): the NEXT row's operands wait in this form while the current row is worked on (round 6)
+template <typename T> struct Raw4;
+template <> struct Raw4<bf16> { typedef bf16x4 type; };
+template <> struct Raw4<float> { typedef f32x4 type; };
+template <typename T>
+__device__ __forceinline__ typename Raw4<T>::type load_raw(const T* p) { return *reinterpret_cast<const typename Raw4<T>::type*>(p); }
+template <typename R>
+__device__ __forceinline__ void unpack4(const R& t, float (&v)[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (float)t[e];
+}
+
+// Round 6: both LayerNorm kernels walk the rows with a grid-stride loop of at most 2 048 workgroups (the guide's sizing for memory-bound kernels) and request
+// row r + stride's operands BEFORE they work on row r.  Until round 5 the forward launched one short-lived wave per row (101 376 workgroups at the bench's ViT
+// row count) and the backward asked for the residual gradient only after its two wave reductions: 4.9 / 5.4 TB/s, bound by the chain load -> reduce -> load -> store
+// of one row per wave, not by HBM.  Same-box A/B against the old build (profiles/r06_h_ln_prefetch.txt): forward 266 - 276 -> 256 us at 405 504 rows (4.6 -> 4.87
+// TB/s), backward 561 - 587 -> 541 - 588 us there and 116 -> 102 us at 65 536 rows.  The arithmetic is unchanged; the compiler contracts it into FMAs slightly
+// differently in the new loop (checksums agree to 6 digits, not bit for bit).
 template <int NS, typename TX>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, bf16* __restrict__ y16,
@@ -45,15 +63,24 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
                                                      uint8_t* __restrict__ y8 = nullptr, float* __restrict__ row_scale = nullptr) {
     constexpr int H = NS * 256;
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
+    typename Raw4<TX>::type nxt[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) nxt[i] = load_raw<TX>(x + row * H + i * 256 + lane * 4);
+  for (; row < rows; row += stride) {
     float v[NS][4];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
-        load4<TX>(x + row * H + i * 256 + lane * 4, v[i]);
+        unpack4(nxt[i], v[i]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) s += v[i][e];
+    }
+    if (row + stride < rows) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) nxt[i] = load_raw<TX>(x + (row + stride) * H + i * 256 + lane * 4);
     }
     const float mean = wave_sum(s) * (1.0f / H);
     float ss = 0.f;
@@ -109,6 +136,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
         if (mean_out) mean_out[row] = mean;
         if (rstd_out) rstd_out[row] = rstd;
     }
+  }
 }
 
 // backward: grid-stride over rows; each wave keeps per-lane partial dgamma/dbeta for its 4*NS columns,
@@ -135,15 +163,38 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
 #pragma unroll
         for (int e = 0; e < 4; ++e) dg[i][e] = db[i][e] = dc[i][e] = 0.f;
     }
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
-        const float mu = mean[row], rs = rstd[row];
-        float dyv[NS][4], xh[NS][4];
-        float c1 = 0.f, c2 = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    typename Raw4<TDY>::type ndy[NS];
+    typename Raw4<TX>::type nx[NS];
+    typename Raw4<TR>::type nr[NS];
+    float nmu = 0.f, nrs = 0.f;
+    auto request = [&](const int64_t r) {                // every operand of row r, before the current row's reductions
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
-            float xv[4];
-            load4<TDY>(dy + row * H + i * 256 + lane * 4, dyv[i]);
-            load4<TX>(x + row * H + i * 256 + lane * 4, xv);
+            ndy[i] = load_raw<TDY>(dy + r * H + i * 256 + lane * 4);
+            nx[i] = load_raw<TX>(x + r * H + i * 256 + lane * 4);
+            if (dres) nr[i] = load_raw<TR>(dres + r * H + i * 256 + lane * 4);
+        }
+        nmu = mean[r];
+        nrs = rstd[r];
+    };
+    if (row < rows) request(row);
+    for (; row < rows; row += stride) {
+        const float mu = nmu, rs = nrs;
+        float dyv[NS][4], xh[NS][4], rv[NS][4];
+        float c1 = 0.f, c2 = 0.f;
+        float xvv[NS][4];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            unpack4(ndy[i], dyv[i]);
+            unpack4(nx[i], xvv[i]);
+            if (dres) unpack4(nr[i], rv[i]);
+        }
+        if (row + stride < rows) request(row + stride);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            float (&xv)[4] = xvv[i];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 xh[i][e] = (xv[e] - mu) * rs;
@@ -162,10 +213,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = rs * (dyv[i][e] * g[i][e] - c1 - xh[i][e] * c2);
             if (dres) {
-                float r[4];
-                load4<TR>(dres + row * H + i * 256 + lane * 4, r);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] += r[e];
+                for (int e = 0; e < 4; ++e) o[e] += rv[i][e];
             }
             store4(dx + row * H + i * 256 + lane * 4, o);
             if (dcolsum) {
@@ -206,7 +255,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
 template <int NS>
 int ln_fwd_launch(const void* x, int x_f32, const float* gamma, const float* beta, void* y16, float* y32, float* mean,
                   float* rstd, int64_t rows, float eps, hipStream_t s, void* y8 = nullptr, float* row_scale = nullptr) {
-    const dim3 grid(cdiv(rows, 4)), block(256);
+    int nblk = cdiv(rows, 4);
+    if (nblk > 2048) nblk = 2048;                        // 8 workgroups per CU; the rest of the rows by the grid-stride loop
+    const dim3 grid(nblk), block(256);
     if (x_f32)
         hipLaunchKernelGGL((ln_fwd_kernel<NS, float>), grid, block, 0, s, (const float*)x, gamma, beta, (bf16*)y16, y32,
                            mean, rstd, rows, eps, (uint8_t*)y8, row_scale);

@@ -56,8 +56,12 @@ def _fwd_linear(x, lin, fp8, x8=None, row_scale=None, **kw):
     return ops.gemm_fp8_nt(x8, sx, w8, sw, bias=lin.b, **kw)
 
 
-# The LayerNorm behind each residual GEMM from that GEMM's own launch (merlot_gemm_bf16_nt_ln, ABI v8).  A module switch so that scripts can A/B it.
-FUSE_LN = True
+# The LayerNorm behind each residual GEMM from that GEMM's own launch (merlot_gemm_bf16_nt_ln, ABI v8).  OFF: built, parity-tested (tests/test_gemm_ln_gpu.py) and
+# measured -- the fused launch costs what the stand-alone LayerNorm kernel costs (proj + LN: -43 ... -59 us, fc2 + LN: +53 ... +73 us per launch at the bench's
+# ViT row count; the step 0.2 - 0.4 % SLOWER on three boxes, profiles/r06_g_ln_fold_ab.txt, r06_g_bench_*.json): every tile pays 5 - 9 k cycles of segment
+# statistics in an epilogue during which the matrix pipe idles anyway, and one CU normalises a 256 x 768 block alone in 27 k cycles where the separate kernel
+# spreads it over the chip at 4.9 TB/s.  bench.py --ln-fold switches it on.
+FUSE_LN = False
 # The fused-QKV bias gradient (its Q third) from the weight-gradient launch's own A fragments (merlot_gemm_bf16_tn_cs) instead of a pass over dQKV.
 TN_COLSUM = True
 
