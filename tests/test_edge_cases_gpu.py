@@ -84,9 +84,14 @@ def test_config5_geometry_gradients_against_the_oracle():
     torch.cuda.synchronize()
     gt = st.export_tf_grads()
     rels = {k: rel_l2(gt[k], v.grad) for k, v in w.items() if v.grad is not None and not k.endswith('key_layer/bias')}
-    bad = {k: r for k, r in rels.items() if r > (0.2 if k.startswith('contrastive/') else 0.12)}
+    # round 6: the per-class bounds of tests/test_grad_classes_gpu.py instead of 0.12 / 0.2.  Measured at this problem
+    # (scripts/exp_config5_grad.py, profiles/r06_c_config5_grad.txt): rel-L2 max 2.6e-2 (a LayerNorm gamma), 2.3e-2 behind l2-normalise, class medians
+    # 6e-3 ... 2e-2, | norm ratio - 1 | <= 7.6e-3
+    bad = {k: r for k, r in rels.items() if r > (6e-2 if k.startswith('contrastive/') else 4e-2)}
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
-    assert np.median(list(rels.values())) < 3e-2
+    assert np.median(list(rels.values())) < 2e-2
+    ratios = {k: abs(float(gt[k].float().norm().cpu() / v.grad.norm()) - 1.0) for k, v in w.items() if k in rels and float(v.grad.norm()) > 0}
+    assert max(ratios.values()) < 1.5e-2, sorted(ratios.items(), key=lambda kv: -kv[1])[:5]
 
 
 def test_ragged_batch_odd_sizes_forward_backward():
