@@ -159,7 +159,7 @@ def self_launch(n):
 
 GEMM_SOURCES = ('gemm.hip', 'gemm_p8.inc', 'gemm_ring.h', 'common.h')
 ATTENTION_SOURCES = ('attention.hip', 'attention_res.inc', 'attention_fb.inc', 'attention_pp.inc', 'common.h')
-TRAFFIC_FILE = 'r05_traffic.txt'
+TRAFFIC_FILE = 'r06_traffic.txt'
 
 
 def source_hash(files):
