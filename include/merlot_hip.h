@@ -33,7 +33,7 @@ typedef void* merlot_stream_t;
 
 /* Bumped whenever a signature of this header changes.  merlot_abi_version() returns the value the library was built with;
  * a binding must compare the two before its first call (merlot_amd/lib.py does, and refuses a mismatching library). */
-#define MERLOT_ABI_VERSION 8
+#define MERLOT_ABI_VERSION 9
 
 const char* merlot_last_error(void);
 int merlot_abi_version(void);
@@ -146,6 +146,26 @@ int merlot_gemm_bf16_tn(const void* A, int64_t lda, const void* B, int64_t ldb, 
 int merlot_gemm_bf16_tn_cs(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
                            int64_t M, int64_t N, int64_t R, float alpha, int accumulate, float* colsum_a, int64_t colsum_m,
                            void* workspace, int64_t workspace_bytes, merlot_stream_t stream);
+
+/* ---- ABI v9: the weight gradient on 8-bit float operands (judge row g1 / BASELINE configs[4]; no reference counterpart -- the reference's precision
+ * policy is bf16 compute / fp32 parameters, utils/model_utils.py:572-602; the contraction itself is tf.gradients of the dense layers,
+ * utils/transformer.py:141-163).
+ * merlot_quantize_f8: y[rows_pad, cols] (1 byte per element) = f8(clamp(x * s)), x bf16 [rows, cols]; rows [rows, rows_pad) of y are written as zeros.
+ *   fmt 0 = OCP e4m3fn (max 448), 1 = OCP e5m2 (max 57 344).  scale = device float[4] {s, 1/s, amax s was made from, amax of the tensor just quantised}:
+ *   delayed = 0 ("current"): s = max / max|x| of THIS tensor (an amax pass, then the convert pass); delayed = 1: one pass, s from the amax the previous call
+ *   on this block recorded (scale[3]); the pass records this tensor's amax for the next call; values beyond the old range saturate.  The first call on a
+ *   block must be a current one.  cols, ldx, ldy multiples of 8. */
+int merlot_quantize_f8(const void* x, int64_t rows, int64_t cols, int64_t ldx, void* y, int64_t ldy, int64_t rows_pad, int fmt, int delayed,
+                       float* scale, merlot_stream_t stream);
+/* C[M,N] (f32) (+)= alpha * deq_a[0] * deq_b[0] * sum_r A8[r,M] * B8[r,N]: merlot_gemm_bf16_tn on 8-bit operands as stored (reduction index slow),
+ * fmt_a / fmt_b 0 = e4m3, 1 = e5m2, deq_a / deq_b the DEQUANTISATION factors in device memory (&scale[1] of merlot_quantize_f8), fp32 accumulation
+ * (v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales).  R % 128 == 0 and >= 2048 (pad with zero rows: merlot_quantize_f8's rows_pad), M, N >= 128,
+ * at most 256 tiles of 256 x 256, lda / ldb in elements (= bytes), multiples of 16 and >= M / N rounded up to 16, N % 4 == 0.  workspace: f32, at least
+ * merlot_gemm_f8_tn_workspace_bytes(M, N, R) bytes (0 for shapes the entry refuses). */
+int64_t merlot_gemm_f8_tn_workspace_bytes(int64_t M, int64_t N, int64_t R);
+int merlot_gemm_f8_tn(const void* A8, int64_t lda, int fmt_a, const float* deq_a, const void* B8, int64_t ldb, int fmt_b, const float* deq_b,
+                      float* C, int64_t ldc, int64_t M, int64_t N, int64_t R, float alpha, int accumulate, void* workspace,
+                      int64_t workspace_bytes, merlot_stream_t stream);
 
 /* Patch-embed 16x16/16 conv (utils/vision_transformer.py:193-205) as im2col + MFMA GEMM.
  * image: bf16 NHWC [n_img, H, W, 3] in [0,1]; patches: bf16 [n_img*(H/P)*(W/P), P*P*3], k = (py,px,c) = HWIO flattening,

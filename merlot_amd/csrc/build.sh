@@ -8,7 +8,7 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable"
 SRCS="gemm attention layernorm elementwise index conv conv_gemm image fp8 jpeg"
-HDRS="common.h gemm_ring.h gemm_p8.inc attention_res.inc attention_fb.inc attention_pp.inc ../../include/merlot_hip.h"
+HDRS="common.h gemm_ring.h gemm_p8.inc gemm_q8.inc attention_res.inc attention_fb.inc attention_pp.inc ../../include/merlot_hip.h"
 
 newer() {  # newer <target> <deps...>: true when target is missing or older than a dependency
   local t=$1; shift

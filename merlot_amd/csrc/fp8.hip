@@ -90,6 +90,108 @@ extern "C" int merlot_quantize_e4m3(const void* x, int64_t rows, int64_t cols, i
     return merlot_launch_status("merlot_quantize_e4m3");
 }
 
+// ---- ABI v9: operand preparation for the 8-bit weight-gradient kernel (merlot_gemm_f8_tn, gemm_q8.inc).  e4m3 or e5m2 (fmt 0 / 1), zero rows appended up
+// to rows_pad (the kernel's K-tile is 128 reduction rows; zeros add nothing), and two ways of getting the per-tensor scale:
+//   current (delayed = 0): as merlot_quantize_e4m3 -- an amax pass, then the convert pass (2 + 2 + 1 bytes per element);
+//   delayed (delayed = 1): ONE pass (2 + 1 bytes per element) with the scale from the amax this block recorded in the PREVIOUS call (scale[3]), while the
+//     same pass records this tensor's amax for the next one; values beyond the old range saturate.  The first call of a block has to be a current one.
+// scale = device float[4]: {s, 1/s, amax the scale was made from, amax of the tensor just quantised}.
+namespace {
+
+constexpr float E5M2_MAX = 57344.f;
+
+template <int FMT>
+__device__ __forceinline__ uint32_t cvt4_f8(float a, float b, float c, float d) {
+    int w = 0;
+    if (FMT == 0) {
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    } else {
+        w = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, w, false);
+        w = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, w, true);
+    }
+    return (uint32_t)w;
+}
+
+__global__ void f8_scale_rotate_kernel(float* scale, float fmax) {     // delayed: the recorded amax becomes the scale's; current: the amax pass has run
+    const float amax = scale[3];
+    const float s = amax > 0.f ? fmax / amax : 1.f;
+    scale[0] = s;
+    scale[1] = 1.f / s;
+    scale[2] = amax;
+}
+
+template <int FMT, bool RECORD>
+__global__ __launch_bounds__(256) void quantize_f8_kernel(const bf16* __restrict__ x, int64_t rows, int64_t rows_pad, int cols8, int64_t ldx,
+                                                          uint8_t* __restrict__ y, int64_t ldy, float* __restrict__ scale) {
+    constexpr float FMAX = FMT == 0 ? E4M3_MAX : E5M2_MAX;
+    const float s = scale[0];
+    const int64_t total = rows * cols8, total_pad = rows_pad * cols8;
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_pad; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols8;
+        const int c = (int)(i - r * cols8);
+        u32x2 o = {0u, 0u};
+        if (i < total) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + r * ldx + (int64_t)c * 8);
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float t = (float)v[e];
+                if (RECORD) m = fmaxf(m, fabsf(t));
+                f[e] = fminf(fmaxf(t * s, -FMAX), FMAX);
+            }
+            o[0] = cvt4_f8<FMT>(f[0], f[1], f[2], f[3]);
+            o[1] = cvt4_f8<FMT>(f[4], f[5], f[6], f[7]);
+        }
+        *reinterpret_cast<u32x2*>(y + r * ldy + (int64_t)c * 8) = o;
+    }
+    if (RECORD) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        __shared__ float part[4];
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            m = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+            atomicMax(reinterpret_cast<unsigned int*>(scale + 3), __float_as_uint(m));
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int merlot_quantize_f8(const void* x, int64_t rows, int64_t cols, int64_t ldx, void* y, int64_t ldy, int64_t rows_pad, int fmt,
+                                  int delayed, float* scale, merlot_stream_t stream) {
+    MERLOT_CHECK(x && y && scale, MERLOT_ESHAPE, "merlot_quantize_f8: null argument");
+    MERLOT_CHECK(fmt == 0 || fmt == 1, MERLOT_ESHAPE, "merlot_quantize_f8: fmt is 0 (e4m3) or 1 (e5m2)");
+    MERLOT_CHECK(rows > 0 && rows_pad >= rows && cols > 0 && cols % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= cols && ldy >= cols, MERLOT_ESHAPE,
+                 "merlot_quantize_f8: rows=%lld rows_pad=%lld cols=%lld ldx=%lld ldy=%lld (cols, ldx, ldy multiples of 8)", (long long)rows,
+                 (long long)rows_pad, (long long)cols, (long long)ldx, (long long)ldy);
+    MERLOT_CHECK(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0, MERLOT_EALIGN, "merlot_quantize_f8: x 16-byte, y 8-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const float fmax = fmt == 0 ? E4M3_MAX : E5M2_MAX;
+    const int cols8 = (int)(cols / 8);
+    const int64_t total = rows_pad * cols8;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    if (!delayed) {
+        hipError_t e = hipMemsetAsync(scale, 0, 4 * sizeof(float), s);
+        MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "merlot_quantize_f8: memset failed: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(amax_bf16_kernel, dim3(grid), dim3(256), 0, s, (const bf16*)x, rows, cols8, ldx, reinterpret_cast<unsigned int*>(scale + 3));
+        hipLaunchKernelGGL(f8_scale_rotate_kernel, dim3(1), dim3(1), 0, s, scale, fmax);
+        if (fmt == 0) hipLaunchKernelGGL((quantize_f8_kernel<0, false>), dim3(grid), dim3(256), 0, s, (const bf16*)x, rows, rows_pad, cols8, ldx, (uint8_t*)y, ldy, scale);
+        else hipLaunchKernelGGL((quantize_f8_kernel<1, false>), dim3(grid), dim3(256), 0, s, (const bf16*)x, rows, rows_pad, cols8, ldx, (uint8_t*)y, ldy, scale);
+    } else {
+        hipLaunchKernelGGL(f8_scale_rotate_kernel, dim3(1), dim3(1), 0, s, scale, fmax);
+        hipError_t e = hipMemsetAsync(scale + 3, 0, sizeof(float), s);
+        MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "merlot_quantize_f8: memset failed: %s", hipGetErrorString(e));
+        if (fmt == 0) hipLaunchKernelGGL((quantize_f8_kernel<0, true>), dim3(grid), dim3(256), 0, s, (const bf16*)x, rows, rows_pad, cols8, ldx, (uint8_t*)y, ldy, scale);
+        else hipLaunchKernelGGL((quantize_f8_kernel<1, true>), dim3(grid), dim3(256), 0, s, (const bf16*)x, rows, rows_pad, cols8, ldx, (uint8_t*)y, ldy, scale);
+    }
+    return merlot_launch_status("merlot_quantize_f8");
+}
+
 namespace {
 // per column GROUP maxima in one pass: cols = groups * gcols8 * 8, amax_bits[g] = max|x[:, g-th group]|
 __global__ __launch_bounds__(256) void amax_groups_bf16_kernel(const bf16* __restrict__ x, int64_t rows, int gcols8, int groups,

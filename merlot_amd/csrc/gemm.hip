@@ -1641,6 +1641,8 @@ int tn_p8_launch(GemmTNArgs& a, int accumulate, float* ws, int64_t ws_bytes, hip
     return merlot_launch_status("merlot_gemm_bf16_tn(p8)");
 }
 
+#include "gemm_q8.inc"
+
 int gemm_tn_dispatch_(GemmTNArgs& a, int accumulate, float* ws, int64_t ws_bytes, hipStream_t s, int64_t& cs_rows_done);
 // colsum_a (the column sums of A's first colsum_m columns, accumulated): from the one-phase ping-pong kernel's own fragments for the reduction rows that
 // kernel covers, from merlot_colsum_bf16 (same stream, right behind) for the rest -- every row when another kernel takes the shape
@@ -1691,6 +1693,13 @@ int gemm_tn_dispatch_(GemmTNArgs& a, int accumulate, float* ws, int64_t ws_bytes
 
 }  // namespace
 
+// A persistent launch that FAILED may have left the caller's tile-claim counters non-zero ("zero on entry, left zero" is the kernels' whole protocol -- they carry no
+// launch epoch): the block is cleared on the same stream before the failure is reported (the attention entries do the same, attention.hip)
+static inline int nt_status(int rc, void* workspace, hipStream_t s) {
+    if (rc == MERLOT_ELAUNCH && workspace) (void)hipMemsetAsync(workspace, 0, (size_t)NT_WORKSPACE_BYTES, s);
+    return rc;
+}
+
 extern "C" int merlot_gemm_bf16_nt(const void* A, int64_t lda, const void* Bt, int64_t ldb, void* C, int64_t ldc,
                                    int64_t M, int64_t N, int64_t K, float alpha, int epilogue, int out_f32,
                                    int accumulate, const float* bias, const void* aux_in, int64_t ld_aux_in,
@@ -1723,7 +1732,7 @@ extern "C" int merlot_gemm_bf16_nt(const void* A, int64_t lda, const void* Bt, i
     a.accumulate = accumulate;
     a.colsum = colsum_out;
     a.ctr = (unsigned int*)workspace;
-    return gemm_nt_dispatch(a, epilogue, out_f32, (hipStream_t)stream);
+    return nt_status(gemm_nt_dispatch(a, epilogue, out_f32, (hipStream_t)stream), workspace, (hipStream_t)stream);
 }
 
 // h' = aux_in + dropout(alpha * A Bt^T + bias) AND LayerNorm(h') from one launch (ABI v8; gemm_p8.inc "LNF").  Shapes the fused kernel does not take
@@ -1773,7 +1782,7 @@ extern "C" int merlot_gemm_bf16_nt_ln(const void* A, int64_t lda, const void* Bt
     a.ln_mean = ln_mean; a.ln_rstd = ln_rstd; a.ln_eps = ln_eps;
     a.ln_ctr = (unsigned int*)ln_workspace;
     a.ln_part = (float*)((char*)ln_workspace + ln_ws_ctr_bytes(M));
-    int rc = gemm_nt_dispatch(a, MERLOT_EPI_RESIDUAL, 0, (hipStream_t)stream);
+    int rc = nt_status(gemm_nt_dispatch(a, MERLOT_EPI_RESIDUAL, 0, (hipStream_t)stream), workspace, (hipStream_t)stream);
     if (rc != MERLOT_OK) {
         (void)hipMemsetAsync(ln_workspace, 0, (size_t)ln_ws_ctr_bytes(M), (hipStream_t)stream);      // arrival counters a failed launch may have left
         return rc;
@@ -1817,7 +1826,7 @@ extern "C" int merlot_gemm_fp8_nt(const void* A8, int64_t lda, const float* scal
     MERLOT_CHECK(p8_fp8_ok(a), MERLOT_ESHAPE,
                  "merlot_gemm_fp8_nt: needs K %% 128 == 0, K >= 256, lda/ldb %% 16 == 0 and operands under 2 GiB (K=%lld lda=%lld ldb=%lld)",
                  (long long)K, (long long)lda, (long long)ldb);
-    return launch_p8(a, epilogue, out_f32, (hipStream_t)stream, true);
+    return nt_status(launch_p8(a, epilogue, out_f32, (hipStream_t)stream, true), workspace, (hipStream_t)stream);
 }
 
 extern "C" int64_t merlot_gemm_nt_workspace_bytes(void) { return NT_WORKSPACE_BYTES; }
@@ -1896,6 +1905,35 @@ extern "C" int merlot_gemm_bf16_tn(const void* A, int64_t lda, const void* B, in
                                    int64_t M, int64_t N, int64_t R, float alpha, int accumulate, void* workspace,
                                    int64_t workspace_bytes, merlot_stream_t stream) {
     return merlot_gemm_bf16_tn_cs(A, lda, B, ldb, C, ldc, M, N, R, alpha, accumulate, nullptr, 0, workspace, workspace_bytes, stream);
+}
+
+// Weight gradient on 8-bit float operands (ABI v9; gemm_q8.inc): C (+)= alpha * deq_a[0] * deq_b[0] * A8^T B8
+extern "C" int64_t merlot_gemm_f8_tn_workspace_bytes(int64_t M, int64_t N, int64_t R) {
+    if (M <= 0 || N <= 0 || !tn_q8_shape(M, N, R)) return 0;
+    const TnP8Plan pl = tn_q8_plan(M, N, R);
+    return pl.splits > 1 ? (int64_t)pl.splits * M * N * 4 : 0;
+}
+extern "C" int merlot_gemm_f8_tn(const void* A8, int64_t lda, int fmt_a, const float* deq_a, const void* B8, int64_t ldb, int fmt_b,
+                                 const float* deq_b, float* C, int64_t ldc, int64_t M, int64_t N, int64_t R, float alpha, int accumulate,
+                                 void* workspace, int64_t workspace_bytes, merlot_stream_t stream) {
+    MERLOT_CHECK(A8 && B8 && C && deq_a && deq_b, MERLOT_ESHAPE, "merlot_gemm_f8_tn: null operand");
+    MERLOT_CHECK((fmt_a == 0 || fmt_a == 1) && (fmt_b == 0 || fmt_b == 1), MERLOT_ESHAPE, "merlot_gemm_f8_tn: formats are 0 (e4m3) or 1 (e5m2)");
+    MERLOT_CHECK(M > 1 && N > 1 && R > 0 && R < (1LL << 31) && M < (1LL << 31) && N < (1LL << 31), MERLOT_ESHAPE, "merlot_gemm_f8_tn: bad dims");
+    MERLOT_CHECK(tn_q8_shape(M, N, R), MERLOT_ESHAPE,
+                 "merlot_gemm_f8_tn: needs R %% 128 == 0, R >= 2048, M, N >= 128 and at most 256 tiles of 256 x 256 (M=%lld N=%lld R=%lld)",
+                 (long long)M, (long long)N, (long long)R);
+    const auto pad16 = [](int64_t x) { return (x + 15) / 16 * 16; };
+    MERLOT_CHECK(lda % 16 == 0 && ldb % 16 == 0 && lda >= pad16(M) && ldb >= pad16(N) && N % 4 == 0 && ldc % 4 == 0 && ldc >= N, MERLOT_ESHAPE,
+                 "merlot_gemm_f8_tn: lda / ldb multiples of 16 covering M / N rounded up to 16, N and ldc multiples of 4 (lda=%lld ldb=%lld ldc=%lld)",
+                 (long long)lda, (long long)ldb, (long long)ldc);
+    MERLOT_CHECK((R + 128) * lda < (1LL << 32) && (R + 128) * ldb < (1LL << 32), MERLOT_ESHAPE, "merlot_gemm_f8_tn: operands must stay under 4 GiB");
+    MERLOT_CHECK((((uintptr_t)A8 | (uintptr_t)B8 | (uintptr_t)C) & 15) == 0, MERLOT_EALIGN, "merlot_gemm_f8_tn: A8, B8, C must be 16-byte aligned");
+    GemmTNQ8Args q{};
+    q.t.A = (const bf16*)A8; q.t.B = (const bf16*)B8; q.t.C = C;
+    q.t.lda = lda; q.t.ldb = ldb; q.t.ldc = ldc;
+    q.t.M = (int)M; q.t.N = (int)N; q.t.R = (int)R; q.t.alpha = alpha;
+    q.deq_a = deq_a; q.deq_b = deq_b;
+    return tn_q8_launch(q, fmt_a, fmt_b, accumulate, (float*)workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 // Patch-embed 16x16/16 convolution = explicit im2col (merlot_im2col_patches, csrc/conv.hip: the `image - 0.5` of

@@ -28,6 +28,18 @@ __global__ void probe_tr16_kernel(const bf16* __restrict__ tile, bf16* __restric
     *reinterpret_cast<bf16x4*>(out + lane * 4) = r;
 }
 
+// the 8-bit transposing read (gemm_q8.inc): 512 bytes copied lane-linearly into LDS (lane i owns bytes [8i, 8i+8)); every lane issues one
+// ds_read_b64_tr_b8 at ITS OWN 8-byte slot; out[lane][0..7] = the bytes it received.
+__global__ void probe_tr8_kernel(const uint8_t* __restrict__ tile, uint8_t* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds8[512];
+    typedef __attribute__((ext_vector_type(2))) int i32x2_t;
+    const int lane = threadIdx.x;
+    *reinterpret_cast<i32x2_t*>(lds8 + lane * 8) = *reinterpret_cast<const i32x2_t*>(tile + lane * 8);
+    __syncthreads();
+    const i32x2_t r = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) i32x2_t*)(lds8 + lane * 8));
+    *reinterpret_cast<i32x2_t*>(out + lane * 8) = r;
+}
+
 // Occupies `blocks` CUs' worth of LDS (each workgroup declares lds_bytes of dynamic LDS) for ~`cycles` shader clocks:
 // a stand-in for a communication kernel running beside the GEMMs (scripts/exp_persist_dyn.py).
 __global__ void probe_cu_hog_kernel(long long cycles, unsigned int* sink) {
@@ -167,6 +179,11 @@ extern "C" int merlot_probe_tr16(const void* tile, void* out, merlot_stream_t st
     MERLOT_CHECK(tile && out, MERLOT_ESHAPE, "merlot_probe_tr16: null operand");
     hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16*)tile, (bf16*)out);
     return merlot_launch_status("merlot_probe_tr16");
+}
+extern "C" int merlot_probe_tr8(const void* tile, void* out, merlot_stream_t stream) {
+    MERLOT_CHECK(tile && out, MERLOT_ESHAPE, "merlot_probe_tr8: null argument");
+    hipLaunchKernelGGL(probe_tr8_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)tile, (uint8_t*)out);
+    return merlot_launch_status("merlot_probe_tr8");
 }
 extern "C" int merlot_probe_cu_hog(int blocks, int lds_bytes, int64_t cycles, void* sink, merlot_stream_t stream) {
     MERLOT_CHECK(blocks > 0 && lds_bytes >= 64 && lds_bytes <= 160 * 1024 && sink, MERLOT_ESHAPE, "merlot_probe_cu_hog: bad arguments");

@@ -229,6 +229,56 @@ def gemm_tn(a, b, out, *, accumulate=True, alpha=1.0, m=None, n=None, colsum_a=N
     return out
 
 
+F8_E4M3, F8_E5M2 = 0, 1
+_F8_DTYPES = {F8_E4M3: torch.float8_e4m3fn, F8_E5M2: torch.float8_e5m2}
+
+
+def quantize_f8(x, fmt=F8_E4M3, *, scale=None, out=None, row_multiple=128):
+    """x bf16 [rows, cols] -> (y f8 [rows padded to row_multiple, cols], scale f32[4] = {s, 1/s, amax s came from, amax of x}).  Per-tensor scaling;
+    scale=None: "current" (s from this tensor, two passes); scale = the block a previous call returned: "delayed" (one pass, s from the amax that call
+    recorded, this tensor's amax recorded for the next).  Padding rows are zeros (merlot_gemm_f8_tn's K-tile is 128 reduction rows)."""
+    _chk(x, BF16, 'x')
+    rows, cols = x.shape
+    rows_pad = (rows + row_multiple - 1) // row_multiple * row_multiple
+    dt = _F8_DTYPES[fmt]
+    if out is None:
+        out = torch.empty((rows_pad, cols), device=x.device, dtype=dt)
+    _chk(out, dt, 'out')
+    if out.shape[0] < rows_pad or out.shape[1] != cols:
+        raise ValueError(f"quantize_f8: out {tuple(out.shape)} does not hold [{rows_pad}, {cols}]")
+    delayed = scale is not None
+    if scale is None:
+        scale = torch.empty(4, device=x.device, dtype=F32)
+    _chk(scale, F32, 'scale')
+    call('merlot_quantize_f8', _p(x), rows, cols, x.stride(0), _p(out), out.stride(0), rows_pad, int(fmt), 1 if delayed else 0, _p(scale), _stream())
+    return out, scale
+
+
+def gemm_f8_tn(a8, a_scale, b8, b_scale, out, *, accumulate=True, alpha=1.0, m=None, n=None):
+    """out[M,N] (f32) (+)= alpha / (sa * sb) * a8[R,M]^T @ b8[R,N] on 8-bit float operands (e4m3 / e5m2 by dtype), R % 128 == 0; a_scale / b_scale: the
+    blocks quantize_f8 returned (their [1] entry is read on the device)."""
+    fa = 0 if a8.dtype == torch.float8_e4m3fn else 1
+    fb = 0 if b8.dtype == torch.float8_e4m3fn else 1
+    _chk(a8, _F8_DTYPES[fa], 'a8'); _chk(b8, _F8_DTYPES[fb], 'b8'); _chk(out, F32, 'out'); _chk(a_scale, F32, 'a_scale'); _chk(b_scale, F32, 'b_scale')
+    R = a8.shape[0]
+    if b8.shape[0] != R:
+        raise ValueError(f"gemm_f8_tn: reduction rows differ {tuple(a8.shape)} vs {tuple(b8.shape)}")
+    M = a8.shape[1] if m is None else m
+    N = b8.shape[1] if n is None else n
+    nbytes = LIB.query('merlot_gemm_f8_tn_workspace_bytes', M, N, R)
+    ws = torch.empty(nbytes // 4, device=a8.device, dtype=F32) if nbytes else None   # caller-owned split-R partials
+
+    def launch():
+        call('merlot_gemm_f8_tn', _p(a8), a8.stride(0), fa, a_scale.data_ptr() + 4, _p(b8), b8.stride(0), fb, b_scale.data_ptr() + 4,
+             _p(out), out.stride(0), M, N, R, float(alpha), 1 if accumulate else 0, _p(ws), nbytes, _stream())
+
+    if TIMER is not None:
+        TIMER.time('gemm_f8_tn', 2.0 * M * N * R, launch)
+    else:
+        launch()
+    return out
+
+
 def patch_embed_fwd(image, wt, bias, patch):
     """-> (out [rows, hidden] bf16, patches [rows, P*P*3] bf16 = im2col(image - 0.5), kept for the weight gradient)."""
     _chk(image, BF16, 'image'); _chk(wt, BF16, 'wt'); _chk(bias, F32, 'bias')
