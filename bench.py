@@ -227,6 +227,9 @@ def main():
     ap.add_argument('--bf16', action='store_true', help='with --config 5: keep every GEMM in bf16 (the comparison line)')
     ap.add_argument('--fp8-attn', action='store_true', help='with --config 5: QKV / fc1 / fc2 GEMMs AND the attention forward (Q K^T, P V) on e4m3 operands')
     ap.add_argument('--fp8-fc2', action='store_true', help='with --config 5: also run fc2 on e4m3 operands (its input needs a separate two-pass quantisation)')
+    ap.add_argument('--fp8-bwd', type=str, default=None,
+                    help='8-bit float operands in the BACKWARD (model.fp8_backward; never the headline): a comma-separated list of w1, w2, wqkv, wproj '
+                         '(that weight gradient through merlot_gemm_f8_tn), e4m3 (gradient operands in e4m3 instead of e5m2)')
     ap.add_argument('--resnet-stem', action='store_true',
                     help='NOT the headline config: swap the patch stem for the ResNet-hybrid stem of merlot.yaml:30 (resnet_layers [3, 4, 9])')
     ap.add_argument('--native-yaml', action='store_true',
@@ -311,6 +314,8 @@ def main():
         fp8 = not args.bf16
         config.model.update(image_size=[384, 384], num_chunks_in_group=16, fp8_forward=('all' if args.fp8_attn else True if args.fp8_fc2 else 'ln') if fp8 else False)
         train_gflop = 3.0 * fwd_gflop_per_segment(384, 16)
+    if args.fp8_bwd:
+        config.model['fp8_backward'] = args.fp8_bwd
     if args.native_yaml:
         # model/configs/merlot.yaml:30,36.  SURVEY 8(d): 72.92 GFLOP forward per segment on the patch stem at 192 x 352 (the closed form below
         # gives 72.9); the stem's 10.041 GFLOP per 224^2 frame scale with the pixel count (every convolution is 'SAME' / stride-aligned)
@@ -391,7 +396,7 @@ def main():
                        'num_chunks': config.data['num_chunks'], 'parallelism': f'dp{world}' + (' (all ranks on ONE device over gloo: a plumbing run, not a scaling number)' if args.one_device_gloo else ''), 'grad_reduce': 'sum',
                        'stem': 'resnet-hybrid [3,4,9] (merlot.yaml:30)' if args.resnet_stem else 'patch 16x16 (north_star)',
                        'image_size': list(config.model['image_size']), 'train_gflop_per_segment': train_gflop,
-                       'final_loss': loss},
+                       'final_loss': loss, **({'fp8_backward': args.fp8_bwd} if args.fp8_bwd else {})},
             'model_flops_utilization': value * train_gflop / 1e3 / (world * PEAK_BF16_TFLOPS),
             'forward_only': {'value': world * seg_per_gpu * fwd_steps / fwd_elapsed, 'unit': 'segments/s',
                              'ms_per_pass': 1e3 * fwd_elapsed / fwd_steps, 'passes': fwd_steps,

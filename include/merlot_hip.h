@@ -167,6 +167,23 @@ int merlot_gemm_f8_tn(const void* A8, int64_t lda, int fmt_a, const float* deq_a
                       float* C, int64_t ldc, int64_t M, int64_t N, int64_t R, float alpha, int accumulate, void* workspace,
                       int64_t workspace_bytes, merlot_stream_t stream);
 
+/* The 8-bit copy from the PRODUCING launch instead of a quantising pass (what makes the 8-bit weight gradient pay: profiles/r06_j_f8_tn.txt):
+ * merlot_gemm_bf16_nt with the DGELU epilogue / merlot_gemm_fp8_nt with the GELU epilogue (+ its pre-activation output aux_out) that ALSO write
+ * q8_out[M, N] = f8(clamp(bf16(C) * q8_scale[0])) (q8_fmt 0 = e4m3, 1 = e5m2; the fp8-operand entry: e4m3 only) and max |bf16(C)| into q8_scale[3]
+ * (atomic max).  C may be NULL: the bf16 output is then not stored at all.  DELAYED scaling: q8_scale[0] comes from an earlier step's amax --
+ * merlot_f8_scale_rotate(blocks, n, fmts) on the stream in front of the producers turns every block's recorded amax ([3], if > 0) into its {s, 1/s, amax}
+ * and clears the record; a block's first scale comes from merlot_quantize_f8 (current).  M, N multiples of 256, operands 16-byte aligned, leading
+ * dimensions multiples of 8 (fp8 operands: lda / ldb of 16); other arguments as the base entries. */
+int merlot_f8_scale_rotate(float* blocks, int n, const int32_t* fmts, merlot_stream_t stream);
+int merlot_gemm_bf16_nt_q8(const void* A, int64_t lda, const void* Bt, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                           float alpha, int epilogue, const float* bias, const void* aux_in, int64_t ld_aux_in, float* colsum_out,
+                           void* q8_out, int64_t ld_q8, int q8_fmt, float* q8_scale, void* workspace, int64_t workspace_bytes,
+                           merlot_stream_t stream);
+int merlot_gemm_fp8_nt_q8(const void* A8, int64_t lda, const float* scale_a, const float* row_scale_a, const void* B8t, int64_t ldb,
+                          const float* scale_b, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, float alpha, int epilogue,
+                          const float* bias, void* aux_out, int64_t ld_aux_out, void* q8_out, int64_t ld_q8, int q8_fmt, float* q8_scale,
+                          void* workspace, int64_t workspace_bytes, merlot_stream_t stream);
+
 /* Patch-embed 16x16/16 conv (utils/vision_transformer.py:193-205) as im2col + MFMA GEMM.
  * image: bf16 NHWC [n_img, H, W, 3] in [0,1]; patches: bf16 [n_img*(H/P)*(W/P), P*P*3], k = (py,px,c) = HWIO flattening,
  * value = pixel + shift (the `image - 0.5` of :193 is applied here). */
@@ -194,6 +211,11 @@ int merlot_ln_fwd(const void* x, int x_f32, const float* gamma, const float* bet
  * normalises a row owns all of it).  y_bf16 may be NULL when no consumer needs it. */
 int merlot_ln_fwd_q8(const void* x, int x_f32, const float* gamma, const float* beta, void* y_bf16, void* y_fp8,
                      float* row_scale, float* mean, float* rstd, int64_t rows, int H, float eps, merlot_stream_t stream);
+/* ABI v9: the same with ONE per-tensor factor: y_fp8 = e4m3(clamp(bf16(y) * tscale[0])) -- tscale = the tensor's merlot_quantize_f8 block (delayed scaling:
+ * merlot_f8_scale_rotate in front), max|bf16(y)| of this launch is max-ed into tscale[3].  The copy both the e4m3 forward GEMM (scale_a = &tscale[1]) and the
+ * 8-bit weight gradient (whose reduction index a per-row factor would lie along) read as stored. */
+int merlot_ln_fwd_q8t(const void* x, int x_f32, const float* gamma, const float* beta, void* y_bf16, void* y_fp8, float* tscale,
+                      float* mean, float* rstd, int64_t rows, int H, float eps, merlot_stream_t stream);
 /* dx = LN'(dy) (+ dres) ; dgamma/dbeta (f32 [H]) are ACCUMULATED with atomics.  dy, x, dres, dx each bf16
  * or f32 per flag; dres may be NULL.
  * Optional fused tail for the residual stream (all NULL/0 to disable): dcolsum[H] += column sums of d_branch, where
@@ -204,6 +226,13 @@ int merlot_ln_bwd(const void* dy, int dy_f32, const void* x, int x_f32, const fl
                   const float* gamma, const void* dres, int dres_f32, void* dx, int dx_f32, float* dgamma,
                   float* dbeta, int64_t rows, int H, void* dx_drop, float drop_p, uint64_t drop_seed,
                   float* dcolsum, merlot_stream_t stream);
+/* ABI v9: merlot_ln_bwd that ALSO writes db8[rows, H] = f8(clamp(d_branch * db8_scale[0])) -- the 8-bit float copy (db8_fmt 0 = e4m3, 1 = e5m2) of the branch
+ * gradient as the next kernels read it (bf16-rounded dx, behind the dropout mask when drop_p > 0): the A operand of that sub-layer's 8-bit weight gradient
+ * (merlot_gemm_f8_tn) without a quantising pass.  db8_scale = the tensor's merlot_quantize_f8 block (delayed scaling), max|d_branch| goes to [3]. */
+int merlot_ln_bwd_q8(const void* dy, int dy_f32, const void* x, int x_f32, const float* mean, const float* rstd,
+                     const float* gamma, const void* dres, int dres_f32, void* dx, int dx_f32, float* dgamma,
+                     float* dbeta, int64_t rows, int H, void* dx_drop, float drop_p, uint64_t drop_seed,
+                     float* dcolsum, void* db8, int db8_fmt, float* db8_scale, merlot_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused scaled-dot-product attention (utils/transformer.py:98-127), head_dim = 64.

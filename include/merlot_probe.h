@@ -20,6 +20,8 @@ int merlot_probe_mfma32(const void* a, const void* b, float* d, merlot_stream_t 
 int merlot_probe_tr16(const void* tile, void* out, merlot_stream_t stream);
 /* ds_read_b64_tr_b8: tile = 512 bytes laid lane-linearly into LDS (lane i owns bytes [8i, 8i + 8)), out[lane][0..7] = what lane received from a read at its own slot */
 int merlot_probe_tr8(const void* tile, void* out, merlot_stream_t stream);
+/* out8[i] = v_cvt_pk_fp8_f32(in[i]), out8[n + i] = v_cvt_pk_bf8_f32(in[i]) with NO clamp in front: what the conversions do beyond the formats' ranges */
+int merlot_probe_cvt8(const float* in, void* out8, int n, merlot_stream_t stream);
 /* experiment helper: `blocks` one-wave workgroups that each hold lds_bytes of LDS and spin for ~cycles shader clocks
  * (a stand-in for a communication kernel sharing the GPU with the GEMMs); sink = any 4-byte device buffer. */
 int merlot_probe_cu_hog(int blocks, int lds_bytes, int64_t cycles, void* sink, merlot_stream_t stream);

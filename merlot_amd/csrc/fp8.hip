@@ -113,12 +113,14 @@ __device__ __forceinline__ uint32_t cvt4_f8(float a, float b, float c, float d) 
     return (uint32_t)w;
 }
 
-__global__ void f8_scale_rotate_kernel(float* scale, float fmax) {     // delayed: the recorded amax becomes the scale's; current: the amax pass has run
-    const float amax = scale[3];
-    const float s = amax > 0.f ? fmax / amax : 1.f;
-    scale[0] = s;
-    scale[1] = 1.f / s;
-    scale[2] = amax;
+__global__ void f8_scale_rotate_kernel(float* scale, float fmax, int current) {   // delayed: the recorded amax (if any: merlot_f8_scale_rotate may have consumed
+    const float amax = scale[3];                                                   // it already) becomes the scale's; current: the amax pass has just run
+    if (amax > 0.f || current) {
+        const float s = amax > 0.f ? fmax / amax : 1.f;
+        scale[0] = s;
+        scale[1] = 1.f / s;
+        scale[2] = amax;
+    }
 }
 
 template <int FMT, bool RECORD>
@@ -161,6 +163,30 @@ __global__ __launch_bounds__(256) void quantize_f8_kernel(const bf16* __restrict
 
 }  // namespace
 
+// A producer that writes its own 8-bit copy (merlot_gemm_*_nt_q8, merlot_ln_*_q8t) scales by block[0] and max-es its amax into block[3]: this call, on the
+// stream IN FRONT of the producer, turns the amax the previous step recorded into the step's scale and clears the record -- the delayed-scaling step of
+// merlot_quantize_f8 without the pass.  n blocks of 4 floats, consecutive.
+namespace {
+__global__ void f8_scale_rotate_n_kernel(float* blocks, int n, float fmax_e4m3, float fmax_e5m2, const int* fmts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float* b = blocks + 4 * i;
+    const float amax = b[3];
+    if (amax > 0.f) {                                    // (a block whose producer has not run since the last rotation keeps its scale)
+        const float fm = fmts[i] == 0 ? fmax_e4m3 : fmax_e5m2;
+        b[0] = fm / amax;
+        b[1] = amax / fm;
+        b[2] = amax;
+        b[3] = 0.f;
+    }
+}
+}  // namespace
+extern "C" int merlot_f8_scale_rotate(float* blocks, int n, const int32_t* fmts, merlot_stream_t stream) {
+    MERLOT_CHECK(blocks && fmts && n > 0, MERLOT_ESHAPE, "merlot_f8_scale_rotate: null argument");
+    hipLaunchKernelGGL(f8_scale_rotate_n_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, blocks, n, E4M3_MAX, E5M2_MAX, (const int*)fmts);
+    return merlot_launch_status("merlot_f8_scale_rotate");
+}
+
 extern "C" int merlot_quantize_f8(const void* x, int64_t rows, int64_t cols, int64_t ldx, void* y, int64_t ldy, int64_t rows_pad, int fmt,
                                   int delayed, float* scale, merlot_stream_t stream) {
     MERLOT_CHECK(x && y && scale, MERLOT_ESHAPE, "merlot_quantize_f8: null argument");
@@ -179,11 +205,11 @@ extern "C" int merlot_quantize_f8(const void* x, int64_t rows, int64_t cols, int
         hipError_t e = hipMemsetAsync(scale, 0, 4 * sizeof(float), s);
         MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "merlot_quantize_f8: memset failed: %s", hipGetErrorString(e));
         hipLaunchKernelGGL(amax_bf16_kernel, dim3(grid), dim3(256), 0, s, (const bf16*)x, rows, cols8, ldx, reinterpret_cast<unsigned int*>(scale + 3));
-        hipLaunchKernelGGL(f8_scale_rotate_kernel, dim3(1), dim3(1), 0, s, scale, fmax);
+        hipLaunchKernelGGL(f8_scale_rotate_kernel, dim3(1), dim3(1), 0, s, scale, fmax, 1);
         if (fmt == 0) hipLaunchKernelGGL((quantize_f8_kernel<0, false>), dim3(grid), dim3(256), 0, s, (const bf16*)x, rows, rows_pad, cols8, ldx, (uint8_t*)y, ldy, scale);
         else hipLaunchKernelGGL((quantize_f8_kernel<1, false>), dim3(grid), dim3(256), 0, s, (const bf16*)x, rows, rows_pad, cols8, ldx, (uint8_t*)y, ldy, scale);
     } else {
-        hipLaunchKernelGGL(f8_scale_rotate_kernel, dim3(1), dim3(1), 0, s, scale, fmax);
+        hipLaunchKernelGGL(f8_scale_rotate_kernel, dim3(1), dim3(1), 0, s, scale, fmax, 0);
         hipError_t e = hipMemsetAsync(scale + 3, 0, sizeof(float), s);
         MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "merlot_quantize_f8: memset failed: %s", hipGetErrorString(e));
         if (fmt == 0) hipLaunchKernelGGL((quantize_f8_kernel<0, true>), dim3(grid), dim3(256), 0, s, (const bf16*)x, rows, rows_pad, cols8, ldx, (uint8_t*)y, ldy, scale);

@@ -73,6 +73,12 @@ struct GemmNTArgs {
     float ln_eps;
     float* ln_part;       // caller workspace: [N / 64][ntm * 256] x (sum, M2) of each row's 64-column segments, written by the tile epilogues
     unsigned int* ln_ctr; // caller workspace: [ntm] arrivals per row block, zero on entry, left zero
+    // Round 6: an 8-bit float copy of the (bf16-rounded) output from the SAME epilogue (ping-pong kernel, GELU / DGELU epilogues, interior tiles only:
+    // the host refuses ragged shapes) -- the operand of the 8-bit weight gradient (gemm_q8.inc) without a pass of its own.  q8_out == nullptr: off.
+    uint8_t* q8_out;      // [M, N] bytes: f8(clamp(bf16(C) * q8_scale[0])), format by the kernel's Q8 template value (e4m3 / e5m2)
+    int64_t ld_q8;
+    const float* q8_scale;   // device float[4], merlot_quantize_f8's block: [0] = s (DELAYED: made from the amax an earlier launch recorded)
+    unsigned int* q8_amax;   // &block[3] as bits: max|bf16(C)| of this launch is atomically max-ed into it (one atomic per wave and LAUNCH)
 };
 
 struct GemmTNArgs {
@@ -874,9 +880,11 @@ __device__ __forceinline__ float octet_sum(float v) {
 // sum of squared deviations from the segment's own mean) of the STORED bf16 values in p.ln_part -- the inputs of the row block's LayerNorm, which
 // the last of the block's three tile columns to finish performs (gemm_p8.inc).  Segment statistics combine exactly (Chan et al.), so the variance
 // does not suffer the cancellation of a sum-of-squares formula when a row's mean is large against its spread.
-template <int EPI, bool OUT_F32, int FM = 2, int FN = 4, int PF = 8, bool RS = false, bool FLAG = false, bool LNF = false>
+// Q8 (round 6): 0 = off; bits 0-1: 1 = e4m3, 2 = e5m2 copy of the bf16-rounded output to p.q8_out (scaled by q8_s); bit 2: the bf16 output itself is NOT stored
+// (its only consumers read the 8-bit copy).  q8_amx: this lane's running max|output| (the caller reduces it).
+template <int EPI, bool OUT_F32, int FM = 2, int FN = 4, int PF = 8, bool RS = false, bool FLAG = false, bool LNF = false, int Q8 = 0>
 __device__ __forceinline__ void fast_tile_epilogue(const GemmNTArgs& p, f32x16 (&acc)[FM][FN], char* slab, int m_base,
-                                                   int n_base, int lane) {
+                                                   int n_base, int lane, float q8_s = 1.f, float* q8_amx = nullptr) {
     static_assert(FM * FN == 8, "a wave owns 8 accumulators = 4 slabs of 32 x 64");
     constexpr int NFP = FN / 2;                          // 64-column slabs per 32-row block
     constexpr bool HAS_AUX = (EPI == MERLOT_EPI_RESIDUAL) || (EPI == MERLOT_EPI_DGELU);
@@ -901,6 +909,10 @@ __device__ __forceinline__ void fast_tile_epilogue(const GemmNTArgs& p, f32x16 (
     const bf16* const aux_lane = HAS_AUX ? p.aux_in + lane_row * p.ld_aux_in + (n_base + c0) : nullptr;
     bf16* const auxo_lane = (EPI == MERLOT_EPI_GELU && FLAG) ? p.aux_out + lane_row * p.ld_aux_out + (n_base + c0) : nullptr;
     char* const c_lane = reinterpret_cast<char*>(p.C) + (lane_row * p.ldc + (n_base + c0)) * (OUT_F32 ? 4 : 2);
+    // (one 32-bit lane offset against the uniform base: a 64-bit lane pointer more tipped this epilogue, already at 250 registers beside the 128 accumulators, into
+    // 100 dwords of scratch per lane -- the first version's GELU' launch ran 39 % slower for it, profiles/r06_n_f8_producers.txt)
+    const uint32_t q8_off = Q8 ? (uint32_t)(lane_row * p.ld_q8 + (n_base + c0)) : 0u;
+    float q8_m = 0.f;
     auto aux_addr = [&](int q) {
         const int sl = q >> 2, ps = q & 3;
         return aux_lane + ((int64_t)((sl / NFP) * 32 + ps * 8) * p.ld_aux_in + (sl % NFP) * 64);
@@ -1001,7 +1013,33 @@ __device__ __forceinline__ void fast_tile_epilogue(const GemmNTArgs& p, f32x16 (
                 bf16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-                *reinterpret_cast<bf16x8*>(c_lane + ((int64_t)(fi * 32 + ps * 8) * p.ldc + fp * 64) * 2) = o;
+                if constexpr (!(Q8 & 4)) *reinterpret_cast<bf16x8*>(c_lane + ((int64_t)(fi * 32 + ps * 8) * p.ldc + fp * 64) * 2) = o;
+                if constexpr (Q8 != 0) {
+                    // (the copy is taken from the fp32 results, not from their bf16 rounding: 8 conversions less per pass, and one rounding instead of two;
+                    // max3 / med3 / packed conversions: the epilogue is vector-ALU bound -- the first version of this block, 36 instructions per pass on
+                    // the bf16-rounded values, made the GELU' launch 42 % slower, profiles/r06_m_f8_fuse_kernels.txt)
+                    constexpr float FMAX8 = (Q8 & 3) == 1 ? 448.f : 57344.f;
+                    q8_m = fmaxf(fmaxf(q8_m, fabsf(v[0])), fabsf(v[1]));
+                    q8_m = fmaxf(fmaxf(q8_m, fabsf(v[2])), fabsf(v[3]));
+                    q8_m = fmaxf(fmaxf(q8_m, fabsf(v[4])), fabsf(v[5]));
+                    q8_m = fmaxf(fmaxf(q8_m, fabsf(v[6])), fabsf(v[7]));
+                    float f[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = __builtin_amdgcn_fmed3f(v[e] * q8_s, -FMAX8, FMAX8);
+                    int w0 = 0, w1 = 0;
+                    if constexpr ((Q8 & 3) == 1) {
+                        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w0, false);
+                        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
+                        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], w1, false);
+                        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
+                    } else {
+                        w0 = __builtin_amdgcn_cvt_pk_bf8_f32(f[0], f[1], w0, false);
+                        w0 = __builtin_amdgcn_cvt_pk_bf8_f32(f[2], f[3], w0, true);
+                        w1 = __builtin_amdgcn_cvt_pk_bf8_f32(f[4], f[5], w1, false);
+                        w1 = __builtin_amdgcn_cvt_pk_bf8_f32(f[6], f[7], w1, true);
+                    }
+                    *reinterpret_cast<u32x2*>(p.q8_out + ((int64_t)(fi * 32 + ps * 8) * p.ld_q8 + fp * 64) + q8_off) = u32x2{(uint32_t)w0, (uint32_t)w1};
+                }
                 if (want_cs) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) cacc[fp][e] += (float)o[e];
@@ -1030,6 +1068,7 @@ __device__ __forceinline__ void fast_tile_epilogue(const GemmNTArgs& p, f32x16 (
 #pragma unroll
         for (int fp = 0; fp < NFP; ++fp) colsum_flush(p.colsum, n_base + fp * 64, lane, cacc[fp]);
     }
+    if constexpr (Q8 != 0) *q8_amx = fmaxf(*q8_amx, q8_m);
 }
 
 // Tile enumeration of the persistent ping-pong kernel (gemm_p8.inc).  Row-major order makes a 32-tile XCD band 2-3 tile rows x ALL tile
@@ -1827,6 +1866,66 @@ extern "C" int merlot_gemm_fp8_nt(const void* A8, int64_t lda, const float* scal
                  "merlot_gemm_fp8_nt: needs K %% 128 == 0, K >= 256, lda/ldb %% 16 == 0 and operands under 2 GiB (K=%lld lda=%lld ldb=%lld)",
                  (long long)K, (long long)lda, (long long)ldb);
     return nt_status(launch_p8(a, epilogue, out_f32, (hipStream_t)stream, true), workspace, (hipStream_t)stream);
+}
+
+// ---- ABI v9: the NT GEMMs that ALSO write the 8-bit float copy of their bf16-rounded output (gemm_p8.inc "Q8").  q8_scale = merlot_quantize_f8's block of the
+// output tensor: [0] (s) is read, [3] receives max|output| of this launch (atomic max; the caller zeroes / rotates the block: merlot_f8_scale_rotate).
+static int q8_mode(int q8_fmt, const void* C) { return (q8_fmt == 0 ? 1 : 2) + (C ? 0 : 4); }
+
+extern "C" int merlot_gemm_bf16_nt_q8(const void* A, int64_t lda, const void* Bt, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                                      float alpha, int epilogue, const float* bias, const void* aux_in, int64_t ld_aux_in, float* colsum_out,
+                                      void* q8_out, int64_t ld_q8, int q8_fmt, float* q8_scale, void* workspace, int64_t workspace_bytes,
+                                      merlot_stream_t stream) {
+    MERLOT_CHECK(A && Bt && q8_out && q8_scale && aux_in, MERLOT_ESHAPE, "merlot_gemm_bf16_nt_q8: null operand");
+    MERLOT_CHECK(epilogue == MERLOT_EPI_DGELU, MERLOT_ESHAPE, "merlot_gemm_bf16_nt_q8: the 8-bit copy exists behind the DGELU epilogue only");
+    MERLOT_CHECK(q8_fmt == 0 || q8_fmt == 1, MERLOT_ESHAPE, "merlot_gemm_bf16_nt_q8: q8_fmt is 0 (e4m3) or 1 (e5m2)");
+    MERLOT_CHECK(workspace && workspace_bytes >= NT_WORKSPACE_BYTES && ((uintptr_t)workspace & 3) == 0, MERLOT_ESHAPE,
+                 "merlot_gemm_bf16_nt_q8: needs the caller's zeroed workspace of merlot_gemm_nt_workspace_bytes() bytes");
+    MERLOT_CHECK(M > 0 && N > 0 && K > 0 && M < (1LL << 31) && N < (1LL << 31) && lda % 8 == 0 && ldb % 8 == 0, MERLOT_ESHAPE,
+                 "merlot_gemm_bf16_nt_q8: bad dims M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
+    MERLOT_CHECK(((uintptr_t)A & 15) == 0 && ((uintptr_t)Bt & 15) == 0 && (!colsum_out || ((uintptr_t)colsum_out & 15) == 0), MERLOT_EALIGN,
+                 "merlot_gemm_bf16_nt_q8: A / Bt / colsum_out must be 16-byte aligned");
+    GemmNTArgs a{};
+    a.A = (const bf16*)A; a.B = (const bf16*)Bt; a.C = C;
+    a.lda = lda; a.ldb = ldb; a.ldc = C ? ldc : 0;
+    a.M = (int)M; a.N = (int)N; a.K = (int)K;
+    a.alpha = alpha; a.bias = bias;
+    a.aux_in = (const bf16*)aux_in; a.ld_aux_in = ld_aux_in;
+    a.drop_scale = 1.0f;
+    a.colsum = colsum_out;
+    a.ctr = (unsigned int*)workspace;
+    a.q8_out = (uint8_t*)q8_out; a.ld_q8 = ld_q8; a.q8_scale = q8_scale; a.q8_amax = reinterpret_cast<unsigned int*>(q8_scale + 3);
+    MERLOT_CHECK(p8_q8_ok(a, false), MERLOT_ESHAPE,
+                 "merlot_gemm_bf16_nt_q8: needs M, N multiples of 256, K %% 64 == 0, leading dimensions multiples of 8 and 16-byte aligned operands under 4 GiB "
+                 "(M=%lld N=%lld K=%lld)", (long long)M, (long long)N, (long long)K);
+    return nt_status(launch_p8_q8(a, epilogue, q8_mode(q8_fmt, C), (hipStream_t)stream, false), workspace, (hipStream_t)stream);
+}
+
+extern "C" int merlot_gemm_fp8_nt_q8(const void* A8, int64_t lda, const float* scale_a, const float* row_scale_a, const void* B8t, int64_t ldb,
+                                     const float* scale_b, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, float alpha, int epilogue,
+                                     const float* bias, void* aux_out, int64_t ld_aux_out, void* q8_out, int64_t ld_q8, int q8_fmt, float* q8_scale,
+                                     void* workspace, int64_t workspace_bytes, merlot_stream_t stream) {
+    MERLOT_CHECK(A8 && B8t && q8_out && q8_scale && aux_out && (scale_a || row_scale_a) && scale_b, MERLOT_ESHAPE, "merlot_gemm_fp8_nt_q8: null operand");
+    MERLOT_CHECK(epilogue == MERLOT_EPI_GELU && q8_fmt == 0, MERLOT_ESHAPE,
+                 "merlot_gemm_fp8_nt_q8: the 8-bit copy exists behind the GELU epilogue (with its pre-activation output), as e4m3");
+    MERLOT_CHECK(workspace && workspace_bytes >= NT_WORKSPACE_BYTES && ((uintptr_t)workspace & 3) == 0, MERLOT_ESHAPE,
+                 "merlot_gemm_fp8_nt_q8: needs the caller's zeroed workspace of merlot_gemm_nt_workspace_bytes() bytes");
+    MERLOT_CHECK(M > 0 && N > 0 && K > 0 && M < (1LL << 31) && N < (1LL << 31), MERLOT_ESHAPE, "merlot_gemm_fp8_nt_q8: bad dims");
+    MERLOT_CHECK(((uintptr_t)A8 & 15) == 0 && ((uintptr_t)B8t & 15) == 0, MERLOT_EALIGN, "merlot_gemm_fp8_nt_q8: A8 / B8t must be 16-byte aligned");
+    GemmNTArgs a{};
+    a.A = (const bf16*)A8; a.B = (const bf16*)B8t; a.C = C;
+    a.lda = lda; a.ldb = ldb; a.ldc = C ? ldc : 0;
+    a.M = (int)M; a.N = (int)N; a.K = (int)K;
+    a.alpha = alpha; a.bias = bias;
+    a.scale_a = scale_a; a.scale_b = scale_b; a.row_scale = row_scale_a;
+    a.aux_out = (bf16*)aux_out; a.ld_aux_out = ld_aux_out;
+    a.drop_scale = 1.0f;
+    a.ctr = (unsigned int*)workspace;
+    a.q8_out = (uint8_t*)q8_out; a.ld_q8 = ld_q8; a.q8_scale = q8_scale; a.q8_amax = reinterpret_cast<unsigned int*>(q8_scale + 3);
+    MERLOT_CHECK(p8_q8_ok(a, true), MERLOT_ESHAPE,
+                 "merlot_gemm_fp8_nt_q8: needs M, N multiples of 256, K %% 128 == 0, lda / ldb multiples of 16, the other leading dimensions of 8 and 16-byte "
+                 "aligned operands under 4 GiB (M=%lld N=%lld K=%lld)", (long long)M, (long long)N, (long long)K);
+    return nt_status(launch_p8_q8(a, epilogue, q8_mode(q8_fmt, C), (hipStream_t)stream, true), workspace, (hipStream_t)stream);
 }
 
 extern "C" int64_t merlot_gemm_nt_workspace_bytes(void) { return NT_WORKSPACE_BYTES; }

@@ -60,9 +60,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
                                                      const float* __restrict__ beta, bf16* __restrict__ y16,
                                                      float* __restrict__ y32, float* __restrict__ mean_out,
                                                      float* __restrict__ rstd_out, int64_t rows, float eps,
-                                                     uint8_t* __restrict__ y8 = nullptr, float* __restrict__ row_scale = nullptr) {
+                                                     uint8_t* __restrict__ y8 = nullptr, float* __restrict__ row_scale = nullptr,
+                                                     float* __restrict__ tscale = nullptr) {
     constexpr int H = NS * 256;
     const int lane = threadIdx.x & 63;
+    // tscale (round 6, ABI v9): the e4m3 copy with ONE per-tensor factor tscale[0] (delayed: from an earlier step's amax) instead of per-row ones -- the copy
+    // the 8-bit weight gradient can read as stored (a per-row factor lies along ITS reduction index); max|y| of this launch is max-ed into tscale[3]
+    const float ts = tscale ? tscale[0] : 0.f;
+    float run_amax = 0.f;
     const int64_t stride = (int64_t)gridDim.x * 4;
     int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -117,9 +122,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
     if (y8) {
         // per-ROW e4m3 copy for the fp8 GEMM that consumes this LayerNorm (QKV / fc1): the wave owns the whole row, so the
         // scale costs one wave reduction and the copy one extra byte per element in the pass that is already running
+        float sq;
+        if (tscale) {
+            run_amax = fmaxf(run_amax, amax);
+            sq = ts;
+        } else {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
-        const float sq = amax > 0.f ? 448.f / amax : 1.f;
+            for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+            sq = amax > 0.f ? 448.f / amax : 1.f;
+        }
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
             float f[4];
@@ -130,13 +141,18 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
             w = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w, true);
             *reinterpret_cast<int*>(y8 + row * H + i * 256 + lane * 4) = w;
         }
-        if (lane == 0) row_scale[row] = 1.f / sq;
+        if (lane == 0 && !tscale) row_scale[row] = 1.f / sq;
     }
     if (lane == 0) {
         if (mean_out) mean_out[row] = mean;
         if (rstd_out) rstd_out[row] = rstd;
     }
   }
+    if (tscale) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) run_amax = fmaxf(run_amax, __shfl_xor(run_amax, o, 64));
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(tscale + 3), __float_as_uint(run_amax));
+    }
 }
 
 // backward: grid-stride over rows; each wave keeps per-lane partial dgamma/dbeta for its 4*NS columns,
@@ -152,10 +168,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
                                                      TDX* __restrict__ dx, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, int64_t rows, bf16* __restrict__ dx_drop,
                                                      uint32_t drop_thresh, float drop_scale, uint64_t drop_seed,
-                                                     float* __restrict__ dcolsum) {
+                                                     float* __restrict__ dcolsum, uint8_t* __restrict__ db8 = nullptr, float* __restrict__ db8_scale = nullptr,
+                                                     int db8_fmt = 1) {
     constexpr int H = NS * 256;
     __shared__ float red[3][4][H];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // db8 (round 6, ABI v9): an 8-bit float copy (db8_fmt 0 = e4m3, 1 = e5m2) of the BRANCH gradient as the next kernels read it (bf16-rounded, behind the
+    // dropout mask) with the per-tensor factor db8_scale[0] (delayed) -- the A operand of the sub-layer's 8-bit weight gradient; max|.| goes to db8_scale[3]
+    const float b8s = db8 ? db8_scale[0] : 0.f;
+    const float b8max = db8_fmt == 0 ? 448.f : 57344.f;
+    float b8_amax = 0.f;
     float g[NS][4], dg[NS][4], db[NS][4], dc[NS][4];
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
@@ -231,6 +253,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) dc[i][e] += sizeof(TDX) == 2 ? (float)(bf16)o[e] : o[e];
+                if (db8) {
+                    float f[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = (float)(bf16)o[e];
+                        b8_amax = fmaxf(b8_amax, fabsf(t));
+                        f[e] = fminf(fmaxf(t * b8s, -b8max), b8max);
+                    }
+                    int w = 0;
+                    if (db8_fmt == 0) {
+                        w = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w, false);
+                        w = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w, true);
+                    } else {
+                        w = __builtin_amdgcn_cvt_pk_bf8_f32(f[0], f[1], w, false);
+                        w = __builtin_amdgcn_cvt_pk_bf8_f32(f[2], f[3], w, true);
+                    }
+                    *reinterpret_cast<int*>(db8 + row * H + i * 256 + lane * 4) = w;
+                }
             }
         }
     }
@@ -250,20 +290,25 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
         if (dbeta) atomicAdd(dbeta + c, sb);
         if (dcolsum) atomicAdd(dcolsum + c, red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c]);
     }
+    if (db8) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) b8_amax = fmaxf(b8_amax, __shfl_xor(b8_amax, o, 64));
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(db8_scale + 3), __float_as_uint(b8_amax));
+    }
 }
 
 template <int NS>
 int ln_fwd_launch(const void* x, int x_f32, const float* gamma, const float* beta, void* y16, float* y32, float* mean,
-                  float* rstd, int64_t rows, float eps, hipStream_t s, void* y8 = nullptr, float* row_scale = nullptr) {
+                  float* rstd, int64_t rows, float eps, hipStream_t s, void* y8 = nullptr, float* row_scale = nullptr, float* tscale = nullptr) {
     int nblk = cdiv(rows, 4);
     if (nblk > 2048) nblk = 2048;                        // 8 workgroups per CU; the rest of the rows by the grid-stride loop
     const dim3 grid(nblk), block(256);
     if (x_f32)
         hipLaunchKernelGGL((ln_fwd_kernel<NS, float>), grid, block, 0, s, (const float*)x, gamma, beta, (bf16*)y16, y32,
-                           mean, rstd, rows, eps, (uint8_t*)y8, row_scale);
+                           mean, rstd, rows, eps, (uint8_t*)y8, row_scale, tscale);
     else
         hipLaunchKernelGGL((ln_fwd_kernel<NS, bf16>), grid, block, 0, s, (const bf16*)x, gamma, beta, (bf16*)y16, y32,
-                           mean, rstd, rows, eps, (uint8_t*)y8, row_scale);
+                           mean, rstd, rows, eps, (uint8_t*)y8, row_scale, tscale);
     return merlot_launch_status("merlot_ln_fwd");
 }
 
@@ -275,7 +320,7 @@ int ln_fwd_launch(const void* x, int x_f32, const float* gamma, const float* bet
 template <int NS>
 int ln_bwd_launch(int combo, const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                   const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, void* dx_drop, float drop_p,
-                  uint64_t drop_seed, float* dcolsum, hipStream_t s) {
+                  uint64_t drop_seed, float* dcolsum, hipStream_t s, void* db8 = nullptr, float* db8_scale = nullptr, int db8_fmt = 1) {
     const uint32_t thresh = (dx_drop && drop_p > 0.f) ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
     const float dscale = 1.0f / (1.0f - drop_p);
     int nblk = cdiv(rows, 4);
@@ -284,7 +329,7 @@ int ln_bwd_launch(int combo, const void* dy, const void* x, const float* mean, c
 #define LN_BWD(TDY, TX, TR, TDX)                                                                                      \
     hipLaunchKernelGGL((ln_bwd_kernel<NS, TDY, TX, TR, TDX>), grid, block, 0, s, (const TDY*)dy, (const TX*)x, mean,  \
                        rstd, gamma, (const TR*)dres, (TDX*)dx, dgamma, dbeta, rows, (bf16*)dx_drop, thresh,     \
-                       dscale, drop_seed, dcolsum)
+                       dscale, drop_seed, dcolsum, (uint8_t*)db8, db8_scale, db8_fmt)
     switch (combo) {
         case 0: LN_BWD(bf16, bf16, bf16, bf16); break;
         case 1: LN_BWD(float, float, float, float); break;
@@ -323,6 +368,15 @@ extern "C" int merlot_ln_fwd_q8(const void* x, int x_f32, const float* gamma, co
     LN_DISPATCH_H(H, (ln_fwd_launch<NS>(x, x_f32, gamma, beta, y_bf16, nullptr, mean, rstd, rows, eps, s, y_fp8, row_scale)));
 }
 
+// ABI v9: merlot_ln_fwd_q8 with ONE per-tensor factor (delayed scaling: tscale = merlot_quantize_f8's block of this tensor; [0] is read, max|y| goes to [3])
+extern "C" int merlot_ln_fwd_q8t(const void* x, int x_f32, const float* gamma, const float* beta, void* y_bf16, void* y_fp8,
+                                 float* tscale, float* mean, float* rstd, int64_t rows, int H, float eps, merlot_stream_t stream) {
+    MERLOT_CHECK(x && gamma && beta && y_fp8 && tscale, MERLOT_ESHAPE, "merlot_ln_fwd_q8t: null operand");
+    MERLOT_CHECK(rows > 0, MERLOT_ESHAPE, "merlot_ln_fwd_q8t: rows must be > 0");
+    hipStream_t s = (hipStream_t)stream;
+    LN_DISPATCH_H(H, (ln_fwd_launch<NS>(x, x_f32, gamma, beta, y_bf16, nullptr, mean, rstd, rows, eps, s, y_fp8, nullptr, tscale)));
+}
+
 extern "C" int merlot_ln_bwd(const void* dy, int dy_f32, const void* x, int x_f32, const float* mean, const float* rstd,
                              const float* gamma, const void* dres, int dres_f32, void* dx, int dx_f32, float* dgamma,
                              float* dbeta, int64_t rows, int H, void* dx_drop, float drop_p, uint64_t drop_seed,
@@ -340,4 +394,25 @@ extern "C" int merlot_ln_bwd(const void* dy, int dy_f32, const void* x, int x_f3
     hipStream_t s = (hipStream_t)stream;
     LN_DISPATCH_H(H, (ln_bwd_launch<NS>(combo, dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, rows, dx_drop, drop_p,
                                         drop_seed, dcolsum, s)));
+}
+
+// ABI v9: merlot_ln_bwd that also writes the 8-bit float copy of the branch gradient (see ln_bwd_kernel "db8")
+extern "C" int merlot_ln_bwd_q8(const void* dy, int dy_f32, const void* x, int x_f32, const float* mean, const float* rstd,
+                             const float* gamma, const void* dres, int dres_f32, void* dx, int dx_f32, float* dgamma,
+                             float* dbeta, int64_t rows, int H, void* dx_drop, float drop_p, uint64_t drop_seed,
+                             float* dcolsum, void* db8, int db8_fmt, float* db8_scale, merlot_stream_t stream) {
+    MERLOT_CHECK(db8 && db8_scale && dcolsum && (db8_fmt == 0 || db8_fmt == 1), MERLOT_ESHAPE, "merlot_ln_bwd_q8: the 8-bit copy is of the branch gradient (needs dcolsum), db8_fmt 0 / 1");
+    MERLOT_CHECK(dy && x && mean && rstd && gamma && dx, MERLOT_ESHAPE, "merlot_ln_bwd: null operand");
+    MERLOT_CHECK(drop_p >= 0.f && drop_p < 1.f, MERLOT_ESHAPE, "merlot_ln_bwd: drop_p out of range");
+    MERLOT_CHECK(!(drop_p > 0.f && dx_drop) || dcolsum, MERLOT_ESHAPE, "merlot_ln_bwd: dx_drop needs dcolsum");
+    MERLOT_CHECK(rows > 0, MERLOT_ESHAPE, "merlot_ln_bwd: rows must be > 0");
+    if (!dres) dres_f32 = dx_f32;
+    int combo = -1;
+    if (!dy_f32 && !x_f32 && !dres_f32 && !dx_f32) combo = 0;
+    else if (dy_f32 && x_f32 && dres_f32 && dx_f32) combo = 1;
+    else if (!dy_f32 && x_f32 && dres_f32 && dx_f32) combo = 2;
+    else if (dy_f32 && !x_f32 && !dres_f32 && !dx_f32) combo = 3;
+    hipStream_t s = (hipStream_t)stream;
+    LN_DISPATCH_H(H, (ln_bwd_launch<NS>(combo, dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, rows, dx_drop, drop_p,
+                                        drop_seed, dcolsum, s, db8, db8_scale, db8_fmt)));
 }

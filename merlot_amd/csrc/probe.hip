@@ -40,6 +40,18 @@ __global__ void probe_tr8_kernel(const uint8_t* __restrict__ tile, uint8_t* __re
     *reinterpret_cast<i32x2_t*>(out + lane * 8) = r;
 }
 
+// what v_cvt_pk_fp8_f32 / v_cvt_pk_bf8_f32 do beyond the formats' ranges (saturate? NaN?): out8[i] = e4m3(in[i]), out8[n + i] = e5m2(in[i]), no clamp in front
+__global__ void probe_cvt8_kernel(const float* __restrict__ in, uint8_t* __restrict__ out8, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(in[i], 0.f, w, false);
+    out8[i] = (uint8_t)(w & 0xff);
+    w = 0;
+    w = __builtin_amdgcn_cvt_pk_bf8_f32(in[i], 0.f, w, false);
+    out8[n + i] = (uint8_t)(w & 0xff);
+}
+
 // Occupies `blocks` CUs' worth of LDS (each workgroup declares lds_bytes of dynamic LDS) for ~`cycles` shader clocks:
 // a stand-in for a communication kernel running beside the GEMMs (scripts/exp_persist_dyn.py).
 __global__ void probe_cu_hog_kernel(long long cycles, unsigned int* sink) {
@@ -179,6 +191,11 @@ extern "C" int merlot_probe_tr16(const void* tile, void* out, merlot_stream_t st
     MERLOT_CHECK(tile && out, MERLOT_ESHAPE, "merlot_probe_tr16: null operand");
     hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16*)tile, (bf16*)out);
     return merlot_launch_status("merlot_probe_tr16");
+}
+extern "C" int merlot_probe_cvt8(const float* in, void* out8, int n, merlot_stream_t stream) {
+    MERLOT_CHECK(in && out8 && n > 0, MERLOT_ESHAPE, "merlot_probe_cvt8: bad argument");
+    hipLaunchKernelGGL(probe_cvt8_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, in, (uint8_t*)out8, n);
+    return merlot_launch_status("merlot_probe_cvt8");
 }
 extern "C" int merlot_probe_tr8(const void* tile, void* out, merlot_stream_t stream) {
     MERLOT_CHECK(tile && out, MERLOT_ESHAPE, "merlot_probe_tr8: null argument");

@@ -56,6 +56,100 @@ def _fwd_linear(x, lin, fp8, x8=None, row_scale=None, **kw):
     return ops.gemm_fp8_nt(x8, sx, w8, sw, bias=lin.b, **kw)
 
 
+class F8Scales(object):
+    """Per-tensor scale blocks of the 8-bit backward (BASELINE config #5, `model.fp8_backward`), one per (stack use, layer, tensor) site, kept on the ParamStore
+    across steps in ONE pooled tensor (block = float[4] {s, 1/s, amax s was made from, amax recorded since}).  A site's FIRST step is a calibration: its
+    tensor is produced in bf16 as without the option and quantised by a "current" pass (ops.quantize_f8: amax pass + convert pass) -- from then on
+    the PRODUCING launch writes the 8-bit copy itself with the block's scale and records the tensor's amax (delayed scaling; ops.ln_fwd_q8t,
+    ops.gemm_fp8_nt_q8, ops.gemm_nt_q8, ops.ln_bwd(db8_block=...)), or, without 'fuse', a one-pass quantisation does.  step_begin() (once per model =
+    once per step, in front of the first stack) turns the recorded amaxes into the step's scales -- never between a forward that quantised with a
+    block and the backward that dequantises with it.  refresh(): forget the history (the next step re-calibrates)."""
+    CAP = 2048
+
+    def __init__(self, device):
+        self.pool = torch.zeros((self.CAP, 4), device=device, dtype=F32)
+        self.fmts = torch.zeros(self.CAP, device=device, dtype=torch.int32)
+        self.index = {}
+        self.calibrated = set()
+        self.dirty = False
+
+    def block(self, key, fmt):
+        i = self.index.get(key)
+        if i is None:
+            i = self.index[key] = len(self.index)
+            if i >= self.CAP:
+                raise RuntimeError("F8Scales: more sites than blocks")
+            if fmt != 0:
+                self.fmts[i] = int(fmt)
+        return self.pool[i]
+
+    def ready(self, key):
+        return key in self.calibrated
+
+    def calibrate(self, key, x, fmt, out=None):
+        """the site's calibration step: current scaling into its block -> (x8, block)"""
+        blk = self.block(key, fmt)
+        y, _ = ops.quantize_f8(x, fmt, current_into=blk, out=out)
+        self.calibrated.add(key)
+        self.dirty = True
+        return y, blk
+
+    def quantize(self, key, x, fmt):
+        """the stand-alone pass (no producer writes this tensor's copy): current in the site's first step, delayed after"""
+        if not self.ready(key):
+            return self.calibrate(key, x, fmt)
+        blk = self.block(key, fmt)
+        y, _ = ops.quantize_f8(x, fmt, scale=blk)
+        return y, blk
+
+    def step_begin(self):
+        if self.dirty and self.index:
+            ops.f8_scale_rotate(self.pool, len(self.index), self.fmts)
+            self.dirty = False
+
+    def refresh(self):
+        self.calibrated.clear()
+
+
+def f8_scales(store, create=True):
+    f8 = getattr(store, 'f8_scales', None)
+    if f8 is None and create:
+        f8 = store.f8_scales = F8Scales(store.grad.device)
+    return f8
+
+
+def f8_step_begin(store):
+    """called by the model in front of its first stack (once per step): the amaxes the last step's producers recorded become this step's scales"""
+    f8 = f8_scales(store, create=False)
+    if f8 is not None:
+        f8.step_begin()
+
+
+def _f8_modes(opt):
+    """`model.fp8_backward`: False / None, or a comma-separated list of what runs on 8-bit operands in the backward: w1, w2, wqkv, wproj = that weight
+    gradient through merlot_gemm_f8_tn (gradient operand e5m2, activation operand e4m3; 'e4m3' in the list: gradients in e4m3 too); 'fuse': the 8-bit
+    copies of x1 / x2 (LayerNorm), a (fc1's GELU epilogue), du (the GELU' epilogue) and the branch gradients (LayerNorm backward) come out of the launches
+    that produce those tensors instead of quantising passes (needs fp8_forward and row counts that are multiples of 256; dqkv and the attention output
+    have no such producer and keep their pass); 'noa': with 'fuse' and w2, fc1 does not store its bf16 output at all (fc2 reads the e4m3 copy).  True = 'w1,w2,fuse'."""
+    if not opt:
+        return frozenset()
+    if opt is True:
+        return frozenset(('w1', 'w2', 'fuse'))
+    return frozenset(t.strip() for t in str(opt).split(',') if t.strip())
+
+
+def _wgrad(f8, key, dy, x, gw, gfmt, **kw):
+    """gw[out, in] += dy[T, out]^T x[T, in]: bf16 (f8 None) or on 8-bit copies quantised here (f8 = the stack's F8Scales)."""
+    if f8 is None or dy.shape[0] < 2048:
+        return ops.gemm_tn(dy, x, gw, **kw)
+    dy8, sdy = f8.quantize(key + '/dy', dy, gfmt)
+    x8, sx = f8.quantize(key + '/x', x, ops.F8_E4M3)
+    colsum_a = kw.pop('colsum_a', None)
+    if colsum_a is not None:                            # (the 8-bit kernel does not sum its A operand's columns: the stand-alone pass)
+        ops.colsum_bf16(dy[:, :colsum_a.numel()], colsum_a)
+    return ops.gemm_f8_tn(dy8, sdy, x8, sx, gw, **kw)
+
+
 # The LayerNorm behind each residual GEMM from that GEMM's own launch (merlot_gemm_bf16_nt_ln, ABI v8).  OFF: built, parity-tested (tests/test_gemm_ln_gpu.py) and
 # measured -- the fused launch costs what the stand-alone LayerNorm kernel costs (proj + LN: -43 ... -59 us, fc2 + LN: +53 ... +73 us per launch at the bench's
 # ViT row count; the step 0.2 - 0.4 % SLOWER on three boxes, profiles/r06_g_ln_fold_ab.txt, r06_g_bench_*.json): every tile pays 5 - 9 k cycles of segment
@@ -106,11 +200,37 @@ class TransformerStackFn(torch.autograd.Function):
         # (ops.gemm_nt_ln, ABI v8) -- bf16 path only; the fp8 path's LayerNorm also emits the e4m3 copy and stays a launch of its own
         fuse_ln = FUSE_LN and not fp8 and h.shape[1] % 256 == 0
         nxt = None                                         # (x1, mean1, rstd1) of this layer when the previous layer's fc2 launch produced them
+        # the 8-bit backward (`fp8_backward`): with 'fuse' the forward's producers write the e4m3 copies the weight gradients will read
+        f8m = _f8_modes(opts.get('fp8_bwd')) if need_bwd else frozenset()
+        site = opts.get('f8_site', stack.scope)           # which use of the stack (the joint and the text-only pass share weights, not activations)
+        T = h.shape[0]
+        fuse8 = 'fuse' in f8m and fp8 and T % 256 == 0 and T >= 2048
+        f8 = f8_scales(stack.store) if fuse8 else None
+        f8_x1, f8_x2, f8_a = fuse8 and 'wqkv' in f8m, fuse8 and 'w1' in f8m, fuse8 and 'w2' in f8m
+        no_a = f8_a and 'noa' in f8m
+
+        def ln_q8t(key, hin, ln):
+            """LayerNorm whose e4m3 copy carries ONE per-tensor factor: -> (x8, block, mean, rstd); no bf16 output once the site is calibrated"""
+            if f8.ready(key):
+                _, x8, mean, rstd = ops.ln_fwd_q8t(hin, ln.gamma, ln.beta, f8.block(key, ops.F8_E4M3))
+                f8.dirty = True
+                return x8, f8.block(key, ops.F8_E4M3), mean, rstd
+            x16, _, mean, rstd = ops.ln_fwd(hin, ln.gamma, ln.beta)
+            x8, blk = f8.calibrate(key, x16, ops.F8_E4M3)
+            return x8, blk, mean, rstd
+
         for l in range(nl):
             w = stack.layers[l]
-            if fp8:
+            x1q = sx1 = a8 = sa = None
+            if f8_x1:
+                x1q, sx1, mean1, rstd1 = ln_q8t(f'{site}/{l}/x1', h, w.ln1)
+                x1 = None
+                w8, sw = ops.quantize_e4m3(w.qkv.wb)
+                qkv = ops.gemm_fp8_nt(x1q, sx1, w8, sw, bias=w.qkv.b)
+            elif fp8:
                 x1, x1q, rs1, mean1, rstd1 = ops.ln_fwd_q8(h, w.ln1.gamma, w.ln1.beta)
                 qkv = _fwd_linear(x1, w.qkv, True, x8=x1q, row_scale=rs1)
+                x1q = None
             else:
                 if nxt is not None:
                     x1, mean1, rstd1 = nxt
@@ -147,23 +267,50 @@ class TransformerStackFn(torch.autograd.Function):
             else:
                 h_mid = ops.gemm_nt(ctx_, w.proj.wb, bias=w.proj.b, epilogue=EPI_RESIDUAL, aux_in=h, dropout_p=p,
                                     dropout_seed=_site_seed(seed, l, 0))
-                if fp8:
+                sx2 = None
+                if f8_x2:
+                    x2q, sx2, mean2, rstd2 = ln_q8t(f'{site}/{l}/x2', h_mid, w.ln2)
+                    x2, rs2 = None, None
+                elif fp8:
                     x2, x2q, rs2, mean2, rstd2 = ops.ln_fwd_q8(h_mid, w.ln2.gamma, w.ln2.beta)
                 else:
                     x2, _, mean2, rstd2 = ops.ln_fwd(h_mid, w.ln2.gamma, w.ln2.beta)
                     x2q = rs2 = None
-            u = torch.empty((x2.shape[0], w.fc1.wb.shape[0]), device=h.device, dtype=BF16)
-            a = _fwd_linear(x2, w.fc1, fp8, x8=x2q, row_scale=rs2, epilogue=EPI_GELU, aux_out=u)
+            u = torch.empty((T, w.fc1.wb.shape[0]), device=h.device, dtype=BF16)
+            if f8_a:
+                # fc1 on e4m3 operands whose GELU epilogue ALSO writes the e4m3 copy of a (and, with 'noa', nothing else of it)
+                key = f'{site}/{l}/a'
+                w8, sw = ops.quantize_e4m3(w.fc1.wb)
+                if f8.ready(key):
+                    sa = f8.block(key, ops.F8_E4M3)
+                    a, a8 = ops.gemm_fp8_nt_q8(x2q, sx2, w8, sw, sa, bias=w.fc1.b, aux_out=u, a_row_scale=rs2, keep_bf16=not no_a)
+                    f8.dirty = True
+                else:
+                    a = ops.gemm_fp8_nt(x2q, sx2, w8, sw, bias=w.fc1.b, a_row_scale=rs2, epilogue=EPI_GELU, aux_out=u)
+                    a8, sa = f8.calibrate(key, a, ops.F8_E4M3)
+                    if no_a:
+                        a = None
+            elif f8_x2:
+                w8, sw = ops.quantize_e4m3(w.fc1.wb)
+                a = ops.gemm_fp8_nt(x2q, sx2, w8, sw, bias=w.fc1.b, epilogue=EPI_GELU, aux_out=u)
+            else:
+                a = _fwd_linear(x2, w.fc1, fp8, x8=x2q, row_scale=rs2, epilogue=EPI_GELU, aux_out=u)
+            if not f8_x2:
+                x2q = None
             if fuse_ln:
                 ln_next = stack.layers[l + 1].ln1 if l + 1 < nl else stack.ln_final
                 h_out, xn, meann, rstdn = ops.gemm_nt_ln(a, w.fc2.wb, ln_next.gamma, ln_next.beta, bias=w.fc2.b, aux_in=h_mid, dropout_p=p,
                                                          dropout_seed=_site_seed(seed, l, 1))
                 nxt = (xn, meann, rstdn)
+            elif a8 is not None and (fp8_fc2 or no_a):
+                w8, sw = ops.quantize_e4m3(w.fc2.wb)      # fc2 reads the copy fc1's epilogue wrote: no quantising pass over a
+                h_out = ops.gemm_fp8_nt(a8, sa, w8, sw, bias=w.fc2.b, epilogue=EPI_RESIDUAL, aux_in=h_mid, dropout_p=p,
+                                        dropout_seed=_site_seed(seed, l, 1))
             else:
                 h_out = _fwd_linear(a, w.fc2, fp8_fc2, epilogue=EPI_RESIDUAL, aux_in=h_mid, dropout_p=p,
                                     dropout_seed=_site_seed(seed, l, 1))
             if need_bwd:
-                saved.append((h, mean1, rstd1, x1, qkv, ctx_, lse, h_mid, mean2, rstd2, x2, u, a))
+                saved.append((h, mean1, rstd1, x1, qkv, ctx_, lse, h_mid, mean2, rstd2, x2, u, a, (x1q, sx1, x2q, sx2, a8, sa)))
             h = h_out
         if fuse_ln and nxt is not None:
             y, meanf, rstdf = nxt
@@ -172,6 +319,7 @@ class TransformerStackFn(torch.autograd.Function):
         ctx.stack, ctx.B, ctx.S, ctx.valid, ctx.heads, ctx.p, ctx.seed, ctx.nl = stack, B, S, valid, heads, p, seed, nl
         ctx.seg = seg
         ctx.fp8_attn = fp8_attn
+        ctx.f8m, ctx.f8_site, ctx.fuse8 = f8m, site, fuse8
         ctx.saved = saved
         ctx.final = (h, meanf, rstdf)
         return y
@@ -183,23 +331,71 @@ class TransformerStackFn(torch.autograd.Function):
         hL, meanf, rstdf = ctx.final
         dy = dy.contiguous()
         nl = ctx.nl
+        f8m = ctx.f8m
+        gfmt = ops.F8_E4M3 if 'e4m3' in f8m else ops.F8_E5M2
+        f8 = f8_scales(store) if f8m else None            # the scale history lives on the ParamStore (the StackW objects are per model = per step)
+        site, fuse8 = ctx.f8_site, ctx.fuse8
+
+        def ln_bwd8(key, want8, *a, **kw):
+            """ln_bwd whose branch gradient also comes as an 8-bit copy (from the same launch once the site is calibrated): -> (dx, d_branch, d_branch8, block)"""
+            if not (want8 and fuse8):
+                dx, dbr = ops.ln_bwd(*a, **kw)
+                return dx, dbr, None, None
+            if f8.ready(key):
+                blk = f8.block(key, gfmt)
+                dx, dbr, dbr8 = ops.ln_bwd(*a, db8_block=blk, db8_fmt=gfmt, **kw)
+                f8.dirty = True
+                return dx, dbr, dbr8, blk
+            dx, dbr = ops.ln_bwd(*a, **kw)
+            dbr8, blk = f8.calibrate(key, dbr, gfmt)
+            return dx, dbr, dbr8, blk
+
         # every ln_bwd also emits the branch gradient of the sub-layer BELOW it (dropout mask regenerated from the
         # counter hash) and accumulates that sub-layer's bias gradient -- no separate dropout / column-sum passes.
-        dh, db2 = ops.ln_bwd(dy, hL, meanf, rstdf, stack.ln_final.gamma, stack.ln_final.ggamma, stack.ln_final.gbeta,
-                             branch_bias_grad=stack.layers[nl - 1].fc2.gb, drop_p=p, drop_seed=_site_seed(seed, nl - 1, 1))
+        dh, db2, db2_8, sdb2 = ln_bwd8(f'{site}/{nl - 1}/db2', 'w2' in f8m, dy, hL, meanf, rstdf, stack.ln_final.gamma, stack.ln_final.ggamma,
+                                       stack.ln_final.gbeta, branch_bias_grad=stack.layers[nl - 1].fc2.gb, drop_p=p, drop_seed=_site_seed(seed, nl - 1, 1))
         for l in range(nl - 1, -1, -1):
             w = stack.layers[l]
-            h, mean1, rstd1, x1, qkv, ctx_, lse, h_mid, mean2, rstd2, x2, u, a = ctx.saved[l]
+            h, mean1, rstd1, x1, qkv, ctx_, lse, h_mid, mean2, rstd2, x2, u, a, (x1q, sx1, x2q, sx2, a8, sa) = ctx.saved[l]
             ctx.saved[l] = None
+            big = h.shape[0] >= 2048                      # (merlot_gemm_f8_tn's floor; below it the bf16 kernel)
             # ---- MLP branch: h_out = h_mid + drop(fc2(gelu(fc1(LN2(h_mid)))))          db2 = d(fc2 output)
-            ops.gemm_tn(db2, a, w.fc2.gw)                                       # dW2[H, I]
-            du = ops.gemm_nt(db2, w.fc2.wbT, epilogue=EPI_DGELU, aux_in=u, colsum_out=w.fc1.gb)   # [T, I] + fc1's bias grad
-            ops.gemm_tn(du, x2, w.fc1.gw)                                       # dW1[I, H]
+            if 'w2' in f8m and big and a8 is not None:    # both operands came out of their producers (or this step calibrates them)
+                ops.gemm_f8_tn(db2_8, sdb2, a8, sa, w.fc2.gw)
+            elif 'w2' in f8m and big:
+                _wgrad(f8, f'{site}/{l}/w2', db2, a, w.fc2.gw, gfmt)
+            else:
+                ops.gemm_tn(db2, a, w.fc2.gw)             # dW2[H, I]
+            a = a8 = db2_8 = None
+            du8 = sdu = None
+            if 'w1' in f8m and fuse8:
+                key = f'{site}/{l}/du'
+                if f8.ready(key):
+                    sdu = f8.block(key, gfmt)
+                    du, du8 = ops.gemm_nt_q8(db2, w.fc2.wbT, sdu, gfmt, epilogue=EPI_DGELU, aux_in=u, colsum_out=w.fc1.gb)
+                    f8.dirty = True
+                else:
+                    du = ops.gemm_nt(db2, w.fc2.wbT, epilogue=EPI_DGELU, aux_in=u, colsum_out=w.fc1.gb)
+                    du8, sdu = f8.calibrate(key, du, gfmt)
+            else:
+                du = ops.gemm_nt(db2, w.fc2.wbT, epilogue=EPI_DGELU, aux_in=u, colsum_out=w.fc1.gb)   # [T, I] + fc1's bias grad
+            if du8 is not None and x2q is not None:
+                ops.gemm_f8_tn(du8, sdu, x2q, sx2, w.fc1.gw)
+            elif 'w1' in f8m and big:
+                _wgrad(f8, f'{site}/{l}/w1', du, x2, w.fc1.gw, gfmt)
+            else:
+                ops.gemm_tn(du, x2, w.fc1.gw)             # dW1[I, H]
+            du8 = x2q = None
             dx2 = ops.gemm_nt(du, w.fc1.wbT)
-            dh_mid, db1 = ops.ln_bwd(dx2, h_mid, mean2, rstd2, w.ln2.gamma, w.ln2.ggamma, w.ln2.gbeta, dres=dh,
-                                     branch_bias_grad=w.proj.gb, drop_p=p, drop_seed=_site_seed(seed, l, 0))
+            dh_mid, db1, db1_8, sdb1 = ln_bwd8(f'{site}/{l}/db1', 'wproj' in f8m, dx2, h_mid, mean2, rstd2, w.ln2.gamma, w.ln2.ggamma, w.ln2.gbeta, dres=dh,
+                                               branch_bias_grad=w.proj.gb, drop_p=p, drop_seed=_site_seed(seed, l, 0))
             # ---- attention branch: h_mid = h + drop(proj(attn(qkv(LN1(h)))))             db1 = d(proj output)
-            ops.gemm_tn(db1, ctx_, w.proj.gw)
+            if db1_8 is not None:                          # (the attention output has no producer that writes its copy: one pass)
+                c8, sc8 = f8.quantize(f'{site}/{l}/wproj/x', ctx_, ops.F8_E4M3)
+                ops.gemm_f8_tn(db1_8, sdb1, c8, sc8, w.proj.gw)
+                c8 = db1_8 = None
+            else:
+                _wgrad(f8 if 'wproj' in f8m else None, f'{site}/{l}/wproj', db1, ctx_, w.proj.gw, gfmt)
             # bias gradients of the fused QKV projection without a pass over dQKV [T, 3D]:
             #   V: sum_k dV_k = sum_q dO_q because every softmax row sums to 1 -> the column sums of dO, from the epilogue of the
             #      GEMM that produces it;  K: identically 0 (adding a constant to every key shifts each query's scores by a
@@ -215,16 +411,21 @@ class TransformerStackFn(torch.autograd.Function):
             else:
                 dqkv = ops.attention_bwd(qkv, ctx_, dctx, lse, B, S, heads, valid, seg=ctx.seg)
             # (round 6: the Q third's column sums come out of the weight-gradient launch below -- its A fragments are dQKV)
-            if TN_COLSUM:
-                ops.gemm_tn(dqkv, x1, w.qkv.gw, colsum_a=w.qkv.gb[:D] if exact_rows else w.qkv.gb)
+            cs_q = w.qkv.gb[:D] if exact_rows else w.qkv.gb
+            if 'wqkv' in f8m and big and x1q is not None:  # x1's copy came out of its LayerNorm; dqkv has no such producer: one pass
+                dq8, sdq = f8.quantize(f'{site}/{l}/wqkv/dy', dqkv, gfmt)
+                ops.colsum_bf16(dqkv[:, :cs_q.numel()], cs_q)
+                ops.gemm_f8_tn(dq8, sdq, x1q, sx1, w.qkv.gw)
+                dq8 = x1q = None
+            elif TN_COLSUM:
+                _wgrad(f8 if 'wqkv' in f8m else None, f'{site}/{l}/wqkv', dqkv, x1, w.qkv.gw, gfmt, colsum_a=cs_q)
             else:
-                ops.colsum_bf16(dqkv[:, :D] if exact_rows else dqkv, w.qkv.gb[:D] if exact_rows else w.qkv.gb)
+                ops.colsum_bf16(dqkv[:, :D] if exact_rows else dqkv, cs_q)
                 ops.gemm_tn(dqkv, x1, w.qkv.gw)
             dx1 = ops.gemm_nt(dqkv, w.qkv.wbT)
             if l > 0:
-                dh, db2 = ops.ln_bwd(dx1, h, mean1, rstd1, w.ln1.gamma, w.ln1.ggamma, w.ln1.gbeta, dres=dh_mid,
-                                     branch_bias_grad=stack.layers[l - 1].fc2.gb, drop_p=p,
-                                     drop_seed=_site_seed(seed, l - 1, 1))
+                dh, db2, db2_8, sdb2 = ln_bwd8(f'{site}/{l - 1}/db2', 'w2' in f8m, dx1, h, mean1, rstd1, w.ln1.gamma, w.ln1.ggamma, w.ln1.gbeta, dres=dh_mid,
+                                               branch_bias_grad=stack.layers[l - 1].fc2.gb, drop_p=p, drop_seed=_site_seed(seed, l - 1, 1))
             else:
                 dh = ops.ln_bwd(dx1, h, mean1, rstd1, w.ln1.gamma, w.ln1.ggamma, w.ln1.gbeta, dres=dh_mid)
             store.notify_ready(w.name)

@@ -178,9 +178,10 @@ class MerlotModel(object):
                          N * Sv, H, self._anchor, act_inv=conv_inv)                # vision_transformer.py:229-233
         x = L.layer_norm(x, st.ln(f'{vs}/LayerNorm_ctx_patches_pre_ln'), out_bf16=True)
         vit_p = cfg.get('vit_hidden_dropout_prob', cfg['hidden_dropout_prob']) if is_training else 0.0
+        L.f8_step_begin(st)                               # `fp8_backward`: last step's recorded amaxes become this step's scales (a no-op otherwise)
         hs = L.transformer_stack(x, self._vit, N, Sv, None,
                                  dict(heads=heads, dropout_p=vit_p, seed=self.seed * 4 + 0, num_layers=nl_vit,
-                                      fp8=cfg.get('fp8_forward', False)))
+                                      fp8=cfg.get('fp8_forward', False), fp8_bwd=cfg.get('fp8_backward', False), f8_site='vit'))
         hs3 = hs.view(N, Sv, H)
         sp = cfg['spatial_pool_size']
         h2, w2 = h1 // sp, w1 // sp
@@ -217,7 +218,7 @@ class MerlotModel(object):
         is_valid = torch.cat([p['is_valid'] for p in self.encoder_pieces], 1)
         Sj = self.P + self.L
         opts = dict(heads=heads, dropout_p=self.dropout_prob if is_training else 0.0, seed=self.seed * 4 + 2,
-                    num_layers=cfg['num_hidden_layers'], fp8=cfg.get('fp8_forward', False))
+                    num_layers=cfg['num_hidden_layers'], fp8=cfg.get('fp8_forward', False), fp8_bwd=cfg.get('fp8_backward', False), f8_site='joint')
         if cfg.get('disable_pairwise_lang_attn', False):                          # :160-168, as a segment vector
             opts['seg'] = torch.cat([torch.zeros(self.P, dtype=torch.int32),
                                      1 + torch.arange(self.L, dtype=torch.int32) // self.lang_chunk_length]).to(dev)
@@ -390,7 +391,7 @@ class MerlotModel(object):
                                  dict(heads=cfg['num_attention_heads'],
                                       dropout_p=self.dropout_prob if self.is_training else 0.0, seed=self.seed * 4 + 1,
                                       num_layers=cfg['num_lang_transformer_hidden_layers'], colsum=summ,
-                                      fp8=cfg.get('fp8_forward', False)))
+                                      fp8=cfg.get('fp8_forward', False), fp8_bwd=cfg.get('fp8_backward', False), f8_site='lang'))
         pool = hs.view(self.batch_size * self.num_chunks, self.lang_chunk_length, H)[:, 0].float()   # :372-378
         info = {'_hidden_state_flat': hs, 'hidden_state': hs.view(R, Sl, H), 'attention_summs': summ}
         return pool, info

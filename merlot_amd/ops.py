@@ -233,10 +233,11 @@ F8_E4M3, F8_E5M2 = 0, 1
 _F8_DTYPES = {F8_E4M3: torch.float8_e4m3fn, F8_E5M2: torch.float8_e5m2}
 
 
-def quantize_f8(x, fmt=F8_E4M3, *, scale=None, out=None, row_multiple=128):
+def quantize_f8(x, fmt=F8_E4M3, *, scale=None, out=None, row_multiple=128, current_into=None):
     """x bf16 [rows, cols] -> (y f8 [rows padded to row_multiple, cols], scale f32[4] = {s, 1/s, amax s came from, amax of x}).  Per-tensor scaling;
-    scale=None: "current" (s from this tensor, two passes); scale = the block a previous call returned: "delayed" (one pass, s from the amax that call
-    recorded, this tensor's amax recorded for the next).  Padding rows are zeros (merlot_gemm_f8_tn's K-tile is 128 reduction rows)."""
+    scale=None: "current" (s from this tensor, two passes; current_into: write the block there instead of a fresh tensor); scale = the block a previous
+    call returned: "delayed" (one pass, s from the amax that call recorded, this tensor's amax recorded for the next).  Padding rows are zeros
+    (merlot_gemm_f8_tn's K-tile is 128 reduction rows)."""
     _chk(x, BF16, 'x')
     rows, cols = x.shape
     rows_pad = (rows + row_multiple - 1) // row_multiple * row_multiple
@@ -248,10 +249,73 @@ def quantize_f8(x, fmt=F8_E4M3, *, scale=None, out=None, row_multiple=128):
         raise ValueError(f"quantize_f8: out {tuple(out.shape)} does not hold [{rows_pad}, {cols}]")
     delayed = scale is not None
     if scale is None:
-        scale = torch.empty(4, device=x.device, dtype=F32)
+        scale = current_into if current_into is not None else torch.empty(4, device=x.device, dtype=F32)
     _chk(scale, F32, 'scale')
     call('merlot_quantize_f8', _p(x), rows, cols, x.stride(0), _p(out), out.stride(0), rows_pad, int(fmt), 1 if delayed else 0, _p(scale), _stream())
     return out, scale
+
+
+def f8_scale_rotate(blocks, n, fmts):
+    """blocks f32 [>= n, 4], fmts int32 [>= n]: every block whose producers recorded an amax ([3] > 0) gets {s, 1/s, amax} from it, the record is cleared."""
+    _chk(blocks, F32, 'blocks'); _chk(fmts, torch.int32, 'fmts')
+    call('merlot_f8_scale_rotate', _p(blocks), int(n), _p(fmts), _stream())
+
+
+def ln_fwd_q8t(x, gamma, beta, block, *, out_bf16=False, eps=1e-5):
+    """ln_fwd that also emits the e4m3 copy of its bf16-rounded output scaled by block[0] (per tensor, delayed) and records max|y| in block[3]:
+    -> (y16 or None, y8, mean, rstd)."""
+    assert x.dtype in (BF16, F32) and x.is_contiguous()
+    _chk(gamma, F32, 'gamma'); _chk(beta, F32, 'beta'); _chk(block, F32, 'block')
+    H = x.shape[-1]
+    rows = x.numel() // H
+    y16 = torch.empty(x.shape, device=x.device, dtype=BF16) if out_bf16 else None
+    y8 = torch.empty(x.shape, device=x.device, dtype=FP8)
+    mean = torch.empty(rows, device=x.device, dtype=F32)
+    rstd = torch.empty(rows, device=x.device, dtype=F32)
+    call('merlot_ln_fwd_q8t', _p(x), 1 if x.dtype == F32 else 0, _p(gamma), _p(beta), _p(y16), _p(y8), _p(block), _p(mean), _p(rstd),
+         rows, H, float(eps), _stream())
+    return y16, y8, mean, rstd
+
+
+def gemm_nt_q8(a, bt, block, fmt, *, epilogue, aux_in, bias=None, colsum_out=None, alpha=1.0, keep_bf16=True):
+    """gemm_nt (DGELU epilogue) that also writes the 8-bit float copy of its bf16-rounded output, scaled by block[0]; max|C| -> block[3].
+    -> (C bf16 or None, C8)."""
+    _chk(a, BF16, 'a'); _chk(bt, BF16, 'bt'); _chk(aux_in, BF16, 'aux_in'); _chk(bias, F32, 'bias'); _chk(colsum_out, F32, 'colsum_out'); _chk(block, F32, 'block')
+    M, K = a.shape
+    N = bt.shape[0]
+    out = torch.empty((M, N), device=a.device, dtype=BF16) if keep_bf16 else None
+    out8 = torch.empty((M, N), device=a.device, dtype=_F8_DTYPES[fmt])
+
+    def launch():
+        call('merlot_gemm_bf16_nt_q8', _p(a), a.stride(0), _p(bt), bt.stride(0), _p(out), N, M, N, K, float(alpha), int(epilogue), _p(bias),
+             _p(aux_in), aux_in.stride(0), _p(colsum_out), _p(out8), N, int(fmt), _p(block), *_nt_ws(), _stream())
+
+    if TIMER is not None:
+        TIMER.time('gemm_nt', 2.0 * M * N * K, launch)
+    else:
+        launch()
+    return out, out8
+
+
+def gemm_fp8_nt_q8(a8, a_scale, bt8, b_scale, block, *, bias=None, aux_out, a_row_scale=None, alpha=1.0, keep_bf16=True):
+    """gemm_fp8_nt (GELU epilogue, pre-activation to aux_out) that also writes the e4m3 copy of its bf16-rounded output, scaled by block[0];
+    max|C| -> block[3].  -> (C bf16 or None, C8)."""
+    _chk(a8, FP8, 'a8'); _chk(bt8, FP8, 'bt8'); _chk(aux_out, BF16, 'aux_out'); _chk(bias, F32, 'bias'); _chk(block, F32, 'block')
+    M, K = a8.shape
+    N = bt8.shape[0]
+    out = torch.empty((M, N), device=a8.device, dtype=BF16) if keep_bf16 else None
+    out8 = torch.empty((M, N), device=a8.device, dtype=FP8)
+
+    def launch():
+        call('merlot_gemm_fp8_nt_q8', _p(a8), a8.stride(0), a_scale.data_ptr() + 4 if a_scale is not None else None, _p(a_row_scale),
+             _p(bt8), bt8.stride(0), b_scale.data_ptr() + 4, _p(out), N, M, N, K, float(alpha), int(EPI_GELU), _p(bias),
+             _p(aux_out), aux_out.stride(0), _p(out8), N, 0, _p(block), *_nt_ws(), _stream())
+
+    if TIMER is not None:
+        TIMER.time('gemm_fp8_nt', 2.0 * M * N * K, launch)
+    else:
+        launch()
+    return out, out8
 
 
 def gemm_f8_tn(a8, a_scale, b8, b_scale, out, *, accumulate=True, alpha=1.0, m=None, n=None):
@@ -334,10 +398,11 @@ def ln_fwd_q8(x, gamma, beta, *, out_bf16=True, save_stats=True, eps=1e-5):
 
 
 def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, dres=None, dx_dtype=None, branch_bias_grad=None, drop_p=0.0,
-           drop_seed=0):
+           drop_seed=0, db8_block=None, db8_fmt=F8_E5M2):
     """dx = LN'(dy) (+dres); dgamma/dbeta accumulated in place.  With `branch_bias_grad` (f32 [H]) the kernel also
     accumulates the column sums of d_branch = dropout'(dx) into it and returns (dx, d_branch) (d_branch is dx when
-    drop_p == 0)."""
+    drop_p == 0).  db8_block (f32[4], with branch_bias_grad): also the 8-bit float copy of d_branch, scaled by block[0], max|d_branch| -> block[3];
+    returns (dx, d_branch, d_branch8)."""
     assert dy.is_contiguous() and x.is_contiguous()
     H = x.shape[-1]
     rows = x.numel() // H
@@ -346,10 +411,16 @@ def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, dres=None, dx_dtype=None,
     dx_drop = None
     if branch_bias_grad is not None and drop_p > 0:
         dx_drop = torch.empty(x.shape, device=x.device, dtype=BF16)
-    call('merlot_ln_bwd', _p(dy), 1 if dy.dtype == F32 else 0, _p(x), 1 if x.dtype == F32 else 0, _p(mean), _p(rstd),
-         _p(gamma), _p(dres), 1 if (dres is not None and dres.dtype == F32) else 0, _p(dx), 1 if dx_dtype == F32 else 0,
-         _p(dgamma), _p(dbeta), rows, H, _p(dx_drop), float(drop_p), int(drop_seed) & 0xFFFFFFFFFFFFFFFF,
-         _p(branch_bias_grad), _stream())
+    args = (_p(dy), 1 if dy.dtype == F32 else 0, _p(x), 1 if x.dtype == F32 else 0, _p(mean), _p(rstd),
+            _p(gamma), _p(dres), 1 if (dres is not None and dres.dtype == F32) else 0, _p(dx), 1 if dx_dtype == F32 else 0,
+            _p(dgamma), _p(dbeta), rows, H, _p(dx_drop), float(drop_p), int(drop_seed) & 0xFFFFFFFFFFFFFFFF,
+            _p(branch_bias_grad))
+    if db8_block is not None:
+        _chk(db8_block, F32, 'db8_block')
+        db8 = torch.empty((rows, H), device=x.device, dtype=_F8_DTYPES[db8_fmt])
+        call('merlot_ln_bwd_q8', *args, _p(db8), int(db8_fmt), _p(db8_block), _stream())
+        return dx, (dx_drop if dx_drop is not None else dx), db8
+    call('merlot_ln_bwd', *args, _stream())
     if branch_bias_grad is None:
         return dx
     return dx, (dx_drop if dx_drop is not None else dx)
