@@ -227,9 +227,14 @@ def main():
     ap.add_argument('--bf16', action='store_true', help='with --config 5: keep every GEMM in bf16 (the comparison line)')
     ap.add_argument('--fp8-attn', action='store_true', help='with --config 5: QKV / fc1 / fc2 GEMMs AND the attention forward (Q K^T, P V) on e4m3 operands')
     ap.add_argument('--fp8-fc2', action='store_true', help='with --config 5: also run fc2 on e4m3 operands (its input needs a separate two-pass quantisation)')
+    ap.add_argument('--fp8', action='store_true',
+                    help='NOT the headline (whose dtype is bf16): the headline GEOMETRY (config 2) with the fp8 forward GEMMs of config 5 (QKV / fc1 on e4m3 operands); '
+                         'combine with --fp8-bwd.  Reported with its own metric and dtype strings')
     ap.add_argument('--fp8-bwd', type=str, default=None,
                     help='8-bit float operands in the BACKWARD (model.fp8_backward; never the headline): a comma-separated list of w1, w2, wqkv, wproj '
-                         '(that weight gradient through merlot_gemm_f8_tn), e4m3 (gradient operands in e4m3 instead of e5m2)')
+                         '(that weight gradient through merlot_gemm_f8_tn), e4m3 (gradient operands in e4m3 instead of e5m2), fuse (the copies come out of the '
+                         'launches that produce the tensors), noa (fc1 stores only the e4m3 copy of its output; fc2 reads it), dgrad1 (fc1\'s input gradient on '
+                         'the copy of du).  The configuration that pays: w1,w2,fuse,noa,dgrad1')
     ap.add_argument('--resnet-stem', action='store_true',
                     help='NOT the headline config: swap the patch stem for the ResNet-hybrid stem of merlot.yaml:30 (resnet_layers [3, 4, 9])')
     ap.add_argument('--native-yaml', action='store_true',
@@ -314,6 +319,9 @@ def main():
         fp8 = not args.bf16
         config.model.update(image_size=[384, 384], num_chunks_in_group=16, fp8_forward=('all' if args.fp8_attn else True if args.fp8_fc2 else 'ln') if fp8 else False)
         train_gflop = 3.0 * fwd_gflop_per_segment(384, 16)
+    if args.fp8 and args.config == 2:
+        fp8 = True
+        config.model['fp8_forward'] = 'ln'
     if args.fp8_bwd:
         config.model['fp8_backward'] = args.fp8_bwd
     if args.native_yaml:
@@ -377,12 +385,15 @@ def main():
         value = world * seg_per_gpu * args.steps / elapsed
         res = {
             'metric': 'frame-caption segments/sec/node (4-seg, 192x352 as merlot.yaml ships it, bf16)' if args.native_yaml else
-                      'frame-caption segments/sec/node (4-seg, 224^2, bf16)' if args.config == 2 else
-                      'frame-caption segments/sec/node (16-seg, 384^2, %s)' % (('fp8 QKV/fc1/fc2 GEMMs + attention forward' if args.fp8_attn else 'fp8 QKV/fc1/fc2 forward GEMMs' if args.fp8_fc2 else 'fp8 QKV/fc1 forward GEMMs') if fp8 else 'bf16'),
+                      'frame-caption segments/sec/node (4-seg, 224^2, bf16)' if (args.config == 2 and not fp8) else
+                      ('frame-caption segments/sec/node (4-seg, 224^2, NOT the headline dtype: fp8 QKV/fc1 forward GEMMs' + (' + 8-bit backward (' + args.fp8_bwd + ')' if args.fp8_bwd else '') + ')') if args.config == 2 else
+                      'frame-caption segments/sec/node (16-seg, 384^2, %s)' % ((('fp8 QKV/fc1/fc2 GEMMs + attention forward' if args.fp8_attn else 'fp8 QKV/fc1/fc2 forward GEMMs' if args.fp8_fc2 else 'fp8 QKV/fc1 forward GEMMs') + (' + 8-bit backward (' + args.fp8_bwd + ')' if args.fp8_bwd else '')) if fp8 else 'bf16'),
             'value': value, 'unit': 'segments/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': ('fp8 (e4m3 operands, fp32 accumulate: QKV / fc1%s forward GEMMs; bf16 elsewhere)' % (' / fc2 GEMMs, attention QK^T and PV' if args.fp8_attn else ' / fc2' if args.fp8_fc2 else '')) if fp8 else 'bf16',
+            'dtype': (('fp8 (e4m3 operands, fp32 accumulate: QKV / fc1%s forward GEMMs; ' % (' / fc2 GEMMs, attention QK^T and PV' if args.fp8_attn else ' / fc2' if args.fp8_fc2 else '')) +
+                      (('8-bit backward [' + args.fp8_bwd + ']: weight gradients on e5m2 x e4m3 operands' + (', fc2 forward on the e4m3 copy fc1 wrote' if 'noa' in args.fp8_bwd else '') +
+                        (", fc1's input gradient on the e5m2 copy the GELU' epilogue wrote" if 'dgrad1' in args.fp8_bwd else '') + '; bf16 elsewhere)') if args.fp8_bwd else 'bf16 elsewhere)')) if fp8 else 'bf16',
             'data': 'synthetic',
             'config': {'workload': (('merlot.yaml 4-segment ResNet-hybrid [3,4,9] + ViT-B/16' if args.resnet_stem else
                                      'merlot.yaml 4-segment full ViT-B/16 (patch stem)') + ' + 12-layer joint + 12-layer text-only, '
@@ -390,7 +401,7 @@ def main():
                                     ', 32-token captions, fwd+bwd+DP all-reduce+AdamW, dropout 0.1') if args.config == 2 else
                                    ('BASELINE configs[4]: 16-segment long-video variant, full ViT-B/16 at 384^2 (578 tokens/frame) + '
                                     '12-layer joint over 2832-token groups + 12-layer text-only, fwd+bwd+AdamW, dropout 0.1; '
-                                    + ('fp8 forward GEMMs' if fp8 else 'all-bf16 comparison run')),
+                                    + (('fp8 forward GEMMs' + (' + 8-bit backward' if args.fp8_bwd else '')) if fp8 else 'all-bf16 comparison run')),
                        'baseline_config': args.config,
                        'segments_per_gpu_per_step': seg_per_gpu, 'examples_per_gpu': args.examples,
                        'num_chunks': config.data['num_chunks'], 'parallelism': f'dp{world}' + (' (all ranks on ONE device over gloo: a plumbing run, not a scaling number)' if args.one_device_gloo else ''), 'grad_reduce': 'sum',
@@ -424,6 +435,16 @@ def main():
                                        'achieved': f8 / t8 / 1e12, 'peak': PEAK_FP8_TFLOPS, 'unit': 'TFLOP/s',
                                        'frac': f8 / t8 / 1e12 / PEAK_FP8_TFLOPS, 'launches': n8,
                                        'share_of_step_time': t8 / timed_steps / (elapsed / args.steps)}
+            if 'gemm_f8_tn' in summ:
+                f3, t3, n3 = summ['gemm_f8_tn']
+                res['roofline_f8_wgrad'] = {'bound': 'mfma', 'kernel': 'merlot_gemm_f8_tn = gemm_tn_q8_kernel (ds_read_b64_tr_b8 fragments, v_mfma_scale_f32_32x32x64_f8f6f4) + tn_reduce_kernel',
+                                            'achieved': f3 / t3 / 1e12, 'peak': PEAK_FP8_TFLOPS, 'unit': 'TFLOP/s', 'frac': f3 / t3 / 1e12 / PEAK_FP8_TFLOPS,
+                                            'launches': n3, 'share_of_step_time': t3 / timed_steps / (elapsed / args.steps)}
+                if 'gemm_fp8_nt' in summ:
+                    res['roofline_f8_all'] = {'bound': 'mfma', 'kernel': 'every 8-bit GEMM launch of the step (merlot_gemm_fp8_nt / _q8, merlot_gemm_f8_nt, merlot_gemm_f8_tn)',
+                                              'achieved': (f8 + f3) / (t8 + t3) / 1e12, 'peak': PEAK_FP8_TFLOPS, 'unit': 'TFLOP/s',
+                                              'frac': (f8 + f3) / (t8 + t3) / 1e12 / PEAK_FP8_TFLOPS, 'launches': n8 + n3,
+                                              'share_of_step_time': (t8 + t3) / timed_steps / (elapsed / args.steps)}
             if 'gemm_tn' in summ:
                 f2, t2, n2 = summ['gemm_tn']
                 res['roofline_wgrad'] = {'kernel': 'merlot_gemm_bf16_tn = gemm_tn_p1_kernel (one phase per K-tile; + gemm_tn_ring_kernel for small shapes) + tn_reduce_kernel', 'achieved': f2 / t2 / 1e12, 'unit': 'TFLOP/s',

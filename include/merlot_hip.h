@@ -175,6 +175,12 @@ int merlot_gemm_f8_tn(const void* A8, int64_t lda, int fmt_a, const float* deq_a
  * and clears the record; a block's first scale comes from merlot_quantize_f8 (current).  M, N multiples of 256, operands 16-byte aligned, leading
  * dimensions multiples of 8 (fp8 operands: lda / ldb of 16); other arguments as the base entries. */
 int merlot_f8_scale_rotate(float* blocks, int n, const int32_t* fmts, merlot_stream_t stream);
+/* C[M,N] (bf16) = alpha * scale_a[0] * scale_b[0] * A8[M,K] * B8t[N,K]^T + bias with A8 in e4m3 (fmt_a 0) or e5m2 (fmt_a 1: a gradient tensor -- the input-gradient
+ * GEMM that reads the copy the GELU' epilogue wrote), B8t e4m3; no epilogue option.  Shapes as merlot_gemm_fp8_nt. */
+int merlot_gemm_f8_nt(const void* A8, int64_t lda, int fmt_a, const float* scale_a, const void* B8t, int64_t ldb, const float* scale_b,
+                      void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, float alpha, const float* bias, void* workspace,
+                      int64_t workspace_bytes, merlot_stream_t stream);
+
 int merlot_gemm_bf16_nt_q8(const void* A, int64_t lda, const void* Bt, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                            float alpha, int epilogue, const float* bias, const void* aux_in, int64_t ld_aux_in, float* colsum_out,
                            void* q8_out, int64_t ld_q8, int q8_fmt, float* q8_scale, void* workspace, int64_t workspace_bytes,

@@ -1928,6 +1928,30 @@ extern "C" int merlot_gemm_fp8_nt_q8(const void* A8, int64_t lda, const float* s
     return nt_status(launch_p8_q8(a, epilogue, q8_mode(q8_fmt, C), (hipStream_t)stream, true), workspace, (hipStream_t)stream);
 }
 
+// ABI v9: the plain NT GEMM (no epilogue option, bf16 output) on 8-bit operands whose A may be e5m2 -- the input-gradient GEMM fed by the GELU' epilogue's copy
+extern "C" int merlot_gemm_f8_nt(const void* A8, int64_t lda, int fmt_a, const float* scale_a, const void* B8t, int64_t ldb, const float* scale_b,
+                                 void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, float alpha, const float* bias, void* workspace,
+                                 int64_t workspace_bytes, merlot_stream_t stream) {
+    MERLOT_CHECK(A8 && B8t && C && scale_a && scale_b, MERLOT_ESHAPE, "merlot_gemm_f8_nt: null operand");
+    MERLOT_CHECK(fmt_a == 0 || fmt_a == 1, MERLOT_ESHAPE, "merlot_gemm_f8_nt: fmt_a is 0 (e4m3) or 1 (e5m2)");
+    MERLOT_CHECK(workspace && workspace_bytes >= NT_WORKSPACE_BYTES && ((uintptr_t)workspace & 3) == 0, MERLOT_ESHAPE,
+                 "merlot_gemm_f8_nt: needs the caller's zeroed workspace of merlot_gemm_nt_workspace_bytes() bytes");
+    MERLOT_CHECK(M > 0 && N > 0 && K > 0 && M < (1LL << 31) && N < (1LL << 31), MERLOT_ESHAPE, "merlot_gemm_f8_nt: bad dims");
+    MERLOT_CHECK(((uintptr_t)A8 & 15) == 0 && ((uintptr_t)B8t & 15) == 0, MERLOT_EALIGN, "merlot_gemm_f8_nt: A8 / B8t must be 16-byte aligned");
+    GemmNTArgs a{};
+    a.A = (const bf16*)A8; a.B = (const bf16*)B8t; a.C = C;
+    a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+    a.M = (int)M; a.N = (int)N; a.K = (int)K;
+    a.alpha = alpha; a.bias = bias;
+    a.scale_a = scale_a; a.scale_b = scale_b;
+    a.drop_scale = 1.0f;
+    a.ctr = (unsigned int*)workspace;
+    MERLOT_CHECK(p8_fp8_ok(a), MERLOT_ESHAPE, "merlot_gemm_f8_nt: needs K %% 128 == 0, K >= 256, lda / ldb %% 16 == 0 and operands under 4 GiB");
+    const int rc = fmt_a == 0 ? launch_p8_two<MERLOT_EPI_NONE, false, true, true>(a, (hipStream_t)stream)
+                              : launch_p8_two<MERLOT_EPI_NONE, false, true, true, false, 0, 1>(a, (hipStream_t)stream);
+    return nt_status(rc, workspace, (hipStream_t)stream);
+}
+
 extern "C" int64_t merlot_gemm_nt_workspace_bytes(void) { return NT_WORKSPACE_BYTES; }
 
 extern "C" int merlot_softmax_ce(const float* logits, int64_t ld, const int32_t* labels, float* loss, int32_t* argmax,

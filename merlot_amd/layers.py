@@ -130,7 +130,8 @@ def _f8_modes(opt):
     gradient through merlot_gemm_f8_tn (gradient operand e5m2, activation operand e4m3; 'e4m3' in the list: gradients in e4m3 too); 'fuse': the 8-bit
     copies of x1 / x2 (LayerNorm), a (fc1's GELU epilogue), du (the GELU' epilogue) and the branch gradients (LayerNorm backward) come out of the launches
     that produce those tensors instead of quantising passes (needs fp8_forward and row counts that are multiples of 256; dqkv and the attention output
-    have no such producer and keep their pass); 'noa': with 'fuse' and w2, fc1 does not store its bf16 output at all (fc2 reads the e4m3 copy).  True = 'w1,w2,fuse'."""
+    have no such producer and keep their pass); 'noa': with 'fuse' and w2, fc1 does not store its bf16 output at all (fc2 reads the e4m3 copy); 'dgrad1': with 'fuse' and w1, fc1's input-gradient GEMM
+    (K = 3 072) reads du's 8-bit copy as well and the GELU' epilogue does not store du in bf16 at all.  True = 'w1,w2,fuse'."""
     if not opt:
         return frozenset()
     if opt is True:
@@ -221,7 +222,7 @@ class TransformerStackFn(torch.autograd.Function):
 
         for l in range(nl):
             w = stack.layers[l]
-            x1q = sx1 = a8 = sa = None
+            x1q = sx1 = sx2 = a8 = sa = None
             if f8_x1:
                 x1q, sx1, mean1, rstd1 = ln_q8t(f'{site}/{l}/x1', h, w.ln1)
                 x1 = None
@@ -267,7 +268,6 @@ class TransformerStackFn(torch.autograd.Function):
             else:
                 h_mid = ops.gemm_nt(ctx_, w.proj.wb, bias=w.proj.b, epilogue=EPI_RESIDUAL, aux_in=h, dropout_p=p,
                                     dropout_seed=_site_seed(seed, l, 0))
-                sx2 = None
                 if f8_x2:
                     x2q, sx2, mean2, rstd2 = ln_q8t(f'{site}/{l}/x2', h_mid, w.ln2)
                     x2, rs2 = None, None
@@ -368,11 +368,12 @@ class TransformerStackFn(torch.autograd.Function):
                 ops.gemm_tn(db2, a, w.fc2.gw)             # dW2[H, I]
             a = a8 = db2_8 = None
             du8 = sdu = None
+            dg1 = 'dgrad1' in f8m and fuse8 and 'w1' in f8m      # fc1's input gradient reads du's copy too: du itself is never stored
             if 'w1' in f8m and fuse8:
                 key = f'{site}/{l}/du'
                 if f8.ready(key):
                     sdu = f8.block(key, gfmt)
-                    du, du8 = ops.gemm_nt_q8(db2, w.fc2.wbT, sdu, gfmt, epilogue=EPI_DGELU, aux_in=u, colsum_out=w.fc1.gb)
+                    du, du8 = ops.gemm_nt_q8(db2, w.fc2.wbT, sdu, gfmt, epilogue=EPI_DGELU, aux_in=u, colsum_out=w.fc1.gb, keep_bf16=not dg1)
                     f8.dirty = True
                 else:
                     du = ops.gemm_nt(db2, w.fc2.wbT, epilogue=EPI_DGELU, aux_in=u, colsum_out=w.fc1.gb)
@@ -385,8 +386,12 @@ class TransformerStackFn(torch.autograd.Function):
                 _wgrad(f8, f'{site}/{l}/w1', du, x2, w.fc1.gw, gfmt)
             else:
                 ops.gemm_tn(du, x2, w.fc1.gw)             # dW1[I, H]
-            du8 = x2q = None
-            dx2 = ops.gemm_nt(du, w.fc1.wbT)
+            if dg1:
+                wt8, swt = ops.quantize_e4m3(w.fc1.wbT)
+                dx2 = ops.gemm_f8_nt(du8, sdu, wt8, swt)
+            else:
+                dx2 = ops.gemm_nt(du, w.fc1.wbT)
+            du = du8 = x2q = None
             dh_mid, db1, db1_8, sdb1 = ln_bwd8(f'{site}/{l}/db1', 'wproj' in f8m, dx2, h_mid, mean2, rstd2, w.ln2.gamma, w.ln2.ggamma, w.ln2.gbeta, dres=dh,
                                                branch_bias_grad=w.proj.gb, drop_p=p, drop_seed=_site_seed(seed, l, 0))
             # ---- attention branch: h_mid = h + drop(proj(attn(qkv(LN1(h)))))             db1 = d(proj output)

@@ -255,6 +255,25 @@ def quantize_f8(x, fmt=F8_E4M3, *, scale=None, out=None, row_multiple=128, curre
     return out, scale
 
 
+def gemm_f8_nt(a8, a_scale, bt8, b_scale, *, bias=None, alpha=1.0):
+    """C[M,N] bf16 = alpha / (sa * sb) * a8[M,K] @ bt8[N,K]^T (+ bias): a8 e4m3 or e5m2 (by dtype), bt8 e4m3; scales: the blocks quantize_f8 / F8Scales hold."""
+    fa = 0 if a8.dtype == torch.float8_e4m3fn else 1
+    _chk(a8, _F8_DTYPES[fa], 'a8'); _chk(bt8, FP8, 'bt8'); _chk(a_scale, F32, 'a_scale'); _chk(b_scale, F32, 'b_scale'); _chk(bias, F32, 'bias')
+    M, K = a8.shape
+    N = bt8.shape[0]
+    out = torch.empty((M, N), device=a8.device, dtype=BF16)
+
+    def launch():
+        call('merlot_gemm_f8_nt', _p(a8), a8.stride(0), fa, a_scale.data_ptr() + 4, _p(bt8), bt8.stride(0), b_scale.data_ptr() + 4, _p(out), N, M, N, K,
+             float(alpha), _p(bias), *_nt_ws(), _stream())
+
+    if TIMER is not None:
+        TIMER.time('gemm_fp8_nt', 2.0 * M * N * K, launch)
+    else:
+        launch()
+    return out
+
+
 def f8_scale_rotate(blocks, n, fmts):
     """blocks f32 [>= n, 4], fmts int32 [>= n]: every block whose producers recorded an amax ([3] > 0) gets {s, 1/s, amax} from it, the record is cleared."""
     _chk(blocks, F32, 'blocks'); _chk(fmts, torch.int32, 'fmts')

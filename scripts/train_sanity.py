@@ -9,9 +9,13 @@ from merlot_amd.train import Trainer, synthetic_batch
 cfgd = yaml.safe_load(open(os.path.join(os.path.dirname(__file__), '..', 'merlot_amd', 'configs', 'pretrain_4seg_224.yaml')))
 cfgd['optimizer'].update(num_warmup_steps=5, num_train_steps=200, learning_rate=2e-4)
 cfgd['model']['hidden_dropout_prob'] = float(sys.argv[1]) if len(sys.argv) > 1 else 0.1
+if len(sys.argv) > 2:                                     # round 6: python scripts/train_sanity.py 0.1 w1,w2,fuse,noa,dgrad1 [examples] -- fp8 forward + the 8-bit backward
+    cfgd['model']['fp8_forward'] = 'ln'
+    cfgd['model']['fp8_backward'] = sys.argv[2]
+    print('fp8_forward ln, fp8_backward', sys.argv[2])
 config = NeatConfig.from_dict(cfgd)
 tr = Trainer(config, 'cuda', None, seed=0)
-batch = synthetic_batch(config, 2, 'cuda', seed=7)
+batch = synthetic_batch(config, int(sys.argv[3]) if len(sys.argv) > 3 else 2, 'cuda', seed=7)
 hist = []
 for it in range(60):
     out = tr.step(batch)

@@ -289,6 +289,22 @@ def test_ln_bwd_copy_equals_the_pass_over_the_branch_gradient(p, fmt):
     assert blk[3].item() == float(br0.float().abs().max())
 
 
+@pytest.mark.parametrize('fmt', [0, 1])
+@pytest.mark.parametrize('M,N,K', [(4096, 768, 3072), (1000, 768, 3072), (66560, 768, 2304)])
+def test_gemm_f8_nt_with_an_e5m2_operand_equals_matmul_of_the_dequantised_operands(M, N, K, fmt):
+    """merlot_gemm_f8_nt: the input-gradient GEMM on the copy the GELU' epilogue wrote (A in e5m2 or e4m3, the weights in e4m3)"""
+    ops = _ops()
+    g = torch.Generator(device='cuda').manual_seed(M + fmt)
+    a = (torch.randn(M, K, device='cuda', generator=g) * 1e-3).bfloat16()
+    w = (torch.randn(N, K, device='cuda', generator=g) * 0.03).bfloat16()
+    a8, sa = ops.quantize_f8(a, fmt, row_multiple=1)
+    w8, sw = ops.quantize_f8(w, 0, row_multiple=1)
+    out = ops.gemm_f8_nt(a8, sa, w8, sw)
+    ref = _deq(a8, sa).double() @ _deq(w8, sw).double().T
+    assert float((out.double() - ref).abs().max() / ref.abs().max()) < 6e-3      # bf16 output rounding
+    assert float((out.double() - ref).norm() / ref.norm()) < 3e-3
+
+
 def test_scale_rotate_turns_recorded_amaxes_into_scales():
     ops = _ops()
     blocks = torch.tensor([[2.0, 0.5, 224.0, 112.0], [3.0, 1 / 3.0, 5.0, 0.0], [1.0, 1.0, 0.0, 7.0]], device='cuda')
@@ -300,7 +316,7 @@ def test_scale_rotate_turns_recorded_amaxes_into_scales():
     assert b[2].tolist() == [8192.0, 1 / 8192.0, 7.0, 0.0]            # e5m2: 57 344 / 7
 
 
-@pytest.mark.parametrize('modes', ['w1,w2,fuse', 'w1,w2,wqkv,wproj,fuse,noa'])
+@pytest.mark.parametrize('modes', ['w1,w2,fuse', 'w1,w2,wqkv,wproj,fuse,noa', 'w1,w2,fuse,noa,dgrad1'])
 def test_config5_geometry_fused_fp8_backward_three_steps(modes):
     """`fp8_backward` with 'fuse' at a batch whose row counts are multiples of 256 (16 examples of 16 frames at 384^2: 147 968 ViT rows, 45 312 joint
     rows, 8 192 text rows): step 0 calibrates every site (current scaling), steps 1 and 2 run on the producers' own copies with delayed scales.  Against
