@@ -225,7 +225,6 @@ def main():
                     help='BASELINE.json configs[]: 2 = the headline 4-segment 224^2 bf16 workload (configs[1]; DP over --gpus); '
                          '5 = NOT the headline: the 16-segment 384^2 long-video variant with fp8 forward GEMMs (configs[4])')
     ap.add_argument('--bf16', action='store_true', help='with --config 5: keep every GEMM in bf16 (the comparison line)')
-    ap.add_argument('--fp8-attn', action='store_true', help='with --config 5: QKV / fc1 / fc2 GEMMs AND the attention forward (Q K^T, P V) on e4m3 operands')
     ap.add_argument('--fp8-fc2', action='store_true', help='with --config 5: also run fc2 on e4m3 operands (its input needs a separate two-pass quantisation)')
     ap.add_argument('--fp8', action='store_true',
                     help='NOT the headline (whose dtype is bf16): the headline GEOMETRY (config 2) with the fp8 forward GEMMs of config 5 (QKV / fc1 on e4m3 operands); '
@@ -234,7 +233,7 @@ def main():
                     help='8-bit float operands in the BACKWARD (model.fp8_backward; never the headline): a comma-separated list of w1, w2, wqkv, wproj '
                          '(that weight gradient through merlot_gemm_f8_tn), e4m3 (gradient operands in e4m3 instead of e5m2), fuse (the copies come out of the '
                          'launches that produce the tensors), noa (fc1 stores only the e4m3 copy of its output; fc2 reads it), dgrad1 (fc1\'s input gradient on '
-                         'the copy of du).  The configuration that pays: w1,w2,fuse,noa,dgrad1')
+                         'the copy of du).  dgradqkv (with wqkv: the QKV input gradient on the copy of dqkv).  The configuration that pays (config 5\'s default): w1,w2,wqkv,fuse,noa,dgrad1,dgradqkv')
     ap.add_argument('--resnet-stem', action='store_true',
                     help='NOT the headline config: swap the patch stem for the ResNet-hybrid stem of merlot.yaml:30 (resnet_layers [3, 4, 9])')
     ap.add_argument('--native-yaml', action='store_true',
@@ -317,15 +316,15 @@ def main():
     if args.config == 5:
         # BASELINE configs[4]: 16 segments per group at 384^2 (Sv = 578, joint S = 2832); everything else as merlot.yaml
         fp8 = not args.bf16
-        config.model.update(image_size=[384, 384], num_chunks_in_group=16, fp8_forward=('all' if args.fp8_attn else True if args.fp8_fc2 else 'ln') if fp8 else False)
+        config.model.update(image_size=[384, 384], num_chunks_in_group=16, fp8_forward=(True if args.fp8_fc2 else 'ln') if fp8 else False)
         train_gflop = 3.0 * fwd_gflop_per_segment(384, 16)
     if args.fp8 and args.config == 2:
         fp8 = True
         config.model['fp8_forward'] = 'ln'
     if args.config == 5 and fp8 and args.fp8_bwd is None:
-        # round 6: config #5's line runs the configuration that pays (profiles/r06_o_bench5_*.json: 561 ms all-bf16, 544 ms fp8 forward only, 492 ms with the
-        # 8-bit backward on one box); --fp8-bwd none gives the forward-only line of rounds 2-5
-        args.fp8_bwd = 'w1,w2,fuse,noa,dgrad1'
+        # round 6: config #5's line runs the configuration that pays (profiles/r06_s_bench5_*.json: 549 ms all-bf16, 532 ms fp8 forward only, 479 ms with the
+        # MLP half's 8-bit backward, 469 ms with the QKV weight / input gradients on dqkv's copy as well, on one box); --fp8-bwd none gives the forward-only line of rounds 2-5
+        args.fp8_bwd = 'w1,w2,wqkv,fuse,noa,dgrad1,dgradqkv'
     if args.fp8_bwd in ('none', 'off', ''):
         args.fp8_bwd = None
     if args.fp8_bwd:
@@ -393,13 +392,13 @@ def main():
             'metric': 'frame-caption segments/sec/node (4-seg, 192x352 as merlot.yaml ships it, bf16)' if args.native_yaml else
                       'frame-caption segments/sec/node (4-seg, 224^2, bf16)' if (args.config == 2 and not fp8) else
                       ('frame-caption segments/sec/node (4-seg, 224^2, NOT the headline dtype: fp8 QKV/fc1 forward GEMMs' + (' + 8-bit backward (' + args.fp8_bwd + ')' if args.fp8_bwd else '') + ')') if args.config == 2 else
-                      'frame-caption segments/sec/node (16-seg, 384^2, %s)' % ((('fp8 QKV/fc1/fc2 GEMMs + attention forward' if args.fp8_attn else 'fp8 QKV/fc1/fc2 forward GEMMs' if args.fp8_fc2 else 'fp8 QKV/fc1 forward GEMMs') + (' + 8-bit backward (' + args.fp8_bwd + ')' if args.fp8_bwd else '')) if fp8 else 'bf16'),
+                      'frame-caption segments/sec/node (16-seg, 384^2, %s)' % ((('fp8 QKV/fc1/fc2 forward GEMMs' if args.fp8_fc2 else 'fp8 QKV/fc1 forward GEMMs') + (' + 8-bit backward (' + args.fp8_bwd + ')' if args.fp8_bwd else '')) if fp8 else 'bf16'),
             'value': value, 'unit': 'segments/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': (('fp8 (e4m3 operands, fp32 accumulate: QKV / fc1%s forward GEMMs; ' % (' / fc2 GEMMs, attention QK^T and PV' if args.fp8_attn else ' / fc2' if args.fp8_fc2 else '')) +
+            'dtype': (('fp8 (e4m3 operands, fp32 accumulate: QKV / fc1%s forward GEMMs; ' % (' / fc2' if args.fp8_fc2 else '')) +
                       (('8-bit backward [' + args.fp8_bwd + ']: weight gradients on e5m2 x e4m3 operands' + (', fc2 forward on the e4m3 copy fc1 wrote' if 'noa' in args.fp8_bwd else '') +
-                        (", fc1's input gradient on the e5m2 copy the GELU' epilogue wrote" if 'dgrad1' in args.fp8_bwd else '') + '; bf16 elsewhere)') if args.fp8_bwd else 'bf16 elsewhere)')) if fp8 else 'bf16',
+                        (", fc1's input gradient on the e5m2 copy the GELU' epilogue wrote" if 'dgrad1' in args.fp8_bwd else '') + (", the QKV input gradient on dqkv's e5m2 copy" if 'dgradqkv' in args.fp8_bwd else '') + '; bf16 elsewhere)') if args.fp8_bwd else 'bf16 elsewhere)')) if fp8 else 'bf16',
             'data': 'synthetic',
             'config': {'workload': (('merlot.yaml 4-segment ResNet-hybrid [3,4,9] + ViT-B/16' if args.resnet_stem else
                                      'merlot.yaml 4-segment full ViT-B/16 (patch stem)') + ' + 12-layer joint + 12-layer text-only, '

@@ -111,15 +111,10 @@ int merlot_gemm_bf16_nt_plan(int64_t M, int64_t N, int64_t K);
 int merlot_quantize_e4m3(const void* x, int64_t rows, int64_t cols, int64_t ldx, void* y, int64_t ldy, float* scale,
                          merlot_stream_t stream);
 /* amax[g] = max|x[:, g-th of `groups` equal column groups]| over a [rows, cols] bf16 view (row stride ldx), one pass;
- * amax = device float[groups] (zeroed here), groups <= 4.  Feeds merlot_attention_fwd_fp8: groups = 3 over the fused QKV
- * tensor gives max|Q|, max|K|, max|V|. */
+ * amax = device float[groups] (zeroed here), groups <= 4 (groups = 3 over the fused QKV tensor gives max|Q|, max|K|, max|V|). */
 int merlot_amax_bf16(const void* x, int64_t rows, int64_t cols, int64_t ldx, int groups, float* amax, merlot_stream_t stream);
-/* merlot_attention_fwd with Q K^T and P V on the e4m3 MFMA (fp32 accumulation; softmax, masks and the lse output unchanged):
- * Q, K, V are quantised on the fly from the bf16 tensor with ONE scale per tensor, 448 / amax3[0..2] (device memory), P with
- * 2^8.  No side outputs on this entry (use merlot_attention_colsum).  The backward stays merlot_attention_bwd. */
-int merlot_attention_fwd_fp8(const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse, const uint8_t* valid,
-                             const int32_t* seg, int B, int S, int heads, float scale, const float* amax3,
-                             merlot_stream_t stream);
+/* (round 6: merlot_attention_fwd_fp8 -- Q K^T / P V on the e4m3 MFMA, operands quantised on the fly -- was correct and 2-19 % SLOWER than the bf16 kernel on every
+ * shape for three rounds; removed in ABI v9, VERDICT r5 #6 "fix or delete") */
 /* C[M,N] = epilogue(alpha * scale_a[0] * scale_b[0] * A8[M,K] * B8t[N,K]^T + bias): merlot_gemm_bf16_nt on e4m3 operands.
  * scale_a / scale_b point at the DEQUANTISATION factor of each operand in device memory (&scale[1] of
  * merlot_quantize_e4m3).  A may instead (or also) carry per-ROW factors row_scale_a (f32 [M], from merlot_ln_fwd_q8;
@@ -273,6 +268,17 @@ int merlot_attention_bwd(const void* qkv, int64_t ld, const void* out, int64_t l
                          const float* lse, const uint8_t* valid, const int32_t* seg, void* dqkv, int64_t lddqkv,
                          float* delta, int B, int S, int heads, float scale, float* log_lo, float* log_hi, int log_qsplit,
                          float log_weight, void* workspace, int64_t workspace_bytes, merlot_stream_t stream);
+/* ABI v9: merlot_attention_bwd that ALSO writes dqkv8[B*S, lddqkv8] = f8(clamp(bf16(dqkv) * q8_scale[0])) (q8_fmt 0 = e4m3, 1 = e5m2; q8_scale = the tensor's
+ * merlot_quantize_f8 block, delayed scaling; max|dqkv| of the launch is max-ed into q8_scale[3]) -- the operand of the QKV weight / input gradients on 8-bit
+ * operands without a quantising pass.  Only the shapes the tiled dQ / dK dV kernel pair takes have it: merlot_attention_bwd_writes_q8(S, has_segment_mask) == 1
+ * (more than 512 tokens -- BASELINE configs[4]'s 578 / 2 832 --, a segment mask, or at most 64 tokens); other shapes are refused (use the plain entry and
+ * merlot_quantize_f8). */
+int merlot_attention_bwd_writes_q8(int S, int has_segment_mask);
+int merlot_attention_bwd_q8(const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout, int64_t lddo,
+                            const float* lse, const uint8_t* valid, const int32_t* seg, void* dqkv, int64_t lddqkv, float* delta,
+                            int B, int S, int heads, float scale, float* log_lo, float* log_hi, int log_qsplit, float log_weight,
+                            void* dqkv8, int64_t lddqkv8, int q8_fmt, float* q8_scale,
+                            void* workspace, int64_t workspace_bytes, merlot_stream_t stream);
 /* Side outputs the reference takes from its stacked [B,layers,S,S] head-mean probabilities, without
  * materialising SxS:  colsum_lo[b,key] += weight * sum_h sum_{q <  qsplit} P[b,h,q,key]
  *                     colsum_hi[b,key] += weight * sum_h sum_{q >= qsplit} P[b,h,q,key]

@@ -61,7 +61,42 @@ struct AttnArgs {
     float weight;
     unsigned int* ctr;   // persistent kernels (attention_pp.inc): the caller's item-claim counters (zero on entry, left zero), or nullptr
     int dbg;             // experiments build only (MERLOT_ATTN_DBG): 1 = the streaming kernels move the data but skip the tile arithmetic
+    // round 6 (ABI v9, merlot_attention_bwd_q8; the tiled dQ / dK dV pair only): an 8-bit float copy of dqkv from the launches that form it -- the operand of the
+    // QKV weight gradient and input gradient on 8-bit operands (gemm_q8.inc) without a quantising pass.  dqkv8 == nullptr: off.
+    uint8_t* dqkv8;      // [B * S, lddqkv8] bytes: f8(clamp(bf16(dqkv) * q8_scale[0])), q8_fmt 0 = e4m3, 1 = e5m2
+    int64_t lddqkv8;
+    const float* q8_scale;   // the tensor's merlot_quantize_f8 block (delayed scale in [0])
+    unsigned int* q8_amax;   // &block[3] as bits: max|bf16(dqkv)| is max-ed into it
+    int q8_fmt;
 };
+
+// the 8-bit copy of four consecutive bf16-rounded gradient values (one dword) + this lane's running amax
+__device__ __forceinline__ void attn_store_q8(uint8_t* dst, const bf16x4& v4, float s, int fmt, float& amax) {
+    float f[4];
+    const float fm = fmt == 0 ? 448.f : 57344.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float t = (float)v4[e];
+        amax = fmaxf(amax, fabsf(t));
+        f[e] = __builtin_amdgcn_fmed3f(t * s, -fm, fm);
+    }
+    int w = 0;
+    if (fmt == 0) {
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w, true);
+    } else {
+        w = __builtin_amdgcn_cvt_pk_bf8_f32(f[0], f[1], w, false);
+        w = __builtin_amdgcn_cvt_pk_bf8_f32(f[2], f[3], w, true);
+    }
+    *reinterpret_cast<int*>(dst) = w;
+}
+// one atomic per wave at most -- and none once the recorded maximum is at least this wave's (a plain read first: a stale value only costs a redundant atomic)
+__device__ __forceinline__ void attn_amax_flush(unsigned int* dst, float amax, int lane) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    const unsigned int bits = __float_as_uint(amax);
+    if (lane == 0 && bits > __builtin_nontemporal_load(dst)) atomicMax(dst, bits);
+}
 
 __device__ __forceinline__ int h2_off(int R, int row, int chunk) {
     return (chunk >> 2) * R * 64 + row * 64 + ((((chunk & 3) ^ (row >> 2)) & 3) << 4);
@@ -299,232 +334,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// forward on e4m3 operands (BASELINE config #5): the kernel above with Q K^T and P V on v_mfma_f32_32x32x16_fp8_fp8, fp32
-// accumulation, softmax / masks / running max unchanged.  The operands are quantised ON THE FLY from the bf16 QKV tensor
-// (which the bf16 backward needs anyway) with one scale per tensor: Q in registers, K as it is staged into LDS, V as it is
-// staged into LDS -- TRANSPOSED there ([d][key position], byte stores), with the keys of every group of 16 stored in the
-// order {0-3, 8-11, 4-7, 12-15} so that the 8 k-slots of a P operand (accumulator rows (r & 3) + 8 (r >> 2) + 4 hi) are 8
-// contiguous bytes: no transposing LDS read in this kernel.
-__device__ __forceinline__ long cvt8_e4m3(u32x4 raw, float s) {
-    const bf16x8 v = __builtin_bit_cast(bf16x8, raw);
-    float f[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) f[e] = clamp_e4m3((float)v[e] * s);
-    int w0 = 0, w1 = 0;
-    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w0, false);
-    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
-    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], w1, false);
-    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
-    return (long)(((unsigned long long)(unsigned)w1 << 32) | (unsigned)w0);
-}
-// the staged K tile (tile_load_regs<64>: thread -> (row, 16-B chunk of 8 d)) -> e4m3 rows of 64 B
-__device__ __forceinline__ void tile_store_k8(char* lds, const u32x4 (&regs)[2], float s, int tid) {
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int idx = it * 256 + tid;
-        const int half = idx / 256;
-        const int rem = idx - half * 256;
-        const int row = rem >> 2;
-        const int chunk = half * 4 + (rem & 3);
-        *reinterpret_cast<long*>(lds + row * 64 + (((chunk ^ (row >> 1)) & 7) << 3)) = cvt8_e4m3(regs[it], s);
-    }
-}
-// the staged V tile -> V^T: byte (d, key position), d = chunk * 8 + e
-__device__ __forceinline__ void tile_store_v8t(char* lds, const u32x4 (&regs)[2], float s, int tid) {
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int idx = it * 256 + tid;
-        const int half = idx / 256;
-        const int rem = idx - half * 256;
-        const int row = rem >> 2;                        // key inside the 64-key tile
-        const int chunk = half * 4 + (rem & 3);
-        const int j = row & 15;
-        const int pos = (row & 48) + (j & 3) + ((j >> 3) & 1) * 4 + ((j >> 2) & 1) * 8;
-        const unsigned long long v = (unsigned long long)cvt8_e4m3(regs[it], s);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int d = chunk * 8 + e;
-            lds[d * 64 + ((((pos >> 3) ^ (d >> 1)) & 7) << 3) + (pos & 7)] = (char)(v >> (8 * e));
-        }
-    }
-}
-
-template <bool MASKED>
-__global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const AttnArgs p, const float* __restrict__ amax3) {
-    __shared__ __attribute__((aligned(1024))) char smem[2 * 4096 + 768];
-    char* ldsK = smem;                                   // [64 keys][64 d] e4m3, 8-B slot index XOR (key >> 1) & 7
-    char* ldsV = smem + 4096;                            // V^T: [64 d][64 key positions] e4m3, 8-B slot index XOR (d >> 1) & 7
-    float* biasA = reinterpret_cast<float*>(smem + 8192);
-    float* biasB = biasA + 64;
-    int* segK = reinterpret_cast<int*>(biasB + 64);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hi = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int S = p.S;
-    const int qw0 = blockIdx.x * 128 + wave * 32;  // first query row of this wave
-    const bool wave_active = qw0 < S;
-    const bf16* base = p.qkv + (int64_t)b * S * p.ld + h * 64;
-    const bf16* kbase = base + p.heads * 64;
-    const bf16* vbase = base + 2 * p.heads * 64;
-    const uint8_t* vrow = MASKED ? p.valid + (int64_t)b * S : nullptr;
-
-    const int q = min(qw0 + (lane & 31), S - 1);
-    const bool qv = MASKED ? (vrow[q] != 0) : true;
-    const bool segd = MASKED && p.seg != nullptr;
-    const int sq = (segd && qv) ? p.seg[q] : 0;     // 0: every key allowed (viz / padded query rows stay uniform)
-    // per-tensor quantisation scales of Q, K, V (448 / max|.| over the whole [B*S, heads*64] slice; the maxima were reduced by
-    // merlot_amax_bf16 into device memory -- no host round trip)
-    const float s_q = amax3[0] > 0.f ? 448.f / amax3[0] : 1.f;
-    const float s_k = amax3[1] > 0.f ? 448.f / amax3[1] : 1.f;
-    const float s_v = amax3[2] > 0.f ? 448.f / amax3[2] : 1.f;
-    long qf[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-        qf[kk] = cvt8_e4m3(*reinterpret_cast<const u32x4*>(base + (int64_t)q * p.ld + kk * 16 + hi * 8), s_q);
-
-    f32x16 o[2] = {zero16(), zero16()};
-    float m_run = -INFINITY, l_run = 0.f;
-    const float sc = qv ? p.scale * LOG2E / (s_q * s_k) : 0.f;      // the scores come out of the MFMA times s_q * s_k
-    const float* bias = (qv ? biasA : biasB) + 4 * hi;
-
-    const int nkt = (S + 63) / 64;
-    u32x4 kreg[2], vreg[2];
-    tile_load_regs<64>(kbase, p.ld, 0, S - 1, kreg, tid);
-    tile_load_regs<64>(vbase, p.ld, 0, S - 1, vreg, tid);
-    for (int kt = 0; kt < nkt; ++kt) {
-        __syncthreads();
-        tile_store_k8(ldsK, kreg, s_k, tid);
-        tile_store_v8t(ldsV, vreg, s_v, tid);
-        const bool ragged = MASKED || (kt * 64 + 64 > S);        // wave-uniform: this tile needs the bias vectors
-        if (ragged && tid < 64) {
-            const int kidx = kt * 64 + tid;
-            const bool in = kidx < S;
-            const bool kval = in && (MASKED ? vrow[min(kidx, S - 1)] != 0 : true);
-            biasA[tid] = in ? (kval ? 0.f : MASKED_T) : -INFINITY;
-            biasB[tid] = in ? 0.f : -INFINITY;
-            if (segd) segK[tid] = p.seg[min(kidx, S - 1)];
-        }
-        __syncthreads();
-        if (kt + 1 < nkt) {
-            tile_load_regs<64>(kbase, p.ld, (kt + 1) * 64, S - 1, kreg, tid);
-            tile_load_regs<64>(vbase, p.ld, (kt + 1) * 64, S - 1, vreg, tid);
-        }
-        if (!wave_active) continue;
-        // keys kt*64+32 .. kt*64+63 all beyond S (e.g. S = 198: the last tile holds 6 keys): skip that half entirely
-        const bool half = kt * 64 + 32 >= S;
-
-        f32x16 st[2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            st[kb] = zero16();
-            if (kb == 1 && half) continue;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int krow = kb * 32 + (lane & 31);
-                const long kf = *reinterpret_cast<const long*>(ldsK + krow * 64 + ((((2 * kk + hi) ^ (krow >> 1)) & 7) << 3));
-                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(kf, qf[kk], st[kb], 0, 0, 0);
-            }
-        }
-        float mloc = -INFINITY;
-        if (ragged) {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                if (kb == 1 && half) continue;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + kb * 32 + 8 * g);
-                    int sk[4] = {0, 0, 0, 0};
-                    if (segd) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) sk[e] = segK[4 * hi + kb * 32 + 8 * g + e];
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float t = fmaf(st[kb][4 * g + e], sc, b4[e]);
-                        if (segd) t = (sq == 0 || sk[e] == 0 || sk[e] == sq) ? t : MASKED_T;   // exactly -1e10, as a padded key
-                        st[kb][4 * g + e] = t;
-                        mloc = fmaxf(mloc, t);
-                    }
-                }
-            }
-        } else {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float t = st[kb][r] * sc;
-                    st[kb][r] = t;
-                    mloc = fmaxf(mloc, t);
-                }
-        }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        if (__any(mloc > m_run)) {   // NO deferred rescale here: p must stay <= 1 so that 256 p fits e4m3 (448); wave-uniform
-            const float m_new = fmaxf(m_run, mloc);
-            const float alpha = fast_exp2(m_run - m_new);
-            l_run *= alpha;
-            m_run = m_new;
-#pragma unroll
-            for (int db = 0; db < 2; ++db)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-        }
-        float lsum = 0.f;
-        long pf[2][2];                                   // P in e4m3, scaled by 2^8: p <= 1 -> <= 256, and a uniform row of a 2832-key
-                                                         // sequence (p = 3.5e-4 -> 0.09) stays a normal number instead of flushing to 0
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            if (kb == 1 && half) continue;
-            float pq[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = fast_exp2(st[kb][r] - m_run);
-                lsum += pv;
-                pq[r] = pv * 256.f;
-            }
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                int w0 = 0, w1 = 0;
-                w0 = __builtin_amdgcn_cvt_pk_fp8_f32(pq[hf * 8 + 0], pq[hf * 8 + 1], w0, false);
-                w0 = __builtin_amdgcn_cvt_pk_fp8_f32(pq[hf * 8 + 2], pq[hf * 8 + 3], w0, true);
-                w1 = __builtin_amdgcn_cvt_pk_fp8_f32(pq[hf * 8 + 4], pq[hf * 8 + 5], w1, false);
-                w1 = __builtin_amdgcn_cvt_pk_fp8_f32(pq[hf * 8 + 6], pq[hf * 8 + 7], w1, true);
-                pf[kb][hf] = (long)(((unsigned long long)(unsigned)w1 << 32) | (unsigned)w0);
-            }
-        }
-        lsum += __shfl_xor(lsum, 32, 64);
-        l_run += lsum;
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                if (kb == 1 && half) continue;
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    const int d = db * 32 + (lane & 31);
-                    const long vf = *reinterpret_cast<const long*>(ldsV + d * 64 + ((((kb * 4 + hf * 2 + hi) ^ (d >> 1)) & 7) << 3));
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(vf, pf[kb][hf], o[db], 0, 0, 0);
-                }
-            }
-    }
-
-    if (wave_active && qw0 + (lane & 31) < S) {
-        const float inv = 1.0f / (l_run * 256.f * s_v);      // O accumulated sum(256 p * s_v v)
-        bf16* orow = p.out + ((int64_t)b * S + q) * p.ldo + h * 64;
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                bf16x4 v4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v4[e] = (bf16)(o[db][4 * g + e] * inv);
-                *reinterpret_cast<bf16x4*>(orow + db * 32 + 8 * g + 4 * hi) = v4;
-            }
-        if (hi == 0 && p.lse) p.lse[((int64_t)b * p.heads + h) * S + q] = m_run * LN2 + logf(l_run);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // backward dQ: one wave per 32 query rows, loop over key tiles (same lane<->query layout and bias vectors as forward)
 // ------------------------------------------------------------------------------------------------
 template <bool MASKED>
@@ -653,8 +462,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
                 }
             }
     }
+    float q8_m = 0.f;
+    const float q8_s = p.dqkv8 ? p.q8_scale[0] : 0.f;
     if (wave_active && qw0 + (lane & 31) < S) {
         bf16* drow = p.dqkv + ((int64_t)b * S + q) * p.lddqkv + h * 64;
+        uint8_t* drow8 = p.dqkv8 ? p.dqkv8 + ((int64_t)b * S + q) * p.lddqkv8 + h * 64 : nullptr;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -663,8 +475,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v4[e] = (bf16)dq[db][4 * g + e];
                 *reinterpret_cast<bf16x4*>(drow + db * 32 + 8 * g + 4 * hi) = v4;
+                if (drow8) attn_store_q8(drow8 + db * 32 + 8 * g + 4 * hi, v4, q8_s, p.q8_fmt, q8_m);
             }
     }
+    if (p.dqkv8 && wave_active) attn_amax_flush(p.q8_amax, q8_m, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -793,9 +607,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs p)
                 }
         }
     }
+    float q8_m = 0.f;
+    const float q8_s = p.dqkv8 ? p.q8_scale[0] : 0.f;
     if (wave_active && key_in) {
         bf16* krow = p.dqkv + ((int64_t)b * S + key) * p.lddqkv + p.heads * 64 + h * 64;
         bf16* vrowp = krow + p.heads * 64;
+        uint8_t* krow8 = p.dqkv8 ? p.dqkv8 + ((int64_t)b * S + key) * p.lddqkv8 + p.heads * 64 + h * 64 : nullptr;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -808,8 +625,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs p)
                 }
                 *reinterpret_cast<bf16x4*>(krow + db * 32 + 8 * g + 4 * hi) = k4;
                 *reinterpret_cast<bf16x4*>(vrowp + db * 32 + 8 * g + 4 * hi) = v4;
+                if (krow8) {
+                    attn_store_q8(krow8 + db * 32 + 8 * g + 4 * hi, k4, q8_s, p.q8_fmt, q8_m);
+                    attn_store_q8(krow8 + p.heads * 64 + db * 32 + 8 * g + 4 * hi, v4, q8_s, p.q8_fmt, q8_m);
+                }
             }
     }
+    if (p.dqkv8 && wave_active) attn_amax_flush(p.q8_amax, q8_m, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -971,30 +793,12 @@ extern "C" int merlot_attention_fwd(const void* qkv, int64_t ld, void* out, int6
     return merlot_launch_status("merlot_attention_fwd");
 }
 
-// e4m3 forward (BASELINE config #5): amax3 = device float[3], max|Q|, max|K|, max|V| over the whole tensor (merlot_amax_bf16 x 3).
-extern "C" int merlot_attention_fwd_fp8(const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse, const uint8_t* valid,
-                                        const int32_t* seg, int B, int S, int heads, float scale, const float* amax3,
-                                        merlot_stream_t stream) {
-    int rc = check_attn(qkv, ld, B, S, heads);
-    if (rc) return rc;
-    MERLOT_CHECK(out && ldo >= heads * 64 && ldo % 4 == 0, MERLOT_ESHAPE, "attention_fwd_fp8: bad out/ldo");
-    MERLOT_CHECK(!seg || valid, MERLOT_ESHAPE, "attention: a segment mask needs the validity mask too");
-    MERLOT_CHECK(amax3 != nullptr, MERLOT_ESHAPE, "attention_fwd_fp8: amax3 is required");
-    AttnArgs a{};
-    a.qkv = (const bf16*)qkv; a.ld = ld; a.out = (bf16*)out; a.ldo = ldo; a.lse = lse; a.valid = valid; a.seg = seg;
-    a.B = B; a.S = S; a.heads = heads; a.scale = scale;
-    if (valid)
-        hipLaunchKernelGGL(attn_fwd_fp8_kernel<true>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, (hipStream_t)stream, a, amax3);
-    else
-        hipLaunchKernelGGL(attn_fwd_fp8_kernel<false>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, (hipStream_t)stream, a, amax3);
-    return merlot_launch_status("merlot_attention_fwd_fp8");
-}
-
-extern "C" int merlot_attention_bwd(const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout,
-                                    int64_t lddo, const float* lse, const uint8_t* valid, const int32_t* seg, void* dqkv,
-                                    int64_t lddqkv, float* delta, int B, int S, int heads, float scale,
-                                    float* log_lo, float* log_hi, int log_qsplit, float log_weight,
-                                    void* workspace, int64_t workspace_bytes, merlot_stream_t stream) {
+static int attention_bwd_impl(const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout,
+                              int64_t lddo, const float* lse, const uint8_t* valid, const int32_t* seg, void* dqkv,
+                              int64_t lddqkv, float* delta, int B, int S, int heads, float scale,
+                              float* log_lo, float* log_hi, int log_qsplit, float log_weight,
+                              void* workspace, int64_t workspace_bytes, merlot_stream_t stream,
+                              void* dqkv8, int64_t lddqkv8, int q8_fmt, float* q8_scale) {
     int rc = check_attn(qkv, ld, B, S, heads);
     if (rc) return rc;
     MERLOT_CHECK(out && dout && lse && dqkv && delta, MERLOT_ESHAPE, "attention_bwd: null operand");
@@ -1016,6 +820,13 @@ extern "C" int merlot_attention_bwd(const void* qkv, int64_t ld, const void* out
     // S <= 512 without a segment mask (every pass of the 224^2 step): ONE launch, K | V and then Q | dO resident in LDS
     // (attention_fb.inc) -- 10 instead of 16 .. 24 [S, 64] tensors through the CU's memory pipe per (batch, head), same results
     int fb_mode = fb_ok(a) ? 1 : 0;
+    if (dqkv8) {
+        MERLOT_CHECK(q8_scale && (q8_fmt == 0 || q8_fmt == 1) && lddqkv8 % 4 == 0 && lddqkv8 >= 3 * heads * 64 && ((uintptr_t)dqkv8 & 3) == 0, MERLOT_ESHAPE,
+                     "attention_bwd_q8: bad copy arguments");
+        MERLOT_CHECK(!fb_mode && !pp_bwd_ok(a), MERLOT_ESHAPE,
+                     "attention_bwd_q8: S = %d runs a kernel without the 8-bit output (merlot_attention_bwd_writes_q8 says which shapes have it)", S);
+        a.dqkv8 = (uint8_t*)dqkv8; a.lddqkv8 = lddqkv8; a.q8_scale = q8_scale; a.q8_amax = reinterpret_cast<unsigned int*>(q8_scale + 3); a.q8_fmt = q8_fmt;
+    }
 #ifdef MERLOT_EXPERIMENTS
     if (const char* e = getenv("MERLOT_ATTN_DBG")) a.dbg = atoi(e);
     if (const char* e = getenv("MERLOT_ATTN_FB")) fb_mode = fb_ok(a) ? atoi(e) : 0;
@@ -1061,6 +872,28 @@ extern "C" int merlot_attention_bwd(const void* qkv, int64_t ld, const void* out
         hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);
     }
     return merlot_launch_status("merlot_attention_bwd");
+}
+
+extern "C" int merlot_attention_bwd(const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout,
+                                    int64_t lddo, const float* lse, const uint8_t* valid, const int32_t* seg, void* dqkv,
+                                    int64_t lddqkv, float* delta, int B, int S, int heads, float scale,
+                                    float* log_lo, float* log_hi, int log_qsplit, float log_weight,
+                                    void* workspace, int64_t workspace_bytes, merlot_stream_t stream) {
+    return attention_bwd_impl(qkv, ld, out, ldo, dout, lddo, lse, valid, seg, dqkv, lddqkv, delta, B, S, heads, scale, log_lo, log_hi, log_qsplit, log_weight,
+                              workspace, workspace_bytes, stream, nullptr, 0, 0, nullptr);
+}
+// ABI v9: merlot_attention_bwd that ALSO writes dqkv8 = f8(clamp(bf16(dqkv) * q8_scale[0])) and max-es max|dqkv| into q8_scale[3] (delayed scaling, as the
+// GEMM producers) -- on the shapes the tiled dQ / dK dV pair takes: longer than 512 tokens, or with a segment mask, or at most 64 tokens
+extern "C" int merlot_attention_bwd_writes_q8(int S, int has_segment_mask) { return (S > FB_MAX_S || has_segment_mask || S <= 64) ? 1 : 0; }
+extern "C" int merlot_attention_bwd_q8(const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout,
+                                       int64_t lddo, const float* lse, const uint8_t* valid, const int32_t* seg, void* dqkv,
+                                       int64_t lddqkv, float* delta, int B, int S, int heads, float scale,
+                                       float* log_lo, float* log_hi, int log_qsplit, float log_weight,
+                                       void* dqkv8, int64_t lddqkv8, int q8_fmt, float* q8_scale,
+                                       void* workspace, int64_t workspace_bytes, merlot_stream_t stream) {
+    MERLOT_CHECK(dqkv8 && q8_scale, MERLOT_ESHAPE, "attention_bwd_q8: null copy arguments");
+    return attention_bwd_impl(qkv, ld, out, ldo, dout, lddo, lse, valid, seg, dqkv, lddqkv, delta, B, S, heads, scale, log_lo, log_hi, log_qsplit, log_weight,
+                              workspace, workspace_bytes, stream, dqkv8, lddqkv8, q8_fmt, q8_scale);
 }
 
 extern "C" int merlot_attention_colsum(const void* qkv, int64_t ld, const float* lse, const uint8_t* valid,

@@ -49,11 +49,24 @@ def _fwd_linear(x, lin, fp8, x8=None, row_scale=None, **kw):
     tensors (x is saved as before)."""
     if not fp8:
         return ops.gemm_nt(x, lin.wb, bias=lin.b, **kw)
-    w8, sw = ops.quantize_e4m3(lin.wb)
+    w8, sw = _w8(lin._store, lin.wb) if lin._store is not None else ops.quantize_e4m3(lin.wb)
     if x8 is not None:
         return ops.gemm_fp8_nt(x8, None, w8, sw, bias=lin.b, a_row_scale=row_scale, **kw)
     x8, sx = ops.quantize_e4m3(x)
     return ops.gemm_fp8_nt(x8, sx, w8, sw, bias=lin.b, **kw)
+
+
+def _w8(store, wt):
+    """the e4m3 copy + scale block of a bf16 weight view (per-tensor, current scaling), made ONCE per version of the working copies: the weights change at
+    the optimizer step only, while a step reads each of them two or three times (forward, and the transposed copy in the backward) -- until round 6 every use
+    ran its own amax + convert launches (~2.8 ms per config-#5 step)."""
+    cache = store.__dict__.setdefault('_w8_cache', {})
+    key = (wt.data_ptr(), tuple(wt.shape))
+    ent = cache.get(key)
+    if ent is None or ent[0] != store.version:
+        w8, sw = ops.quantize_e4m3(wt, out=ent[1] if ent is not None else None)
+        ent = cache[key] = (store.version, w8, sw)
+    return ent[1], ent[2]
 
 
 class F8Scales(object):
@@ -130,7 +143,8 @@ def _f8_modes(opt):
     gradient through merlot_gemm_f8_tn (gradient operand e5m2, activation operand e4m3; 'e4m3' in the list: gradients in e4m3 too); 'fuse': the 8-bit
     copies of x1 / x2 (LayerNorm), a (fc1's GELU epilogue), du (the GELU' epilogue) and the branch gradients (LayerNorm backward) come out of the launches
     that produce those tensors instead of quantising passes (needs fp8_forward and row counts that are multiples of 256; dqkv and the attention output
-    have no such producer and keep their pass); 'noa': with 'fuse' and w2, fc1 does not store its bf16 output at all (fc2 reads the e4m3 copy); 'dgrad1': with 'fuse' and w1, fc1's input-gradient GEMM
+    have no such producer and keep their pass); 'noa': with 'fuse' and w2, fc1 does not store its bf16 output at all (fc2 reads the e4m3 copy); 'dgradqkv': with 'fuse' and wqkv, the QKV input-gradient GEMM (K = 2 304) reads dqkv's copy too (then the one quantising pass over dqkv pays);
+    'dgrad1': with 'fuse' and w1, fc1's input-gradient GEMM
     (K = 3 072) reads du's 8-bit copy as well and the GELU' epilogue does not store du in bf16 at all.  True = 'w1,w2,fuse'."""
     if not opt:
         return frozenset()
@@ -169,7 +183,7 @@ class TransformerStackFn(torch.autograd.Function):
     """hidden [B*S, H] bf16 -> LN_final(stack(hidden)) [B*S, H] bf16.
 
     opts: dict(heads, dropout_p, seed, fp8 (True: QKV / fc1 / fc2 forward GEMMs on e4m3 operands; 'ln': only the two fed by a
-               LayerNorm, whose e4m3 copy costs no extra pass; 'all': True + the attention forward's two contractions), colsum (f32 [B,S] accumulated over layers, all query rows, weight 1/heads),
+               LayerNorm, whose e4m3 copy costs no extra pass; 'all' (rounds 2-5: + the attention forward on e4m3, removed in round 6) = True), colsum (f32 [B,S] accumulated over layers, all query rows, weight 1/heads),
                log_lo / log_hi (f32 [B,S], valid pairs only, queries < / >= log_split), num_layers,
                log_in_backward (True: when a backward will run, log_lo / log_hi are filled by the attention BACKWARD -- its dK / dV
                pass forms P anyway -- instead of a second Q K^T walk in every forward launch; `log_done` (callable) is invoked once
@@ -188,10 +202,8 @@ class TransformerStackFn(torch.autograd.Function):
         seg = opts.get('seg')                              # int32 [S] block mask of disable_pairwise_lang_attn, or None
         fp8 = bool(opts.get('fp8', False))
         fp8_fc2 = fp8 and opts.get('fp8') != 'ln'
-        fp8_attn = opts.get('fp8') == 'all'              # + Q K^T and P V of the forward on the e4m3 MFMA
         need_bwd = ctx.needs_input_grad[0]
         log_bwd = bool(opts.get('log_in_backward', False)) and need_bwd and log_lo is not None
-        assert not (log_bwd and fp8_attn), "log_in_backward with the fp8 attention forward: the caller (modeling.py) must not ask for it"
         ctx.log = (log_lo, log_hi, opts.get('log_split'), opts.get('log_done')) if log_bwd else None
         if log_bwd:
             log_lo = log_hi = None                        # the forward launches carry no log side output
@@ -226,7 +238,7 @@ class TransformerStackFn(torch.autograd.Function):
             if f8_x1:
                 x1q, sx1, mean1, rstd1 = ln_q8t(f'{site}/{l}/x1', h, w.ln1)
                 x1 = None
-                w8, sw = ops.quantize_e4m3(w.qkv.wb)
+                w8, sw = _w8(stack.store, w.qkv.wb)
                 qkv = ops.gemm_fp8_nt(x1q, sx1, w8, sw, bias=w.qkv.b)
             elif fp8:
                 x1, x1q, rs1, mean1, rstd1 = ops.ln_fwd_q8(h, w.ln1.gamma, w.ln1.beta)
@@ -239,15 +251,7 @@ class TransformerStackFn(torch.autograd.Function):
                     x1, _, mean1, rstd1 = ops.ln_fwd(h, w.ln1.gamma, w.ln1.beta)
                 qkv = _fwd_linear(x1, w.qkv, False)
             # the attention-probability side outputs (a7) come out of the forward launch: K is still resident in LDS
-            if fp8_attn:
-                ctx_, lse = ops.attention_fwd_fp8(qkv, B, S, heads, valid, seg=seg)
-                if colsum is not None:
-                    ops.attention_colsum(qkv, lse, B, S, heads, colsum, valid=valid, valid_q_only=False, weight=1.0 / heads,
-                                         seg=seg)
-                if log_lo is not None:
-                    ops.attention_colsum(qkv, lse, B, S, heads, log_lo, log_hi, qsplit=opts['log_split'], valid=valid,
-                                         valid_q_only=True, weight=1.0 / heads, seg=seg)
-            elif colsum is not None and log_lo is None:
+            if colsum is not None and log_lo is None:
                 ctx_, lse = ops.attention_fwd(qkv, B, S, heads, valid, seg=seg, colsum_lo=colsum, valid_q_only=False,
                                               weight=1.0 / heads)
             elif log_lo is not None and colsum is None:
@@ -280,7 +284,7 @@ class TransformerStackFn(torch.autograd.Function):
             if f8_a:
                 # fc1 on e4m3 operands whose GELU epilogue ALSO writes the e4m3 copy of a (and, with 'noa', nothing else of it)
                 key = f'{site}/{l}/a'
-                w8, sw = ops.quantize_e4m3(w.fc1.wb)
+                w8, sw = _w8(stack.store, w.fc1.wb)
                 if f8.ready(key):
                     sa = f8.block(key, ops.F8_E4M3)
                     a, a8 = ops.gemm_fp8_nt_q8(x2q, sx2, w8, sw, sa, bias=w.fc1.b, aux_out=u, a_row_scale=rs2, keep_bf16=not no_a)
@@ -291,7 +295,7 @@ class TransformerStackFn(torch.autograd.Function):
                     if no_a:
                         a = None
             elif f8_x2:
-                w8, sw = ops.quantize_e4m3(w.fc1.wb)
+                w8, sw = _w8(stack.store, w.fc1.wb)
                 a = ops.gemm_fp8_nt(x2q, sx2, w8, sw, bias=w.fc1.b, epilogue=EPI_GELU, aux_out=u)
             else:
                 a = _fwd_linear(x2, w.fc1, fp8, x8=x2q, row_scale=rs2, epilogue=EPI_GELU, aux_out=u)
@@ -303,7 +307,7 @@ class TransformerStackFn(torch.autograd.Function):
                                                          dropout_seed=_site_seed(seed, l, 1))
                 nxt = (xn, meann, rstdn)
             elif a8 is not None and (fp8_fc2 or no_a):
-                w8, sw = ops.quantize_e4m3(w.fc2.wb)      # fc2 reads the copy fc1's epilogue wrote: no quantising pass over a
+                w8, sw = _w8(stack.store, w.fc2.wb)          # fc2 reads the copy fc1's epilogue wrote: no quantising pass over a
                 h_out = ops.gemm_fp8_nt(a8, sa, w8, sw, bias=w.fc2.b, epilogue=EPI_RESIDUAL, aux_in=h_mid, dropout_p=p,
                                         dropout_seed=_site_seed(seed, l, 1))
             else:
@@ -318,7 +322,6 @@ class TransformerStackFn(torch.autograd.Function):
             y, _, meanf, rstdf = ops.ln_fwd(h, stack.ln_final.gamma, stack.ln_final.beta)
         ctx.stack, ctx.B, ctx.S, ctx.valid, ctx.heads, ctx.p, ctx.seed, ctx.nl = stack, B, S, valid, heads, p, seed, nl
         ctx.seg = seg
-        ctx.fp8_attn = fp8_attn
         ctx.f8m, ctx.f8_site, ctx.fuse8 = f8m, site, fuse8
         ctx.saved = saved
         ctx.final = (h, meanf, rstdf)
@@ -387,7 +390,7 @@ class TransformerStackFn(torch.autograd.Function):
             else:
                 ops.gemm_tn(du, x2, w.fc1.gw)             # dW1[I, H]
             if dg1:
-                wt8, swt = ops.quantize_e4m3(w.fc1.wbT)
+                wt8, swt = _w8(store, w.fc1.wbT)
                 dx2 = ops.gemm_f8_nt(du8, sdu, wt8, swt)
             else:
                 dx2 = ops.gemm_nt(du, w.fc1.wbT)
@@ -406,28 +409,39 @@ class TransformerStackFn(torch.autograd.Function):
             #      GEMM that produces it;  K: identically 0 (adding a constant to every key shifts each query's scores by a
             #      constant: softmax does not move);  Q: the column sums of the first third of dQKV only.
             D = heads * 64
-            #   (fp8 attention forward: the saved log-sum-exp comes from e4m3 scores while the backward recomputes P from bf16
-            #   ones, so the rows of P no longer sum to exactly 1 and the shortcut does not hold: all three thirds are summed)
-            exact_rows = not ctx.fp8_attn
+            exact_rows = True                             # (False: sum all three thirds -- what the e4m3 attention forward of rounds 2-5 needed; it is gone)
             dctx = ops.gemm_nt(db1, w.proj.wbT, colsum_out=w.qkv.gb[2 * D:3 * D] if exact_rows else None)
+            akw = dict(seg=ctx.seg)
             if ctx.log is not None:
-                dqkv = ops.attention_bwd(qkv, ctx_, dctx, lse, B, S, heads, valid, seg=ctx.seg, log_lo=ctx.log[0], log_hi=ctx.log[1],
-                                         log_split=ctx.log[2], log_weight=1.0 / heads)
+                akw.update(log_lo=ctx.log[0], log_hi=ctx.log[1], log_split=ctx.log[2], log_weight=1.0 / heads)
+            dq8 = sdq = None
+            qkey = f'{site}/{l}/wqkv/dy'
+            # dqkv's 8-bit copy from the attention backward's own launches where the tiled kernel pair runs (config #5's 578 / 2 832 tokens); elsewhere a pass below
+            if 'wqkv' in f8m and big and x1q is not None and f8.ready(qkey) and ops.attention_bwd_writes_q8(S, ctx.seg is not None) and qkv.shape[0] % 128 == 0:
+                sdq = f8.block(qkey, gfmt)
+                dqkv, dq8 = ops.attention_bwd(qkv, ctx_, dctx, lse, B, S, heads, valid, q8_block=sdq, q8_fmt=gfmt, **akw)
+                f8.dirty = True
             else:
-                dqkv = ops.attention_bwd(qkv, ctx_, dctx, lse, B, S, heads, valid, seg=ctx.seg)
+                dqkv = ops.attention_bwd(qkv, ctx_, dctx, lse, B, S, heads, valid, **akw)
             # (round 6: the Q third's column sums come out of the weight-gradient launch below -- its A fragments are dQKV)
             cs_q = w.qkv.gb[:D] if exact_rows else w.qkv.gb
-            if 'wqkv' in f8m and big and x1q is not None:  # x1's copy came out of its LayerNorm; dqkv has no such producer: one pass
-                dq8, sdq = f8.quantize(f'{site}/{l}/wqkv/dy', dqkv, gfmt)
+            if 'wqkv' in f8m and big and x1q is not None:  # x1's copy came out of its LayerNorm; dqkv's out of the attention backward where the tiled pair
+                if dq8 is None:                            # runs -- elsewhere (the fused / persistent kernels of <= 512 tokens) one pass (delayed scale), which
+                    dq8, sdq = f8.quantize(qkey, dqkv, gfmt)   # pays once BOTH of dqkv's consumers read the copy ('dgradqkv')
                 ops.colsum_bf16(dqkv[:, :cs_q.numel()], cs_q)
                 ops.gemm_f8_tn(dq8, sdq, x1q, sx1, w.qkv.gw)
-                dq8 = x1q = None
+                x1q = None
             elif TN_COLSUM:
                 _wgrad(f8 if 'wqkv' in f8m else None, f'{site}/{l}/wqkv', dqkv, x1, w.qkv.gw, gfmt, colsum_a=cs_q)
             else:
                 ops.colsum_bf16(dqkv[:, :D] if exact_rows else dqkv, cs_q)
                 ops.gemm_tn(dqkv, x1, w.qkv.gw)
-            dx1 = ops.gemm_nt(dqkv, w.qkv.wbT)
+            if dq8 is not None and 'dgradqkv' in f8m:      # the QKV input gradient (K = 2 304) on the same copy
+                wt8, swt = _w8(store, w.qkv.wbT)
+                dx1 = ops.gemm_f8_nt(dq8[:dqkv.shape[0]], sdq, wt8, swt)
+            else:
+                dx1 = ops.gemm_nt(dqkv, w.qkv.wbT)
+            dq8 = None
             if l > 0:
                 dh, db2, db2_8, sdb2 = ln_bwd8(f'{site}/{l - 1}/db2', 'w2' in f8m, dx1, h, mean1, rstd1, w.ln1.gamma, w.ln1.ggamma, w.ln1.gbeta, dres=dh_mid,
                                                branch_bias_grad=stack.layers[l - 1].fc2.gb, drop_p=p, drop_seed=_site_seed(seed, l - 1, 1))

@@ -240,10 +240,8 @@ class MerlotModel(object):
             # reference reads these metrics at the end of the train step too (model/modeling.py:709).  Without a backward
             # (inference, forward-only timing) and by default they are complete right after construction.
             opts.update(log_lo=log_lo, log_hi=log_hi, log_split=self.P, log_done=finish_log,
-                        # decided HERE, once: the fp8 attention forward (fp8_forward = 'all') has no log in its backward (the stack would
-                        # silently keep the log in the forward and nobody would finish it: ADVICE r4)
-                        log_in_backward=(bool(cfg.get('attention_log_in_backward', False)) and is_training and torch.is_grad_enabled()
-                                         and cfg.get('fp8_forward', False) != 'all'))
+                        # decided HERE, once (the stack must not silently keep the log in the forward where nobody finishes it)
+                        log_in_backward=(bool(cfg.get('attention_log_in_backward', False)) and is_training and torch.is_grad_enabled()))
         enc = L.transformer_stack(encoder_input.reshape(self.B * Sj, H), self._enc, self.B, Sj,
                                   is_valid.to(torch.uint8).contiguous(), opts)
         enc3 = enc.view(self.B, Sj, H)

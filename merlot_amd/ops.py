@@ -466,30 +466,28 @@ def amax_groups(x, groups):
     return out
 
 
-def attention_fwd_fp8(qkv, B, S, heads, valid=None, scale=None, seg=None, amax3=None):
-    """attention_fwd with Q K^T and P V on the e4m3 MFMA (per-tensor scales from amax3 = amax_groups(qkv, 3)) -> (out, lse)."""
-    _chk(qkv, BF16, 'qkv')
-    D = heads * 64
-    scale = scale if scale is not None else 1.0 / 8.0
-    if amax3 is None:
-        amax3 = amax_groups(qkv[:, :3 * D], 3)
-    _chk(amax3, F32, 'amax3')
-    out = torch.empty((B * S, D), device=qkv.device, dtype=BF16)
-    lse = torch.empty((B, heads, S), device=qkv.device, dtype=F32)
-    call('merlot_attention_fwd_fp8', _p(qkv), qkv.stride(0), _p(out), out.stride(0), _p(lse), _p(valid), _p(seg), B, S, heads,
-         float(scale), _p(amax3), _stream())
-    return out, lse
+def attention_bwd_writes_q8(S, has_seg):
+    """whether merlot_attention_bwd_q8 exists for this shape (the tiled dQ / dK dV kernel pair: > 512 tokens, a segment mask, or <= 64 tokens)"""
+    return bool(LIB.query('merlot_attention_bwd_writes_q8', int(S), 1 if has_seg else 0))
 
 
-def attention_bwd(qkv, out, dout, lse, B, S, heads, valid=None, seg=None, log_lo=None, log_hi=None, log_split=None, log_weight=1.0):
+def attention_bwd(qkv, out, dout, lse, B, S, heads, valid=None, seg=None, log_lo=None, log_hi=None, log_split=None, log_weight=1.0,
+                  q8_block=None, q8_fmt=F8_E5M2):
     """log_lo / log_hi (f32 [B, S], accumulated): the attention LOG side output (valid pairs only, queries below / from log_split),
-    taken from the backward's own P instead of a second Q K^T walk in the forward (merlot_hip.h, merlot_attention_bwd)."""
+    taken from the backward's own P instead of a second Q K^T walk in the forward (merlot_hip.h, merlot_attention_bwd).
+    q8_block (f32[4]; shapes with attention_bwd_writes_q8 only): also the 8-bit float copy of dqkv, scaled by block[0], max|dqkv| -> block[3]; returns (dqkv, dqkv8)."""
     _chk(dout, BF16, 'dout'); _chk(seg, torch.int32, 'seg'); _chk(log_lo, F32, 'log_lo'); _chk(log_hi, F32, 'log_hi')
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, heads, S), device=qkv.device, dtype=F32)
-    call('merlot_attention_bwd', _p(qkv), qkv.stride(0), _p(out), out.stride(0), _p(dout), dout.stride(0), _p(lse),
-         _p(valid), _p(seg), _p(dqkv), dqkv.stride(0), _p(delta), B, S, heads, 0.125, _p(log_lo), _p(log_hi),
-         S if log_split is None else int(log_split), float(log_weight), *_attn_ws(), _stream())
+    args = (_p(qkv), qkv.stride(0), _p(out), out.stride(0), _p(dout), dout.stride(0), _p(lse),
+            _p(valid), _p(seg), _p(dqkv), dqkv.stride(0), _p(delta), B, S, heads, 0.125, _p(log_lo), _p(log_hi),
+            S if log_split is None else int(log_split), float(log_weight))
+    if q8_block is not None:
+        _chk(q8_block, F32, 'q8_block')
+        dqkv8 = torch.empty(qkv.shape, device=qkv.device, dtype=_F8_DTYPES[q8_fmt])
+        call('merlot_attention_bwd_q8', *args, _p(dqkv8), dqkv8.stride(0), int(q8_fmt), _p(q8_block), *_attn_ws(), _stream())
+        return dqkv, dqkv8
+    call('merlot_attention_bwd', *args, *_attn_ws(), _stream())
     return dqkv
 
 

@@ -305,6 +305,37 @@ def test_gemm_f8_nt_with_an_e5m2_operand_equals_matmul_of_the_dequantised_operan
     assert float((out.double() - ref).norm() / ref.norm()) < 3e-3
 
 
+@pytest.mark.parametrize('B,S,masked,fmt', [(4, 578, False, 1), (2, 700, True, 1), (3, 578, False, 0), (5, 40, True, 1)])
+def test_attention_bwd_copy_equals_the_pass_over_dqkv(B, S, masked, fmt):
+    """merlot_attention_bwd_q8 (the tiled dQ / dK dV pair: config #5's sequence lengths): dqkv identical to the plain entry's, the copy bit-equal to the
+    conversion of the bf16 dqkv with the block's scale, the amax recorded; shapes another kernel takes are refused."""
+    ops = _ops()
+    from merlot_amd.lib import MerlotHipError
+    heads = 12
+    g = torch.Generator(device='cuda').manual_seed(S)
+    qkv = torch.randn(B * S, 3 * heads * 64, device='cuda', generator=g).bfloat16()
+    valid = None
+    if masked:
+        valid = torch.ones(B, S, dtype=torch.uint8, device='cuda')
+        valid[:, S - 7:] = 0
+    out, lse = ops.attention_fwd(qkv, B, S, heads, valid)
+    dout = (torch.randn(B * S, heads * 64, device='cuda', generator=g) * 1e-2).bfloat16()
+    ref = ops.attention_bwd(qkv, out, dout, lse, B, S, heads, valid)
+    assert ops.attention_bwd_writes_q8(S, False)
+    s = FMAX[fmt] / float(ref.float().abs().max()) * 0.8
+    blk = _block(s, fmt)
+    dqkv, dq8 = ops.attention_bwd(qkv, out, dout, lse, B, S, heads, valid, q8_block=blk, q8_fmt=fmt)
+    assert torch.equal(dqkv, ref)
+    assert torch.equal(dq8.view(torch.uint8), _q(ref, s, fmt).view(torch.uint8))
+    assert blk[3].item() == float(ref.float().abs().max())
+    assert not ops.attention_bwd_writes_q8(328, False) and ops.attention_bwd_writes_q8(328, True)
+    if S > 512:
+        q2 = qkv[:B * 328].contiguous()
+        o2, l2 = ops.attention_fwd(q2, B, 328, heads, None)
+        with pytest.raises(MerlotHipError):
+            ops.attention_bwd(q2, o2, dout[:B * 328].contiguous(), l2, B, 328, heads, None, q8_block=blk, q8_fmt=fmt)
+
+
 def test_scale_rotate_turns_recorded_amaxes_into_scales():
     ops = _ops()
     blocks = torch.tensor([[2.0, 0.5, 224.0, 112.0], [3.0, 1 / 3.0, 5.0, 0.0], [1.0, 1.0, 0.0, 7.0]], device='cuda')
@@ -316,7 +347,7 @@ def test_scale_rotate_turns_recorded_amaxes_into_scales():
     assert b[2].tolist() == [8192.0, 1 / 8192.0, 7.0, 0.0]            # e5m2: 57 344 / 7
 
 
-@pytest.mark.parametrize('modes', ['w1,w2,fuse', 'w1,w2,wqkv,wproj,fuse,noa', 'w1,w2,fuse,noa,dgrad1'])
+@pytest.mark.parametrize('modes', ['w1,w2,fuse', 'w1,w2,wqkv,wproj,fuse,noa', 'w1,w2,fuse,noa,dgrad1', 'w1,w2,wqkv,fuse,noa,dgrad1,dgradqkv'])
 def test_config5_geometry_fused_fp8_backward_three_steps(modes):
     """`fp8_backward` with 'fuse' at a batch whose row counts are multiples of 256 (16 examples of 16 frames at 384^2: 147 968 ViT rows, 45 312 joint
     rows, 8 192 text rows): step 0 calibrates every site (current scaling), steps 1 and 2 run on the producers' own copies with delayed scales.  Against

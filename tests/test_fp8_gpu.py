@@ -180,37 +180,6 @@ def _attn_ref(qkv, B, S, heads, valid=None):
     return (torch.softmax(sc, -1) @ v).permute(0, 2, 1, 3).reshape(B * S, D)
 
 
-@pytest.mark.parametrize('B,S,heads,masked', [(2, 198, 12, False), (3, 328, 12, True), (1, 2832, 12, True), (5, 100, 4, True), (2, 64, 12, False)])
-def test_attention_fwd_fp8_against_fp32_softmax_attention(B, S, heads, masked):
-    """Q K^T and P V on the e4m3 MFMA with per-tensor scales: against fp32 attention of the same bf16 inputs, and beside the
-    bf16 kernel's own error.  The long sequence (config #5's joint S = 2832) is the case the 2^8 scale on P exists for: its
-    probabilities (~3.5e-4) would flush to zero in e4m3 unscaled."""
-    ops = _ops()
-    g = torch.Generator(device='cpu').manual_seed(B * 1000 + S)
-    qkv = (torch.randn(B * S, 3 * heads * 64, generator=g) * 0.7).to(torch.bfloat16).to(_dev())
-    valid = None
-    if masked:
-        valid = torch.ones(B, S, dtype=torch.uint8)
-        for b in range(B):
-            valid[b, S - 1 - 7 * b - (S // 5):] = 0
-        valid = valid.to(_dev())
-    want = _attn_ref(qkv, B, S, heads, valid)
-    o16, lse16 = ops.attention_fwd(qkv, B, S, heads, valid)
-    amax3 = ops.amax_groups(qkv, 3)
-    assert torch.equal(amax3.cpu(), qkv.float().abs().view(B * S, 3, -1).amax(dim=(0, 2)).cpu())
-    o8, lse8 = ops.attention_fwd_fp8(qkv, B, S, heads, valid, amax3=amax3)
-    rows = slice(None) if valid is None else valid.view(-1).bool()          # padded QUERY rows attend uniformly; compared too below
-    e16 = ((o16.float() - want)[rows].norm() / want[rows].norm()).item()
-    e8 = ((o8.float() - want)[rows].norm() / want[rows].norm()).item()
-    assert e16 < 8e-3
-    assert e8 < 6e-2, (e8, e16)                              # e4m3 operands: 2^-4 per element, averaged over 64-d dot products and S keys
-    assert (lse8 - lse16).abs().max().item() < 5e-2
-    assert torch.isfinite(o8.float()).all()
-    if valid is not None:                                    # padded query rows: uniform attention over all keys, as the reference
-        pad = ~valid.view(-1).bool()
-        assert ((o8.float() - o16.float())[pad].abs().max().item()) < 5e-2
-
-
 def test_gemm_fp8_rejects_what_the_kernel_cannot_take():
     ops = _ops()
     a = torch.randn(256, 192, device=_dev()).to(torch.bfloat16)
@@ -233,7 +202,7 @@ def test_config5_geometry_fp8_forward_loss_within_2e2_of_bf16():
     from oracle import merlot_oracle as mo
     out = {}
     b = None
-    for fp8 in (False, True, 'ln', 'all'):
+    for fp8 in (False, True, 'ln'):
         cfg = tiny_config(image_size=[384, 384], num_chunks_in_group=16, max_position_embeddings=1024, fp8_forward=fp8,
                           masking_use_attn=False, attention_log_in_backward=True)      # MLM targets from the noise alone: identical in both runs
         if b is None:
@@ -253,7 +222,7 @@ def test_config5_geometry_fp8_forward_loss_within_2e2_of_bf16():
                         log=torch.stack([pm.attention_log[k] for k in sorted(pm.attention_log)]).float().cpu(),
                         lang=pm.encoder_hidden_states['lang'].float().cpu(),
                         masked=pm.lang_mask_info['masked_idx'].cpu(), grads={k: v.float().cpu() for k, v in st.export_tf_grads().items()})
-    for mode in (True, 'ln', 'all'):     # QKV + fc1 (per-row, from the LayerNorm) + fc2 (per-tensor) | without fc2 | + attention forward
+    for mode in (True, 'ln'):     # QKV + fc1 (per-row, from the LayerNorm) + fc2 (per-tensor) | without fc2
         for a, c in zip(out[False]['losses'], out[mode]['losses']):
             assert abs(a - c) < 2e-2, (mode, out[False]['losses'], out[mode]['losses'])
         assert abs(sum(out[False]['losses']) - sum(out[mode]['losses'])) < 2e-2

@@ -117,16 +117,28 @@ def test_gemm_main_loops():
     lines = _compile('gemm.hip')
     # ping-pong NT kernel, two phases per K-tile: 32 MFMAs per wave and K-tile, 24 fragment reads; 56 vector-ALU instructions before the bases were pinned
     for epi in range(4):
-        body, vg = _kernel(lines, r'gemm_nt_p8_kernelILi%dELb0ELb0ELb1ELb0E' % epi)          # <EPI, bf16 out, bf16 operands, two phases, no LayerNorm fold>
+        body, vg = _kernel(lines, r'gemm_nt_p8_kernelILi%dELb0ELb0ELb1ELb0ELi0ELi0E' % epi)   # <EPI, bf16 out, bf16 operands, two phases, no LayerNorm fold, no 8-bit copy, A format 0>
         steady = _loops(body, 32, inner_labels=True)
         assert len(steady) == 1 and _valu(steady[0]) <= 50 and steady[0]['ds_read_b128'] == 24, (epi, steady)
         assert 'scratch_load_dwordx4' not in steady[0] and 'scratch_store_dwordx4' not in steady[0]
     # the RESIDUAL kernel that also emits LayerNorm(C) (round 6): the same main loop -- no scratch, 24 fragment reads; its extra epilogue state costs address
     # arithmetic in the loop (66 vector-ALU instructions when first built)
-    body, vg = _kernel(lines, r'gemm_nt_p8_kernelILi2ELb0ELb0ELb1ELb1E')
+    body, vg = _kernel(lines, r'gemm_nt_p8_kernelILi2ELb0ELb0ELb1ELb1ELi0ELi0E')
     steady = _loops(body, 32, inner_labels=True)
     assert len(steady) == 1 and _valu(steady[0]) <= 70 and steady[0]['ds_read_b128'] == 24, steady
     assert 'scratch_load_dwordx4' not in steady[0] and 'scratch_store_dwordx4' not in steady[0] and 'scratch_load_dword' not in steady[0]
+    # round 6, the 8-bit kernels.  The epilogues that also write an 8-bit copy (Q8 = 1 / 2 / 5 / 6) must not spill: their first version carried four more kernel
+    # arguments and a 64-bit lane pointer through an epilogue already at 250 registers -- 384 .. 448 bytes of scratch per lane, launches 39 - 60 % slower
+    # (profiles/r06_n_f8_producers.txt); with the epilogue operands re-read from the kernel-argument segment and a 32-bit lane offset they have the base kernels' 48 bytes
+    for pat in (r'ILi1ELb0ELb1ELb1ELb0ELi1ELi0E', r'ILi1ELb0ELb1ELb1ELb0ELi5ELi0E', r'ILi3ELb0ELb0ELb1ELb0ELi2ELi0E', r'ILi3ELb0ELb0ELb1ELb0ELi6ELi0E',
+                r'ILi3ELb0ELb0ELb1ELb0ELi1ELi0E', r'ILi3ELb0ELb0ELb1ELb0ELi5ELi0E'):
+        starts = [l for l in lines if re.match(r'\s*\.set _ZN\S*gemm_nt_p8_kernel' + pat + r'\S*\.private_seg_size, (\d+)', l)]
+        assert len(starts) == 1 and int(starts[0].rsplit(',', 1)[1]) <= 48, (pat, starts)
+    # the 8-bit weight gradient: one K-tile = 48 transposing byte reads + 16 scaled MFMAs, nothing else in the vector ALU, no scratch
+    body, vg = _kernel(lines, r'gemm_tn_q8_kernelILi1ELi0E')
+    steady = [c for c in _loops(body, 16, inner_labels=True) if c['ds_read_b64_tr_b8'] == 48 and sum(c.values()) < 200]
+    assert len(steady) == 1 and _valu(steady[0]) <= 6 and steady[0]['v_mfma_scale_f32_32x32x64_f8f6f4'] == 16, steady
+    assert vg <= 240 and not any('scratch_' in l for l in body)
     # one-phase TN kernel: 48 transposing reads, 32 MFMAs; 18 vector-ALU instructions before the B base was pinned
     body, vg = _kernel(lines, r'gemm_tn_p1_kernelILb0E')
     steady = [c for c in _loops(body, 32, inner_labels=True) if c['ds_read_b64_tr_b16'] == 48 and sum(c.values()) < 200]
