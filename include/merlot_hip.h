@@ -167,7 +167,7 @@ int merlot_gemm_f8_tn(const void* A8, int64_t lda, int fmt_a, const float* deq_a
  * q8_out[M, N] = f8(clamp(bf16(C) * q8_scale[0])) (q8_fmt 0 = e4m3, 1 = e5m2; the fp8-operand entry: e4m3 only) and max |bf16(C)| into q8_scale[3]
  * (atomic max).  C may be NULL: the bf16 output is then not stored at all.  DELAYED scaling: q8_scale[0] comes from an earlier step's amax --
  * merlot_f8_scale_rotate(blocks, n, fmts) on the stream in front of the producers turns every block's recorded amax ([3], if > 0) into its {s, 1/s, amax}
- * and clears the record; a block's first scale comes from merlot_quantize_f8 (current).  M, N multiples of 256, operands 16-byte aligned, leading
+ * and clears the record; a block's first scale comes from merlot_quantize_f8 (current).  N a multiple of 256, operands 16-byte aligned, leading
  * dimensions multiples of 8 (fp8 operands: lda / ldb of 16); other arguments as the base entries. */
 int merlot_f8_scale_rotate(float* blocks, int n, const int32_t* fmts, merlot_stream_t stream);
 /* C[M,N] (bf16) = alpha * scale_a[0] * scale_b[0] * A8[M,K] * B8t[N,K]^T + bias with A8 in e4m3 (fmt_a 0) or e5m2 (fmt_a 1: a gradient tensor -- the input-gradient

@@ -430,8 +430,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTNArgs p) {
 // and then works on whole row segments: a lane owns 8 consecutive columns, so the output store, the residual /
 // pre-activation loads and the bias loads are all 16-32 B per lane and 128-512 contiguous bytes per row.
 // ------------------------------------------------------------------------------------------------
-template <int EPI, bool OUT_F32, bool FOLD = false>
-__device__ __forceinline__ void epilogue_row8(const GemmNTArgs& p, int m, int n, float (&v)[8], float* cacc = nullptr) {
+template <int EPI, bool OUT_F32, bool FOLD = false, int Q8 = 0>
+__device__ __forceinline__ void epilogue_row8(const GemmNTArgs& p, int m, int n, float (&v)[8], float* cacc = nullptr, float* q8_m = nullptr) {
     // v = alpha * acc for columns n..n+7 of row m (FOLD: the raw accumulators, see nt_epilogue_quad); n + 7 < N guaranteed, 16-B alignment
     // guaranteed by the caller
     if DBG_BIT(p, 8) {                                     // experiments: epilogue arithmetic + staging, no memory ops
@@ -517,10 +517,34 @@ __device__ __forceinline__ void epilogue_row8(const GemmNTArgs& p, int m, int n,
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-        *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + n) = o;
+        if constexpr (!(Q8 & 4)) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + n) = o;
         if (cacc) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) cacc[e] += (float)o[e];
+        }
+        if constexpr (Q8 != 0) {                         // the 8-bit copy in a row block's ragged last tile: the block of fast_tile_epilogue, per row
+            constexpr float FMAX8 = (Q8 & 3) == 1 ? 448.f : 57344.f;
+            const float q8_s = p.q8_scale[0];
+            float mx = *q8_m, f[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                mx = fmaxf(mx, fabsf(v[e]));
+                f[e] = __builtin_amdgcn_fmed3f(v[e] * q8_s, -FMAX8, FMAX8);
+            }
+            *q8_m = mx;
+            int w0 = 0, w1 = 0;
+            if constexpr ((Q8 & 3) == 1) {
+                w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w0, false);
+                w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
+                w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], w1, false);
+                w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
+            } else {
+                w0 = __builtin_amdgcn_cvt_pk_bf8_f32(f[0], f[1], w0, false);
+                w0 = __builtin_amdgcn_cvt_pk_bf8_f32(f[2], f[3], w0, true);
+                w1 = __builtin_amdgcn_cvt_pk_bf8_f32(f[4], f[5], w1, false);
+                w1 = __builtin_amdgcn_cvt_pk_bf8_f32(f[6], f[7], w1, true);
+            }
+            *reinterpret_cast<u32x2*>(p.q8_out + (int64_t)m * p.ld_q8 + n) = u32x2{(uint32_t)w0, (uint32_t)w1};
         }
     }
 }
@@ -803,9 +827,9 @@ __global__ __launch_bounds__(C::NT, ring_occ<C>::value) void gemm_nt_ring_kernel
 // Counted vmcnt stays valid across the epilogue's own loads/stores: loads complete in order, so "<= (S-2)*LOADS
 // outstanding" still implies stage t has landed; stores only make the wait more conservative.
 // ------------------------------------------------------------------------------------------------
-template <int EPI, bool OUT_F32, bool RS = false>
+template <int EPI, bool OUT_F32, bool RS = false, int Q8 = 0>
 __device__ __forceinline__ void slab_epilogue(const GemmNTArgs& p, const f32x16& acc0, const f32x16& acc1, char* slab,
-                                              int m_base, int n_base, int lane) {
+                                              int m_base, int n_base, int lane, float* q8_m = nullptr) {
     // slab: [32 rows][64 cols] fp32, 16-B chunk index XOR (row & 15); acc0 = columns 0..31, acc1 = columns 32..63
     const int hi = lane >> 5;
     const int row = lane & 31;
@@ -844,7 +868,7 @@ __device__ __forceinline__ void slab_epilogue(const GemmNTArgs& p, const f32x16&
                 v[e] = x0[e];
                 v[4 + e] = x1[e];
             }
-            epilogue_row8<EPI, OUT_F32, !RS>(p, m, n, v, (!OUT_F32 && p.colsum) ? cacc : nullptr);
+            epilogue_row8<EPI, OUT_F32, !RS, Q8>(p, m, n, v, (!OUT_F32 && p.colsum) ? cacc : nullptr, q8_m);
         } else {
             float q0[4] = {x0[0], x0[1], x0[2], x0[3]}, q1[4] = {x1[0], x1[1], x1[2], x1[3]};
             const bool vec_ok = ((p.ldc & 3) == 0) && ((p.ld_aux_in & 3) == 0) && ((p.ld_aux_out & 3) == 0);
@@ -1896,7 +1920,7 @@ extern "C" int merlot_gemm_bf16_nt_q8(const void* A, int64_t lda, const void* Bt
     a.ctr = (unsigned int*)workspace;
     a.q8_out = (uint8_t*)q8_out; a.ld_q8 = ld_q8; a.q8_scale = q8_scale; a.q8_amax = reinterpret_cast<unsigned int*>(q8_scale + 3);
     MERLOT_CHECK(p8_q8_ok(a, false), MERLOT_ESHAPE,
-                 "merlot_gemm_bf16_nt_q8: needs M, N multiples of 256, K %% 64 == 0, leading dimensions multiples of 8 and 16-byte aligned operands under 4 GiB "
+                 "merlot_gemm_bf16_nt_q8: needs N a multiple of 256, K %% 64 == 0, leading dimensions multiples of 8 and 16-byte aligned operands under 4 GiB "
                  "(M=%lld N=%lld K=%lld)", (long long)M, (long long)N, (long long)K);
     return nt_status(launch_p8_q8(a, epilogue, q8_mode(q8_fmt, C), (hipStream_t)stream, false), workspace, (hipStream_t)stream);
 }
@@ -1923,7 +1947,7 @@ extern "C" int merlot_gemm_fp8_nt_q8(const void* A8, int64_t lda, const float* s
     a.ctr = (unsigned int*)workspace;
     a.q8_out = (uint8_t*)q8_out; a.ld_q8 = ld_q8; a.q8_scale = q8_scale; a.q8_amax = reinterpret_cast<unsigned int*>(q8_scale + 3);
     MERLOT_CHECK(p8_q8_ok(a, true), MERLOT_ESHAPE,
-                 "merlot_gemm_fp8_nt_q8: needs M, N multiples of 256, K %% 128 == 0, lda / ldb multiples of 16, the other leading dimensions of 8 and 16-byte "
+                 "merlot_gemm_fp8_nt_q8: needs N a multiple of 256, K %% 128 == 0, lda / ldb multiples of 16, the other leading dimensions of 8 and 16-byte "
                  "aligned operands under 4 GiB (M=%lld N=%lld K=%lld)", (long long)M, (long long)N, (long long)K);
     return nt_status(launch_p8_q8(a, epilogue, q8_mode(q8_fmt, C), (hipStream_t)stream, true), workspace, (hipStream_t)stream);
 }

@@ -142,8 +142,8 @@ def _f8_modes(opt):
     """`model.fp8_backward`: False / None, or a comma-separated list of what runs on 8-bit operands in the backward: w1, w2, wqkv, wproj = that weight
     gradient through merlot_gemm_f8_tn (gradient operand e5m2, activation operand e4m3; 'e4m3' in the list: gradients in e4m3 too); 'fuse': the 8-bit
     copies of x1 / x2 (LayerNorm), a (fc1's GELU epilogue), du (the GELU' epilogue) and the branch gradients (LayerNorm backward) come out of the launches
-    that produce those tensors instead of quantising passes (needs fp8_forward and row counts that are multiples of 256; dqkv and the attention output
-    have no such producer and keep their pass); 'noa': with 'fuse' and w2, fc1 does not store its bf16 output at all (fc2 reads the e4m3 copy); 'dgradqkv': with 'fuse' and wqkv, the QKV input-gradient GEMM (K = 2 304) reads dqkv's copy too (then the one quantising pass over dqkv pays);
+    that produce those tensors instead of quantising passes (needs fp8_forward and at least 2 048 rows; the attention output has no such
+    producer, dqkv only where the tiled attention backward runs: they keep their pass); 'noa': with 'fuse' and w2, fc1 does not store its bf16 output at all (fc2 reads the e4m3 copy); 'dgradqkv': with 'fuse' and wqkv, the QKV input-gradient GEMM (K = 2 304) reads dqkv's copy too (then the one quantising pass over dqkv pays);
     'dgrad1': with 'fuse' and w1, fc1's input-gradient GEMM
     (K = 3 072) reads du's 8-bit copy as well and the GELU' epilogue does not store du in bf16 at all.  True = 'w1,w2,fuse'."""
     if not opt:
@@ -217,7 +217,7 @@ class TransformerStackFn(torch.autograd.Function):
         f8m = _f8_modes(opts.get('fp8_bwd')) if need_bwd else frozenset()
         site = opts.get('f8_site', stack.scope)           # which use of the stack (the joint and the text-only pass share weights, not activations)
         T = h.shape[0]
-        fuse8 = 'fuse' in f8m and fp8 and T % 256 == 0 and T >= 2048
+        fuse8 = 'fuse' in f8m and fp8 and T >= 2048       # (any row count: the copies are allocated in whole K-tiles of 128 rows, the padding zero)
         f8 = f8_scales(stack.store) if fuse8 else None
         f8_x1, f8_x2, f8_a = fuse8 and 'wqkv' in f8m, fuse8 and 'w1' in f8m, fuse8 and 'w2' in f8m
         no_a = f8_a and 'noa' in f8m
@@ -239,7 +239,7 @@ class TransformerStackFn(torch.autograd.Function):
                 x1q, sx1, mean1, rstd1 = ln_q8t(f'{site}/{l}/x1', h, w.ln1)
                 x1 = None
                 w8, sw = _w8(stack.store, w.qkv.wb)
-                qkv = ops.gemm_fp8_nt(x1q, sx1, w8, sw, bias=w.qkv.b)
+                qkv = ops.gemm_fp8_nt(x1q[:T], sx1, w8, sw, bias=w.qkv.b)
             elif fp8:
                 x1, x1q, rs1, mean1, rstd1 = ops.ln_fwd_q8(h, w.ln1.gamma, w.ln1.beta)
                 qkv = _fwd_linear(x1, w.qkv, True, x8=x1q, row_scale=rs1)
@@ -287,16 +287,16 @@ class TransformerStackFn(torch.autograd.Function):
                 w8, sw = _w8(stack.store, w.fc1.wb)
                 if f8.ready(key):
                     sa = f8.block(key, ops.F8_E4M3)
-                    a, a8 = ops.gemm_fp8_nt_q8(x2q, sx2, w8, sw, sa, bias=w.fc1.b, aux_out=u, a_row_scale=rs2, keep_bf16=not no_a)
+                    a, a8 = ops.gemm_fp8_nt_q8(x2q[:T], sx2, w8, sw, sa, bias=w.fc1.b, aux_out=u, a_row_scale=rs2, keep_bf16=not no_a)
                     f8.dirty = True
                 else:
-                    a = ops.gemm_fp8_nt(x2q, sx2, w8, sw, bias=w.fc1.b, a_row_scale=rs2, epilogue=EPI_GELU, aux_out=u)
+                    a = ops.gemm_fp8_nt(x2q[:T], sx2, w8, sw, bias=w.fc1.b, a_row_scale=rs2, epilogue=EPI_GELU, aux_out=u)
                     a8, sa = f8.calibrate(key, a, ops.F8_E4M3)
                     if no_a:
                         a = None
             elif f8_x2:
                 w8, sw = _w8(stack.store, w.fc1.wb)
-                a = ops.gemm_fp8_nt(x2q, sx2, w8, sw, bias=w.fc1.b, epilogue=EPI_GELU, aux_out=u)
+                a = ops.gemm_fp8_nt(x2q[:T], sx2, w8, sw, bias=w.fc1.b, epilogue=EPI_GELU, aux_out=u)
             else:
                 a = _fwd_linear(x2, w.fc1, fp8, x8=x2q, row_scale=rs2, epilogue=EPI_GELU, aux_out=u)
             if not f8_x2:
@@ -308,7 +308,7 @@ class TransformerStackFn(torch.autograd.Function):
                 nxt = (xn, meann, rstdn)
             elif a8 is not None and (fp8_fc2 or no_a):
                 w8, sw = _w8(stack.store, w.fc2.wb)          # fc2 reads the copy fc1's epilogue wrote: no quantising pass over a
-                h_out = ops.gemm_fp8_nt(a8, sa, w8, sw, bias=w.fc2.b, epilogue=EPI_RESIDUAL, aux_in=h_mid, dropout_p=p,
+                h_out = ops.gemm_fp8_nt(a8[:T], sa, w8, sw, bias=w.fc2.b, epilogue=EPI_RESIDUAL, aux_in=h_mid, dropout_p=p,
                                         dropout_seed=_site_seed(seed, l, 1))
             else:
                 h_out = _fwd_linear(a, w.fc2, fp8_fc2, epilogue=EPI_RESIDUAL, aux_in=h_mid, dropout_p=p,
@@ -391,7 +391,7 @@ class TransformerStackFn(torch.autograd.Function):
                 ops.gemm_tn(du, x2, w.fc1.gw)             # dW1[I, H]
             if dg1:
                 wt8, swt = _w8(store, w.fc1.wbT)
-                dx2 = ops.gemm_f8_nt(du8, sdu, wt8, swt)
+                dx2 = ops.gemm_f8_nt(du8[:h.shape[0]], sdu, wt8, swt)
             else:
                 dx2 = ops.gemm_nt(du, w.fc1.wbT)
             du = du8 = x2q = None
@@ -417,7 +417,7 @@ class TransformerStackFn(torch.autograd.Function):
             dq8 = sdq = None
             qkey = f'{site}/{l}/wqkv/dy'
             # dqkv's 8-bit copy from the attention backward's own launches where the tiled kernel pair runs (config #5's 578 / 2 832 tokens); elsewhere a pass below
-            if 'wqkv' in f8m and big and x1q is not None and f8.ready(qkey) and ops.attention_bwd_writes_q8(S, ctx.seg is not None) and qkv.shape[0] % 128 == 0:
+            if 'wqkv' in f8m and big and x1q is not None and f8.ready(qkey) and ops.attention_bwd_writes_q8(S, ctx.seg is not None):
                 sdq = f8.block(qkey, gfmt)
                 dqkv, dq8 = ops.attention_bwd(qkv, ctx_, dctx, lse, B, S, heads, valid, q8_block=sdq, q8_fmt=gfmt, **akw)
                 f8.dirty = True

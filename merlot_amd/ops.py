@@ -274,6 +274,16 @@ def gemm_f8_nt(a8, a_scale, bt8, b_scale, *, bias=None, alpha=1.0):
     return out
 
 
+def _f8_rows(rows, cols, dtype, device, row_multiple=128):
+    """an 8-bit tensor for `rows` rows whose allocation is padded to a multiple of 128 rows (merlot_gemm_f8_tn's K-tile), the padding zeroed: producers
+    write rows [0, rows), the weight gradient reads all of it"""
+    rp = (rows + row_multiple - 1) // row_multiple * row_multiple
+    t = torch.empty((rp, cols), device=device, dtype=dtype)
+    if rp > rows:
+        t[rows:].zero_()
+    return t
+
+
 def f8_scale_rotate(blocks, n, fmts):
     """blocks f32 [>= n, 4], fmts int32 [>= n]: every block whose producers recorded an amax ([3] > 0) gets {s, 1/s, amax} from it, the record is cleared."""
     _chk(blocks, F32, 'blocks'); _chk(fmts, torch.int32, 'fmts')
@@ -288,7 +298,7 @@ def ln_fwd_q8t(x, gamma, beta, block, *, out_bf16=False, eps=1e-5):
     H = x.shape[-1]
     rows = x.numel() // H
     y16 = torch.empty(x.shape, device=x.device, dtype=BF16) if out_bf16 else None
-    y8 = torch.empty(x.shape, device=x.device, dtype=FP8)
+    y8 = _f8_rows(rows, H, FP8, x.device)                # (rows padded to 128, padding zero)
     mean = torch.empty(rows, device=x.device, dtype=F32)
     rstd = torch.empty(rows, device=x.device, dtype=F32)
     call('merlot_ln_fwd_q8t', _p(x), 1 if x.dtype == F32 else 0, _p(gamma), _p(beta), _p(y16), _p(y8), _p(block), _p(mean), _p(rstd),
@@ -303,7 +313,7 @@ def gemm_nt_q8(a, bt, block, fmt, *, epilogue, aux_in, bias=None, colsum_out=Non
     M, K = a.shape
     N = bt.shape[0]
     out = torch.empty((M, N), device=a.device, dtype=BF16) if keep_bf16 else None
-    out8 = torch.empty((M, N), device=a.device, dtype=_F8_DTYPES[fmt])
+    out8 = _f8_rows(M, N, _F8_DTYPES[fmt], a.device)
 
     def launch():
         call('merlot_gemm_bf16_nt_q8', _p(a), a.stride(0), _p(bt), bt.stride(0), _p(out), N, M, N, K, float(alpha), int(epilogue), _p(bias),
@@ -323,7 +333,7 @@ def gemm_fp8_nt_q8(a8, a_scale, bt8, b_scale, block, *, bias=None, aux_out, a_ro
     M, K = a8.shape
     N = bt8.shape[0]
     out = torch.empty((M, N), device=a8.device, dtype=BF16) if keep_bf16 else None
-    out8 = torch.empty((M, N), device=a8.device, dtype=FP8)
+    out8 = _f8_rows(M, N, FP8, a8.device)
 
     def launch():
         call('merlot_gemm_fp8_nt_q8', _p(a8), a8.stride(0), a_scale.data_ptr() + 4 if a_scale is not None else None, _p(a_row_scale),
@@ -436,7 +446,7 @@ def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, dres=None, dx_dtype=None,
             _p(branch_bias_grad))
     if db8_block is not None:
         _chk(db8_block, F32, 'db8_block')
-        db8 = torch.empty((rows, H), device=x.device, dtype=_F8_DTYPES[db8_fmt])
+        db8 = _f8_rows(rows, H, _F8_DTYPES[db8_fmt], x.device)
         call('merlot_ln_bwd_q8', *args, _p(db8), int(db8_fmt), _p(db8_block), _stream())
         return dx, (dx_drop if dx_drop is not None else dx), db8
     call('merlot_ln_bwd', *args, _stream())
@@ -484,7 +494,7 @@ def attention_bwd(qkv, out, dout, lse, B, S, heads, valid=None, seg=None, log_lo
             S if log_split is None else int(log_split), float(log_weight))
     if q8_block is not None:
         _chk(q8_block, F32, 'q8_block')
-        dqkv8 = torch.empty(qkv.shape, device=qkv.device, dtype=_F8_DTYPES[q8_fmt])
+        dqkv8 = _f8_rows(qkv.shape[0], qkv.shape[1], _F8_DTYPES[q8_fmt], qkv.device)
         call('merlot_attention_bwd_q8', *args, _p(dqkv8), dqkv8.stride(0), int(q8_fmt), _p(q8_block), *_attn_ws(), _stream())
         return dqkv, dqkv8
     call('merlot_attention_bwd', *args, *_attn_ws(), _stream())

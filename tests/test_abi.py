@@ -173,4 +173,4 @@ def test_abi_v9_8bit_entries_validate_without_a_gpu():
     assert d.merlot_gemm_f8_tn(p, 768, 2, p, p, 768, 0, p, p, 768, 768, 768, 4096, 1.0, 0, None, 0, None) == -1      # format 2 does not exist
     assert d.merlot_gemm_f8_tn(p, 768, 0, p, p, 768, 0, p, p, 768, 768, 768, 4000, 1.0, 0, None, 0, None) == -1      # R % 128
     assert b'R %% 128' in d.merlot_last_error() or b'128' in d.merlot_last_error()
-    assert d.merlot_gemm_bf16_nt_q8(p, 768, p, 768, None, 0, 1000, 3072, 768, 1.0, 3, None, p, 3072, None, p, 3072, 1, p, p, 64, None) == -1   # M % 256
+    assert d.merlot_gemm_bf16_nt_q8(p, 768, p, 768, None, 0, 1024, 3000, 768, 1.0, 3, None, p, 3000, None, p, 3000, 1, p, p, 64, None) == -1   # N % 256
