@@ -486,8 +486,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
 // first wave publishes per-ROW vectors in LDS: lse2 (+inf beyond S => p = 0), delta, scq = scale*log2e (0 for a
 // padded row) and mq = -1e10*log2e (0 for a padded row); a lane with a masked key adds mq, others add 0.
 // ------------------------------------------------------------------------------------------------
-template <bool MASKED>
+// LOG (round 6; masked launches with the attention log, the sequence lengths of BASELINE configs[4]): the log's per-key sums of P over the VALID query rows below / from
+// `qsplit` (a multiple of 4, checked by the host) are two lane accumulators of this pass, which forms P anyway -- until now the entry launched the tiled column-sum
+// kernel in front (a second Q K^T walk: 2.85 ms per joint layer of config #5 beside this kernel's 3.1 ms).  The same construction as attn_bwd_fused_kernel<.., LOG>.
+template <bool MASKED, bool LOG = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) {
+    static_assert(!LOG || MASKED, "the attention log counts valid pairs only: masked instantiations");
     __shared__ __attribute__((aligned(1024))) char smem[2 * 8192 + 5 * 256];
     char* ldsQ = smem;
     char* ldsO = smem + 8192;
@@ -525,6 +529,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs p)
     const float sc_const = p.scale * LOG2E;
     f32x16 dk[2] = {zero16(), zero16()};
     f32x16 dv[2] = {zero16(), zero16()};
+    float log_lo1 = 0.f, log_hi1 = 0.f;                  // LOG: this key's sums over this lane's query rows
 
     const int nqt = (S + 63) / 64;
     u32x4 qreg[2], oreg[2];
@@ -586,6 +591,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs p)
                         }
                     }
                 }
+                float tg = 0.f;                          // LOG: P summed over this lane's four rows of the group, padded query rows (uniform P) left out
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g + e;
@@ -593,6 +599,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs p)
                     const float ds = pv * (dp[r] - d4[e]) * (s4[e] * LN2);
                     pf[r >> 3][r & 7] = (bf16)pv;
                     dsf[r >> 3][r & 7] = (bf16)ds;
+                    if (LOG) tg += s4[e] != 0.f ? pv : 0.f;
+                }
+                if (LOG) {                               // the four rows qt * 64 + ro .. + 3 lie on one side of qsplit (a multiple of 4)
+                    const bool lo_side = qt * 64 + ro < p.qsplit;
+                    log_lo1 += lo_side ? tg : 0.f;
+                    log_hi1 += lo_side ? 0.f : tg;
                 }
             }
 #pragma unroll
@@ -632,6 +644,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs p)
             }
     }
     if (p.dqkv8 && wave_active) attn_amax_flush(p.q8_amax, q8_m, lane);
+    if (LOG) {                                           // the two row halves (lane, lane ^ 32) of this key, then one atomic per key and sum
+        log_lo1 += __shfl_xor(log_lo1, 32, 64);
+        log_hi1 += __shfl_xor(log_hi1, 32, 64);
+        if (wave_active && lane < 32 && key_in) {
+            if (p.colsum_lo) atomicAdd(p.colsum_lo + (int64_t)b * S + key, log_lo1 * p.weight);
+            if (p.colsum_hi) atomicAdd(p.colsum_hi + (int64_t)b * S + key, log_hi1 * p.weight);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -860,16 +880,19 @@ static int attention_bwd_impl(const void* qkv, int64_t ld, const void* out, int6
         rc = fb_bwd(a, s);
         return rc ? rc : merlot_launch_status("merlot_attention_bwd");
     }
-    if (want_log) hipLaunchKernelGGL(attn_colsum_kernel, dim3(cdiv(S, 32), heads, B), dim3(64), 0, s, a);
+    // (round 6) a masked launch's log comes out of the dK / dV kernel's own P (attn_bwd_dkdv_kernel<true, true>) when its split is a multiple of 4
+    const bool log_in_dkdv = want_log && valid != nullptr && (log_qsplit % 4 == 0);
+    if (want_log && !log_in_dkdv) hipLaunchKernelGGL(attn_colsum_kernel, dim3(cdiv(S, 32), heads, B), dim3(64), 0, s, a);
     // everything else (longer sequences -- BASELINE config #5's S = 578 / 2832 --, segment masks, S <= 64, unaligned outputs):
     // the tiled pair, dQ (+ delta) then dK / dV, each recomputing S and dP.  (Round 3's persistent streaming dQ kernel sat between
     // the two; since the fused kernel took every sequence <= 512 it was reachable only for misaligned outputs and was retired.)
     if (valid) {
         hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);
+        if (log_in_dkdv) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<true, true>), dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<true, false>), dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);
     } else {
         hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<false, false>), dim3(cdiv(S, 128), heads, B), dim3(256), 0, s, a);
     }
     return merlot_launch_status("merlot_attention_bwd");
 }

@@ -490,12 +490,12 @@ def test_attention_fwd_fused_colsum(ops, B, S, pad, vq):
 
 
 @pytest.mark.parametrize("B,S,pad,split", [(3, 328, True, 200), (2, 410, True, 250), (2, 200, True, 96), (2, 148, True, 0), (2, 328, True, 328),
-                                           (3, 198, False, 100), (1, 578, True, 300), (2, 50, True, 20)])
+                                           (3, 198, False, 100), (1, 578, True, 300), (2, 50, True, 20), (2, 700, True, 298), (1, 1200, True, 644), (2, 578, True, 0), (1, 600, True, 600)])
 def test_attention_log_from_the_backward(ops, B, S, pad, split):
     """the attention LOG side output (valid pairs only, queries below / from `split`) taken from the BACKWARD launch (round 4):
     S <= 512 masked = two lane accumulators of the fused kernel's dK / dV pass (chunks below, above and straddling the split: 250
-    and 100 are not multiples of 32, 0 and S put everything on one side), unmasked / long / short sequences = the tiled column-sum
-    kernel launched by the entry -- equal to the stand-alone op, accumulated in place, and the gradients are the plain call's bit
+    and 100 are not multiples of 32, 0 and S put everything on one side), masked sequences of more than 512 / at most 64 tokens with a split that is a multiple of 4 (round 6) = two lane accumulators of
+    the tiled dK / dV kernel; unmasked sequences and other splits = the tiled column-sum kernel launched by the entry -- equal to the stand-alone op, accumulated in place, and the gradients are the plain call's bit
     for bit."""
     heads = 12
     qkv, valid, g = _attn_inputs(B, S, heads, 500 + S, pad)
