@@ -33,7 +33,7 @@ typedef void* merlot_stream_t;
 
 /* Bumped whenever a signature of this header changes.  merlot_abi_version() returns the value the library was built with;
  * a binding must compare the two before its first call (merlot_amd/lib.py does, and refuses a mismatching library). */
-#define MERLOT_ABI_VERSION 9
+#define MERLOT_ABI_VERSION 10
 
 const char* merlot_last_error(void);
 int merlot_abi_version(void);
@@ -456,6 +456,18 @@ int merlot_groupnorm_fwd(const void* x, const float* gamma, const float* beta, c
 int merlot_groupnorm_bwd(const void* dy, const void* y, const void* x, const float* stats, const float* gamma, const float* beta,
                          float* dgamma, float* dbeta, float* gsum, void* dx, void* dres, int N, int H, int W, int C, int G,
                          float eps, int relu, merlot_stream_t stream);
+/* GroupNorm in ONE launch per direction (ABI v10; same results as the two entries above up to the order of the moment sums): every workgroup
+ * keeps its slice of a sample in registers between "reduce the moments" and "normalise", the slices of a sample meet at a counter in the
+ * caller-owned workspace -- x is read once forward and x | dy once backward (5 tensor passes per layer instead of 8; the as-shipped
+ * 192 x 352 hybrid stem of model/configs/merlot.yaml:30,36 spends 17 % of its step in GroupNorm, utils/model_utils.py:133-222).
+ * ws: merlot_groupnorm_fused_workspace_bytes(N, C, G) bytes, 16-B aligned, any content (zeroed by the call, on `stream`); one block per call in
+ * flight.  All other arguments as in merlot_groupnorm_fwd / merlot_groupnorm_bwd. */
+int64_t merlot_groupnorm_fused_workspace_bytes(int N, int C, int G);
+int merlot_groupnorm_fwd_fused(const void* x, const float* gamma, const float* beta, const void* res, void* y, float* stats,
+                               int N, int H, int W, int C, int G, float eps, int relu, void* ws, int64_t ws_bytes, merlot_stream_t stream);
+int merlot_groupnorm_bwd_fused(const void* dy, const void* y, const void* x, const float* stats, const float* gamma, const float* beta,
+                               float* dgamma, float* dbeta, float* gsum, void* dx, void* dres, int N, int H, int W, int C, int G,
+                               float eps, int relu, void* ws, int64_t ws_bytes, merlot_stream_t stream);
 /* tf.nn.avg_pool2d(ksize 2, strides 2) on even H, W; the backward takes dy [N, H/2, W/2, C] and writes dx [N, H, W, C]. */
 int merlot_avgpool2_fwd(const void* x, void* y, int N, int H, int W, int C, merlot_stream_t stream);
 int merlot_avgpool2_bwd(const void* dy, void* dx, int N, int H, int W, int C, merlot_stream_t stream);

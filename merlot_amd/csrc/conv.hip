@@ -319,6 +319,256 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const bf16* __restric
     }
 }
 
+// ---- GroupNorm in ONE launch per direction (round 6, ABI v10) ---------------------------------------------------------------
+// The two-launch forms above read x twice forward (moments, then apply) and x | dy twice backward: 8 tensor passes per layer where
+// 5 are algorithmic, and between the launches the whole activation (up to 1.9 GB at the as-shipped geometry) passes through the
+// caches, so the second read is an HBM read.  Here a workgroup keeps its slice of the sample IN REGISTERS between the two phases:
+//   claim an item (sample n, slice) -> load the slice, reduce its moments -> add them to the sample's sums (device-scope atomics)
+//   -> count itself in arrive[n] -> wait until the sample's `split` slices are counted -> normalise the held slice, store.
+// Items are CLAIMED from a counter, not derived from blockIdx: a workgroup only ever waits for items with smaller claim numbers
+// than slices it could itself still be waiting for -- items that running workgroups hold and finish without waiting for anybody --
+// so the wait terminates whatever order the hardware dispatches workgroups in and however many of them are resident.
+// Workspace (caller-owned, zeroed by the entry point): u32 ctr[16] | u32 arrive[N rounded to 16] | f32 sums[N][G][2] (forward) |
+// f32 chsum[N][C][2] (backward: per-sample channel sums; the sample's LAST arriver adds them to dgamma / dbeta -- N atomics per
+// address instead of N * split).
+// Every access to the shared words is a RELAXED device-scope atomic (performed at the memory side, coherent between the XCDs' L2s) and the order "my additions,
+// then my arrival" comes from WAITING FOR THE ADDITIONS' RETURN VALUES, not from fences: a release / acquire pair at device scope is an L2 write-back + invalidate
+// (buffer_wbl2 / buffer_inv sc1) per wave -- with tens of thousands of workgroups per launch, each between other workgroups' output stores, the first version of
+// these kernels (release on the arrival, __threadfence() in front of it) ran the as-shipped step into a 600 s timeout where the two-launch form takes 0.4 s.
+__device__ __forceinline__ float gn_ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void gn_add(float* p, float v) {   // returns only when the addition has been performed
+    const float old = __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::"v"(old));
+}
+// one thread, behind a workgroup barrier that follows every thread's gn_add: count this workgroup in, wait for the sample's other slices; returns the arrival number
+__device__ __forceinline__ unsigned gn_arrive_and_wait(unsigned* slot, unsigned split) {
+    const unsigned old = __hip_atomic_fetch_add(slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < split) __builtin_amdgcn_s_sleep(2);
+    return old;
+}
+__host__ __device__ constexpr int64_t gn_ws_arrive_words(int N) { return (N + 15) & ~15; }
+
+template <int ITER, bool RES>
+__global__ __launch_bounds__(256) void gn_fwd_fused_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const bf16* __restrict__ res,
+                                                           bf16* __restrict__ y, float* __restrict__ stats, unsigned* __restrict__ ws,
+                                                           int N, int HW, int C, int G, int relu, int split, float inv_cnt, float eps) {
+    extern __shared__ float gsm[];                         // [G][2] this slice's sums, then [G][2] {mean, rstd} of the sample
+    __shared__ int s_item;
+    unsigned* arrive = ws + 16;
+    float* sums = reinterpret_cast<float*>(ws + 16 + gn_ws_arrive_words(N));
+    const int tid = threadIdx.x, bd = blockDim.x;
+    if (tid == 0) s_item = (int)__hip_atomic_fetch_add(ws, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = tid; i < 2 * G; i += bd) gsm[i] = 0.f;
+    __syncthreads();
+    const int item = s_item, n = item / split, sl = item - n * split;
+    const int cpr = C / 8, cpg = C / G;
+    const int chunk = tid % cpr, prow = tid / cpr, pstep = bd / cpr;
+    const int pbase = sl * (ITER * pstep) + prow;
+    const int64_t off0 = ((int64_t)n * HW) * C + chunk * 8;
+    bf16x8 v[ITER], r8[RES ? ITER : 1];
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+        const int p = pbase + i * pstep;
+        bf16x8 z;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = (bf16)0.f;
+        v[i] = z;
+        if (p < HW) v[i] = *reinterpret_cast<const bf16x8*>(x + off0 + (int64_t)p * C);
+    }
+    if (RES) {
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) {
+            const int p = pbase + i * pstep;
+            if (p < HW) r8[i] = *reinterpret_cast<const bf16x8*>(res + off0 + (int64_t)p * C);
+        }
+    }
+    float gam[8], bet[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        gam[e] = gamma[chunk * 8 + e];
+        bet[e] = beta[chunk * 8 + e];
+    }
+    float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < ITER; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float f = (float)v[i][e];                // rows beyond HW hold zeros
+            s1[e] += f;
+            s2[e] = __builtin_fmaf(f, f, s2[e]);
+        }
+    int gidx[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gidx[e] = (chunk * 8 + e) / cpg;
+    {                                                      // channels of one group first summed in the thread: 2 LDS atomics per group it touches
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            a1 += s1[e];
+            a2 += s2[e];
+            if (e == 7 || gidx[e + 1 < 8 ? e + 1 : 7] != gidx[e]) {
+                atomicAdd(&gsm[2 * gidx[e]], a1);
+                atomicAdd(&gsm[2 * gidx[e] + 1], a2);
+                a1 = a2 = 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * G; i += bd) gn_add(sums + (int64_t)n * 2 * G + i, gsm[i]);
+    __syncthreads();                                       // every thread's additions are performed (returned) before thread 0 counts the workgroup in
+    if (tid == 0) gn_arrive_and_wait(arrive + n, (unsigned)split);
+    __syncthreads();
+    for (int g = tid; g < G; g += bd) {
+        const float mean = gn_ld(sums + ((int64_t)n * G + g) * 2) * inv_cnt;
+        const float var = gn_ld(sums + ((int64_t)n * G + g) * 2 + 1) * inv_cnt - mean * mean;
+        const float rstd = rsqrtf(var + eps);
+        gsm[2 * G + 2 * g] = mean;
+        gsm[2 * G + 2 * g + 1] = rstd;
+        if (sl == 0) {
+            stats[((int64_t)n * G + g) * 2] = mean;
+            stats[((int64_t)n * G + g) * 2 + 1] = rstd;
+        }
+    }
+    __syncthreads();
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gn_affine(gsm[2 * G + 2 * gidx[e]], gsm[2 * G + 2 * gidx[e] + 1], gam[e], bet[e], sc[e], sh[e]);
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+        const int p = pbase + i * pstep;
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float f = gn_y((float)v[i][e], sc[e], sh[e]);
+            if (RES) f += (float)r8[i][e];
+            if (relu) f = fmaxf(f, 0.f);
+            o[e] = (bf16)f;
+        }
+        if (p < HW) *reinterpret_cast<bf16x8*>(y + off0 + (int64_t)p * C) = o;
+    }
+}
+
+// backward in one launch: phase 1 = gn_bwd_stats_kernel's sums on the held slice (x, dy' kept as bf16: dy' is dy or 0), phase 2 = gn_bwd_apply_kernel's
+// expression.  HAS_Y: the ReLU mask from the stored output (layers with a residual add); otherwise recomputed from x (relu) or absent.
+template <int ITER, bool HAS_Y>
+__global__ __launch_bounds__(256) void gn_bwd_fused_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ y, const bf16* __restrict__ x,
+                                                           const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           float* __restrict__ gsum, bf16* __restrict__ dx, bf16* __restrict__ dres,
+                                                           unsigned* __restrict__ ws, int N, int HW, int C, int G, int relu, int split) {
+    extern __shared__ float gsm[];                         // [C][2] per-channel partials of this slice, then [G][2] the sample's gsum
+    __shared__ int s_item, s_last;
+    unsigned* arrive = ws + 16;
+    float* chsum = reinterpret_cast<float*>(ws + 16 + gn_ws_arrive_words(N));
+    const int tid = threadIdx.x, bd = blockDim.x;
+    if (tid == 0) s_item = (int)__hip_atomic_fetch_add(ws, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = tid; i < 2 * C; i += bd) gsm[i] = 0.f;
+    __syncthreads();
+    const int item = s_item, n = item / split, sl = item - n * split;
+    const int cpr = C / 8, cpg = C / G;
+    const float inv_cnt = 1.0f / ((float)HW * (float)cpg);
+    const int chunk = tid % cpr, prow = tid / cpr, pstep = bd / cpr;
+    const int pbase = sl * (ITER * pstep) + prow;
+    const int64_t off0 = ((int64_t)n * HW) * C + chunk * 8;
+    const bool from_x = relu && !HAS_Y;
+    bf16x8 xv[ITER], dv[ITER];
+    bf16x8 zero8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) zero8[e] = (bf16)0.f;
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+        const int p = pbase + i * pstep;
+        xv[i] = zero8;
+        dv[i] = zero8;
+        if (p < HW) {
+            xv[i] = *reinterpret_cast<const bf16x8*>(x + off0 + (int64_t)p * C);
+            dv[i] = *reinterpret_cast<const bf16x8*>(dy + off0 + (int64_t)p * C);
+        }
+    }
+    float mean[8], rs[8], gam[8], k1[8], bet[8];
+    int gidx[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = chunk * 8 + e;
+        gidx[e] = c / cpg;
+        mean[e] = stats[((int64_t)n * G + gidx[e]) * 2];
+        rs[e] = stats[((int64_t)n * G + gidx[e]) * 2 + 1];
+        gam[e] = gamma[c];
+        k1[e] = rs[e] * gam[e];
+        bet[e] = 0.f;
+        if (from_x) gn_affine(mean[e], rs[e], gam[e], beta[c], k1[e], bet[e]);     // y = x * k1 + bet, gn_apply_kernel's own expression
+    }
+    float dg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, db[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+        bf16x8 y8 = zero8;
+        if (HAS_Y) {
+            const int p = pbase + i * pstep;
+            if (p < HW) y8 = *reinterpret_cast<const bf16x8*>(y + off0 + (int64_t)p * C);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float d = (float)dv[i][e];
+            const float yv = from_x ? gn_y((float)xv[i][e], k1[e], bet[e]) : (float)y8[e];
+            if (relu && !gn_relu_passes(yv)) {
+                d = 0.f;
+                dv[i][e] = (bf16)0.f;
+            }
+            dg[e] += d * ((float)xv[i][e] - mean[e]) * rs[e];
+            db[e] += d;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        atomicAdd(&gsm[2 * (chunk * 8 + e)], dg[e]);
+        atomicAdd(&gsm[2 * (chunk * 8 + e) + 1], db[e]);
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += bd) {
+        const float g_ = gsm[2 * c], b_ = gsm[2 * c + 1];
+        gn_add(chsum + ((int64_t)n * C + c) * 2, g_);
+        gn_add(chsum + ((int64_t)n * C + c) * 2 + 1, b_);
+        const int g = c / cpg;
+        gn_add(gsum + ((int64_t)n * G + g) * 2, gamma[c] * b_);
+        gn_add(gsum + ((int64_t)n * G + g) * 2 + 1, gamma[c] * g_);
+    }
+    __syncthreads();
+    if (tid == 0) s_last = gn_arrive_and_wait(arrive + n, (unsigned)split) == (unsigned)split - 1u;
+    __syncthreads();
+    float* gs = gsm + 2 * C;
+    for (int i = tid; i < 2 * G; i += bd) gs[i] = gn_ld(gsum + (int64_t)n * 2 * G + i);
+    if (s_last)                                            // the sample's channel sums into the layer's gradient: once per sample
+        for (int c = tid; c < C; c += bd) {
+            atomicAdd(dgamma + c, gn_ld(chsum + ((int64_t)n * C + c) * 2));
+            atomicAdd(dbeta + c, gn_ld(chsum + ((int64_t)n * C + c) * 2 + 1));
+        }
+    __syncthreads();
+    float mr[8], k2[8], k3[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        mr[e] = mean[e] * rs[e];
+        k1[e] = rs[e] * gam[e];
+        k2[e] = rs[e] * gs[2 * gidx[e]] * inv_cnt;
+        k3[e] = rs[e] * gs[2 * gidx[e] + 1] * inv_cnt;
+    }
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+        const int p = pbase + i * pstep;
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float d = (float)dv[i][e];
+            const float xhat = __builtin_fmaf((float)xv[i][e], rs[e], -mr[e]);
+            o[e] = (bf16)(d * k1[e] - k2[e] - xhat * k3[e]);
+        }
+        if (p < HW) {
+            *reinterpret_cast<bf16x8*>(dx + off0 + (int64_t)p * C) = o;
+            if (dres) *reinterpret_cast<bf16x8*>(dres + off0 + (int64_t)p * C) = dv[i];
+        }
+    }
+}
+
 // ---- 2x2 / stride 2 average pool (tf.nn.avg_pool2d, even H and W) --------------------------------------------------------
 __global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, int64_t N, int H,
                                                            int W, int C) {
@@ -461,6 +711,77 @@ extern "C" int merlot_groupnorm_bwd(const void* dy, const void* y, const void* x
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(N, split), dim3(threads), 0, (hipStream_t)stream, (const bf16*)dy,
                        (const bf16*)y, (const bf16*)x, stats, gsum, gamma, beta, (bf16*)dx, (bf16*)dres, HW, C, G, relu, ppb);
     return merlot_launch_status("merlot_groupnorm_bwd");
+}
+
+// One launch per direction (ABI v10): see gn_fwd_fused_kernel.  ws: merlot_groupnorm_fused_workspace_bytes(N, C, G) bytes, caller-owned, any content
+// (zeroed here, on the stream); stats / gsum as in the two-launch entries.
+extern "C" int64_t merlot_groupnorm_fused_workspace_bytes(int N, int C, int G) {
+    if (N <= 0 || C <= 0 || G <= 0) return 0;
+    const int64_t per_sample = 2 * (int64_t)(C > G ? C : G);
+    return 4 * (16 + gn_ws_arrive_words(N) + (int64_t)N * per_sample);
+}
+
+extern "C" int merlot_groupnorm_fwd_fused(const void* x, const float* gamma, const float* beta, const void* res, void* y, float* stats,
+                                          int N, int H, int W, int C, int G, float eps, int relu, void* ws, int64_t ws_bytes,
+                                          merlot_stream_t stream) {
+    CONV_CHECK_GEOM("merlot_groupnorm_fwd_fused");
+    MERLOT_CHECK(gamma && beta && y && stats && G > 0 && C % G == 0 && C % 8 == 0 && C <= 2048 && G <= 1024, MERLOT_ESHAPE,
+                 "merlot_groupnorm_fwd_fused: C must be a multiple of 8 and of G, C <= 2048");
+    MERLOT_CHECK(ws && ws_bytes >= merlot_groupnorm_fused_workspace_bytes(N, C, G) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0, MERLOT_ESHAPE,
+                 "merlot_groupnorm_fwd_fused: workspace of merlot_groupnorm_fused_workspace_bytes(N, C, G) = %lld bytes required (got %lld)",
+                 (long long)merlot_groupnorm_fused_workspace_bytes(N, C, G), (long long)ws_bytes);
+    MERLOT_CHECK(((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(res)) & 15) == 0, MERLOT_EALIGN,
+                 "merlot_groupnorm_fwd_fused: operands must be 16-B aligned");
+    const int HW = H * W;
+    const int threads = gn_block_threads(C);
+    const int pstep = threads / (C / 8);
+    const int iter = res ? 8 : 16;
+    const int split = (HW + iter * pstep - 1) / (iter * pstep);
+    MERLOT_CHECK((int64_t)N * split < (1LL << 31), MERLOT_ESHAPE, "merlot_groupnorm_fwd_fused: too many slices");
+    hipError_t e = hipMemsetAsync(ws, 0, 4 * (16 + gn_ws_arrive_words(N) + (size_t)N * 2 * G), (hipStream_t)stream);
+    MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+    const float inv_cnt = 1.0f / ((float)HW * (float)(C / G));
+    const size_t lds = sizeof(float) * 4 * G;
+    if (res)
+        hipLaunchKernelGGL((gn_fwd_fused_kernel<8, true>), dim3(N * split), dim3(threads), lds, (hipStream_t)stream, (const bf16*)x, gamma, beta,
+                           (const bf16*)res, (bf16*)y, stats, (unsigned*)ws, N, HW, C, G, relu, split, inv_cnt, eps);
+    else
+        hipLaunchKernelGGL((gn_fwd_fused_kernel<16, false>), dim3(N * split), dim3(threads), lds, (hipStream_t)stream, (const bf16*)x, gamma, beta,
+                           (const bf16*)nullptr, (bf16*)y, stats, (unsigned*)ws, N, HW, C, G, relu, split, inv_cnt, eps);
+    return merlot_launch_status("merlot_groupnorm_fwd_fused");
+}
+
+extern "C" int merlot_groupnorm_bwd_fused(const void* dy, const void* y, const void* x, const float* stats, const float* gamma,
+                                          const float* beta, float* dgamma, float* dbeta, float* gsum, void* dx, void* dres, int N, int H,
+                                          int W, int C, int G, float eps, int relu, void* ws, int64_t ws_bytes, merlot_stream_t stream) {
+    CONV_CHECK_GEOM("merlot_groupnorm_bwd_fused");
+    MERLOT_CHECK(dy && stats && gamma && dgamma && dbeta && gsum && dx && (!relu || y || beta) && G > 0 && C % G == 0 && C % 8 == 0 &&
+                     C <= 2048 && G <= 1024, MERLOT_ESHAPE, "merlot_groupnorm_bwd_fused: bad arguments (relu needs y, or beta to recompute the mask from x)");
+    MERLOT_CHECK(ws && ws_bytes >= merlot_groupnorm_fused_workspace_bytes(N, C, G) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0, MERLOT_ESHAPE,
+                 "merlot_groupnorm_bwd_fused: workspace of merlot_groupnorm_fused_workspace_bytes(N, C, G) = %lld bytes required (got %lld)",
+                 (long long)merlot_groupnorm_fused_workspace_bytes(N, C, G), (long long)ws_bytes);
+    MERLOT_CHECK(((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(dres)) & 15) == 0,
+                 MERLOT_EALIGN, "merlot_groupnorm_bwd_fused: operands must be 16-B aligned");
+    const int HW = H * W;
+    const int threads = gn_block_threads(C);
+    const int pstep = threads / (C / 8);
+    constexpr int ITER = 8;
+    const int split = (HW + ITER * pstep - 1) / (ITER * pstep);
+    MERLOT_CHECK((int64_t)N * split < (1LL << 31), MERLOT_ESHAPE, "merlot_groupnorm_bwd_fused: too many slices");
+    hipError_t e = hipMemsetAsync(ws, 0, 4 * (16 + gn_ws_arrive_words(N) + (size_t)N * 2 * C), (hipStream_t)stream);
+    MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+    e = hipMemsetAsync(gsum, 0, sizeof(float) * 2 * (size_t)N * G, (hipStream_t)stream);
+    MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+    const size_t lds = sizeof(float) * 2 * (C + G);
+    const bool has_y = relu && y != nullptr;
+    if (has_y)
+        hipLaunchKernelGGL((gn_bwd_fused_kernel<ITER, true>), dim3(N * split), dim3(threads), lds, (hipStream_t)stream, (const bf16*)dy, (const bf16*)y,
+                           (const bf16*)x, stats, gamma, beta, dgamma, dbeta, gsum, (bf16*)dx, (bf16*)dres, (unsigned*)ws, N, HW, C, G, relu, split);
+    else
+        hipLaunchKernelGGL((gn_bwd_fused_kernel<ITER, false>), dim3(N * split), dim3(threads), lds, (hipStream_t)stream, (const bf16*)dy,
+                           (const bf16*)nullptr, (const bf16*)x, stats, gamma, beta, dgamma, dbeta, gsum, (bf16*)dx, (bf16*)dres, (unsigned*)ws, N,
+                           HW, C, G, relu, split);
+    return merlot_launch_status("merlot_groupnorm_bwd_fused");
 }
 
 extern "C" int merlot_avgpool2_fwd(const void* x, void* y, int N, int H, int W, int C, merlot_stream_t stream) {

@@ -756,12 +756,27 @@ def col2im3x3(dpatches, N, H, W, C, stride=1):
     return dx
 
 
+# GroupNorm in one launch per direction (merlot_groupnorm_*_fused, ABI v10): same-box A/B at the as-shipped geometry in
+# profiles/r06_x_gn_fused.txt; False = the two-launch entries (bench.py --no-gn-fused).
+GN_FUSED = True
+
+
+def _gn_ws(device, N, C, groups):
+    """caller-owned workspace of one fused GroupNorm call (zeroed by the call itself, on its stream)."""
+    return torch.empty(LIB.query('merlot_groupnorm_fused_workspace_bytes', N, C, groups) // 4, device=device, dtype=torch.int32)
+
+
 def groupnorm_fwd(x, gamma, beta, *, res=None, relu=True, groups=32, eps=1e-4):
     _chk(x, BF16, 'x'); _chk(gamma, F32, 'gamma'); _chk(beta, F32, 'beta'); _chk(res, BF16, 'res')
     N, H, W, C = x.shape
     assert x.is_contiguous() and (res is None or res.is_contiguous())
     y = torch.empty_like(x)
     stats = torch.empty((N, groups, 2), device=x.device, dtype=F32)
+    if GN_FUSED:                                           # one launch, x read once (ABI v10)
+        ws = _gn_ws(x.device, N, C, groups)
+        call('merlot_groupnorm_fwd_fused', _p(x), _p(gamma), _p(beta), _p(res), _p(y), _p(stats), N, H, W, C, groups, float(eps),
+             1 if relu else 0, _p(ws), ws.numel() * 4, _stream())
+        return y, stats
     call('merlot_groupnorm_fwd', _p(x), _p(gamma), _p(beta), _p(res), _p(y), _p(stats), N, H, W, C, groups, float(eps),
          1 if relu else 0, _stream())
     return y, stats
@@ -776,6 +791,11 @@ def groupnorm_bwd(dy, y, x, stats, gamma, dgamma, dbeta, *, beta=None, relu=True
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
     gsum = torch.empty((N, groups, 2), device=x.device, dtype=F32)
+    if GN_FUSED:                                           # one launch, x | dy read once (ABI v10)
+        ws = _gn_ws(x.device, N, C, groups)
+        call('merlot_groupnorm_bwd_fused', _p(dy), _p(y), _p(x), _p(stats), _p(gamma), _p(beta), _p(dgamma), _p(dbeta), _p(gsum), _p(dx),
+             _p(dres), N, H, W, C, groups, float(eps), 1 if relu else 0, _p(ws), ws.numel() * 4, _stream())
+        return dx, dres
     call('merlot_groupnorm_bwd', _p(dy), _p(y), _p(x), _p(stats), _p(gamma), _p(beta), _p(dgamma), _p(dbeta), _p(gsum), _p(dx), _p(dres),
          N, H, W, C, groups, float(eps), 1 if relu else 0, _stream())
     return dx, dres

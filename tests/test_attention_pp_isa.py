@@ -153,3 +153,79 @@ def test_persistent_attention_kernels_keep_their_wait_counts():
         assert not bad, '\n'.join(bad)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def _fused_ch_sequence(body):
+    """text-order sequence of one kernel's vector-memory events: D = LDS-DMA request, g = load, s = store, a = atomic, W<n> / w<n> = s_waitcnt vmcnt(n) inside
+    / outside hand-written assembly, | = barrier; plus the violations check_kernel's first rules would report."""
+    seq, bad, in_asm = [], [], False
+    for i, ln in enumerate(body):
+        if '#ASMSTART' in ln:
+            in_asm = True
+            continue
+        if '#ASMEND' in ln:
+            in_asm = False
+            continue
+        code = ln.split(';')[0].strip()
+        if not code or code.endswith(':') or code.startswith('.'):
+            continue
+        if 'scratch_' in code:
+            bad.append(f'scratch access {code!r}')
+        if not in_asm and re.search(r'\bm0\b', code):
+            bad.append(f'compiler-generated use of m0 {code!r} (line {i})')
+        if re.match(r'buffer_load_dword(x4)? ', code) and code.endswith('lds'):
+            if not in_asm:
+                bad.append(f'an LDS-DMA the compiler can see: {code!r}')
+            seq.append('D')
+        elif code.startswith('global_load'):
+            seq.append('g')
+        elif code.startswith('global_store'):
+            seq.append('s')
+        elif code.startswith('global_atomic'):
+            seq.append('a')
+        elif code.startswith('s_waitcnt') and 'vmcnt' in code:
+            seq.append(('W' if in_asm else 'w') + re.search(r'vmcnt\((\d+)\)', code).group(1))
+        elif code.startswith('s_barrier'):
+            seq.append('|')
+    return seq, bad
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not available')
+def test_chunked_fused_backward_keeps_its_requests_out_of_the_compilers_sight():
+    """attn_bwd_fused_kernel<512, .., CH = true> (attention_fb.inc, round 6): the K | V and Q | dO images arrive in groups of 128 rows under the passes that read
+    them.  That holds while (1) every request is assembly and nothing of the compiler's touches m0, (2) a wave issues FOUR requests per group (the wait ladder's
+    immediates 12 / 8 / 4 / 0 count them), (3) every ordinary load is issued where no later group is outstanding or is the youngest operation (in front of the
+    first walk: behind group 0 and drained by a wait the compiler sees; inside it: at chunk 4, drained -- visibly -- behind the walk), so that (4) the compiler
+    inserts NO wait of its own between pass 1's stores and the refill requests: the first version drained those stores on every wave there."""
+    tmp = tempfile.mkdtemp(prefix='fb_isa_')
+    try:
+        out = os.path.join(tmp, 'attention.s')
+        subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-w', '-S', '--cuda-device-only',
+                               os.path.join(CSRC, 'attention.hip'), '-o', out], cwd=CSRC)
+        kernels, cur = {}, None
+        for ln in open(out).read().split('\n'):
+            m = re.match(r'^(_ZN\S*attn_bwd_fused_kernelILi512E\S*Li2ELb1EEE\S*):', ln)
+            if m:
+                cur = m.group(1)
+                kernels[cur] = []
+            if cur is not None:
+                kernels[cur].append(ln)
+                if ln.startswith('.Lfunc_end'):
+                    cur = None
+        assert len(kernels) == 3, sorted(kernels)              # unmasked, masked, masked + attention log
+        for name, body in kernels.items():
+            seq, bad = _fused_ch_sequence(body)
+            assert not bad, name + ': ' + '; '.join(bad)
+            s = ' '.join(seq)
+            # three request sites (group 0 of K | V; its later groups, one rolled loop; the refill, one rolled loop), four requests each
+            assert seq.count('D') == 12 and s.count('D D D D') == 3, (name, s)
+            # group 0, then ordinary loads only, then the wait the compiler sees, then the later groups and the barrier that opens pass 1
+            assert re.search(r'D D D D( g)+ w0 D D D D \|', s), (name, s)
+            # every counted wait is the whole ladder, hand-written (the barrier behind it may sit elsewhere in the listing: block layout)
+            assert 'W' in s and all(x in ('W12', 'W8', 'W4', 'W0') for x in seq if x.startswith('W')), (name, s)
+            assert s.count('W12 W8 W4 W0') == s.count('W12') == s.count('W0') >= 3, (name, s)
+            # nothing of the compiler's between the loads of the second block (drained visibly behind the walk), pass 1's stores and the refill
+            m = re.search(r'g w0( s)+ \| D D D D W12', s)
+            assert m, (name, s)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
