@@ -664,6 +664,36 @@ extern "C" int merlot_col2im3x3(const void* x, void* dx, int N, int H, int W, in
     return merlot_launch_status("merlot_col2im3x3");
 }
 
+// Round 6: the two passes of a direction walk the batch in GROUPS OF SAMPLES whose tensors fit the 256 MiB Infinity Cache, so that the
+// second pass finds what the first one read (x forward; x | dy [| y] backward) on the die instead of in HBM: 8 tensor passes per layer become 5 HBM passes
+// without any workgroup waiting for another (the one-launch form above does that, and loses: profiles/r06_y_gn_fused.txt).  Same kernels, same grids per
+// sample, pointer offsets per group; results identical up to the order of the fp32 atomics (as between any two runs).  GN_GROUP_BYTES: bytes of the
+// re-read tensors per group (profiles/r06_z_gn_groups.txt for the sweep).
+constexpr int64_t GN_GROUP_BYTES = 64LL << 20;
+static int64_t gn_group_bytes() {
+#ifdef MERLOT_EXPERIMENTS
+    if (const char* e = getenv("MERLOT_GN_GROUP_MB")) return (int64_t)atoi(e) << 20;      // 0 = one group (rounds 3 - 5)
+#endif
+    return GN_GROUP_BYTES;
+}
+// samples per group: whole samples, at least one; 0 bytes = everything in one group
+static int gn_group_samples(int N, int64_t bytes_per_sample) {
+    const int64_t lim = gn_group_bytes();
+    if (lim <= 0) return N;
+    int64_t nb = lim / bytes_per_sample;
+    if (nb < 1) nb = 1;
+    return nb > N ? N : (int)nb;
+}
+// slices per sample: enough blocks to fill the chip (>= ~2048) but no more: every block ends in atomics (2G forward, 4C in the backward)
+static int gn_split(int nb, int HW, int C, int threads) {
+    int split = (2048 + nb - 1) / nb;
+    const int max_split = (HW * (C / 8) + threads * 4 - 1) / (threads * 4);
+    if (split > max_split) split = max_split;
+    if (split > 64) split = 64;
+    if (split < 1) split = 1;
+    return split;
+}
+
 extern "C" int merlot_groupnorm_fwd(const void* x, const float* gamma, const float* beta, const void* res, void* y, float* stats,
                                     int N, int H, int W, int C, int G, float eps, int relu, merlot_stream_t stream) {
     CONV_CHECK_GEOM("merlot_groupnorm_fwd");
@@ -671,21 +701,21 @@ extern "C" int merlot_groupnorm_fwd(const void* x, const float* gamma, const flo
                  "merlot_groupnorm_fwd: C must be a multiple of 8 and of G");
     const int HW = H * W;
     const int threads = gn_block_threads(C);
-    // enough blocks to fill the chip (>= ~2048) but no more: every block ends in atomics (2G here, 4C in the backward)
-    int split = (2048 + N - 1) / N;
-    const int max_split = (HW * (C / 8) + threads * 4 - 1) / (threads * 4);
-    if (split > max_split) split = max_split;
-    if (split > 64) split = 64;
-    if (split < 1) split = 1;
-    const int ppb = (HW + split - 1) / split;
+    const int64_t per = (int64_t)HW * C;                   // elements of one sample
+    const int nb_max = gn_group_samples(N, per * 2);
     hipError_t e = hipMemsetAsync(stats, 0, sizeof(float) * 2 * (size_t)N * G, (hipStream_t)stream);
     MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(N, split), dim3(threads), sizeof(float) * 2 * G, (hipStream_t)stream, (const bf16*)x,
-                       stats, HW, C, G, ppb);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(((int64_t)N * G + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats,
-                       (int64_t)N * G, 1.0f / ((float)HW * (float)(C / G)), eps);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(N, split), dim3(threads), 0, (hipStream_t)stream, (const bf16*)x, stats, gamma, beta,
-                       (const bf16*)res, (bf16*)y, HW, C, G, relu, ppb);
+    for (int n0 = 0; n0 < N; n0 += nb_max) {
+        const int nb = N - n0 < nb_max ? N - n0 : nb_max;
+        const int split = gn_split(nb, HW, C, threads), ppb = (HW + split - 1) / split;
+        const bf16* xg = (const bf16*)x + n0 * per;
+        float* sg = stats + (int64_t)n0 * 2 * G;
+        hipLaunchKernelGGL(gn_stats_kernel, dim3(nb, split), dim3(threads), sizeof(float) * 2 * G, (hipStream_t)stream, xg, sg, HW, C, G, ppb);
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(((int64_t)nb * G + 255) / 256), dim3(256), 0, (hipStream_t)stream, sg, (int64_t)nb * G,
+                           1.0f / ((float)HW * (float)(C / G)), eps);
+        hipLaunchKernelGGL(gn_apply_kernel, dim3(nb, split), dim3(threads), 0, (hipStream_t)stream, xg, sg, gamma, beta,
+                           res ? (const bf16*)res + n0 * per : nullptr, (bf16*)y + n0 * per, HW, C, G, relu, ppb);
+    }
     return merlot_launch_status("merlot_groupnorm_fwd");
 }
 
@@ -697,19 +727,21 @@ extern "C" int merlot_groupnorm_bwd(const void* dy, const void* y, const void* x
                      C <= 2048, MERLOT_ESHAPE, "merlot_groupnorm_bwd: bad arguments (relu needs y, or beta to recompute the mask from x)");
     const int HW = H * W;
     const int threads = gn_block_threads(C);
-    // enough blocks to fill the chip (>= ~2048) but no more: every block ends in atomics (2G here, 4C in the backward)
-    int split = (2048 + N - 1) / N;
-    const int max_split = (HW * (C / 8) + threads * 4 - 1) / (threads * 4);
-    if (split > max_split) split = max_split;
-    if (split > 64) split = 64;
-    if (split < 1) split = 1;
-    const int ppb = (HW + split - 1) / split;
+    const int64_t per = (int64_t)HW * C;
+    const int nb_max = gn_group_samples(N, per * 2 * (y ? 3 : 2));      // both passes read x | dy [| y]
     hipError_t e = hipMemsetAsync(gsum, 0, sizeof(float) * 2 * (size_t)N * G, (hipStream_t)stream);
     MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(N, split), dim3(threads), sizeof(float) * 2 * C, (hipStream_t)stream, (const bf16*)dy,
-                       (const bf16*)y, (const bf16*)x, stats, gamma, beta, dgamma, dbeta, gsum, HW, C, G, eps, relu, ppb);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(N, split), dim3(threads), 0, (hipStream_t)stream, (const bf16*)dy,
-                       (const bf16*)y, (const bf16*)x, stats, gsum, gamma, beta, (bf16*)dx, (bf16*)dres, HW, C, G, relu, ppb);
+    for (int n0 = 0; n0 < N; n0 += nb_max) {
+        const int nb = N - n0 < nb_max ? N - n0 : nb_max;
+        const int split = gn_split(nb, HW, C, threads), ppb = (HW + split - 1) / split;
+        const bf16 *dyg = (const bf16*)dy + n0 * per, *yg = y ? (const bf16*)y + n0 * per : nullptr, *xg = (const bf16*)x + n0 * per;
+        const float* sg = stats + (int64_t)n0 * 2 * G;
+        float* gg = gsum + (int64_t)n0 * 2 * G;
+        hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(nb, split), dim3(threads), sizeof(float) * 2 * C, (hipStream_t)stream, dyg, yg, xg, sg,
+                           gamma, beta, dgamma, dbeta, gg, HW, C, G, eps, relu, ppb);
+        hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nb, split), dim3(threads), 0, (hipStream_t)stream, dyg, yg, xg, sg, gg, gamma, beta,
+                           (bf16*)dx + n0 * per, dres ? (bf16*)dres + n0 * per : nullptr, HW, C, G, relu, ppb);
+    }
     return merlot_launch_status("merlot_groupnorm_bwd");
 }
 

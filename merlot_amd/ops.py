@@ -756,9 +756,11 @@ def col2im3x3(dpatches, N, H, W, C, stride=1):
     return dx
 
 
-# GroupNorm in one launch per direction (merlot_groupnorm_*_fused, ABI v10): same-box A/B at the as-shipped geometry in
-# profiles/r06_x_gn_fused.txt; False = the two-launch entries (bench.py --no-gn-fused).
-GN_FUSED = True
+# GroupNorm in one launch per direction (merlot_groupnorm_*_fused, ABI v10).  Built, value-tested, and it LOSES: 1.7x (forward) / 2.3x (backward) the two-launch
+# entries at the first as-shipped shape and the as-shipped step did not finish inside 300 s (profiles/r06_x_gn_fused.txt, r06_y_gn_fused.txt) -- workgroups that
+# wait for other workgroups behind device-scope atomics.  OFF; bench.py --gn-fused turns it on for an A/B.  The two-launch entries walk the batch in groups of
+# samples that fit the Infinity Cache instead (csrc/conv.hip, GN_GROUP_BYTES).
+GN_FUSED = False
 
 
 def _gn_ws(device, N, C, groups):

@@ -23,7 +23,9 @@ def timeit(fn, n=20):
 torch.manual_seed(0)
 for name, B, S, nfix, log in (('joint + log (512 x 328)', 512, 328, 200, True), ('joint (512 x 328)', 512, 328, 200, False), ('text-only (1536 x 512, masked)', 1536, 512, 64, False),
                               ('as-shipped ViT (896 x 266, no mask)', 896, 266, 266, False), ('as-shipped joint + log (224 x 396)', 224, 396, 268, True),
-                              ('sort_story joint (320 x 410, masked)', 320, 410, 250, False), ('258 tokens, no mask', 512, 258, 258, False), ('385 tokens + log', 256, 385, 200, True)):
+                              ('sort_story joint (320 x 410, masked)', 320, 410, 250, False), ('258 tokens, no mask', 512, 258, 258, False), ('385 tokens + log', 256, 385, 200, True),
+                              ('266 tokens, masked', 512, 266, 200, False), ('300 tokens, masked', 512, 300, 200, False), ('320 tokens, masked', 512, 320, 200, False),
+                              ('300 tokens, no mask', 512, 300, 300, False), ('328 tokens, no mask', 512, 328, 328, False), ('400 tokens, no mask', 384, 400, 400, False)):
     qkv = (torch.randn(B * S, 2304, device='cuda') * 0.7).bfloat16()
     valid = None
     if nfix < S:

@@ -16,6 +16,10 @@ SHAPES = [(96, 176, 32, True, False, 2), (96, 176, 64, True, False, 1), (48, 88,
           (12, 22, 256, True, False, 16)]
 
 
+if len(sys.argv) > 1:                                      # one shape per process: scripts/gpu_r6_z.sh runs each under its own timeout
+    SHAPES = [SHAPES[int(sys.argv[1])]]
+
+
 def timed(fn, reps=6):
     fn()
     torch.cuda.synchronize()
@@ -56,4 +60,5 @@ for H, W, C, relu, res, cnt in SHAPES:
           f'({fb / row[2][0] * 1e6:5.0f} -> {fb / row[3][0] * 1e6:5.0f} GB/s)   bwd {row[0][1]:7.1f} {row[2][1]:7.1f} | {row[1][1]:7.1f} {row[3][1]:7.1f} us '
           f'({bb / row[2][1] * 1e6:5.0f} -> {bb / row[3][1] * 1e6:5.0f} GB/s)', flush=True)
     del x, r, dy
-print(f"per step (54 layers): forward {tot[('fwd', False)] / 1e3:.2f} -> {tot[('fwd', True)] / 1e3:.2f} ms, backward {tot[('bwd', False)] / 1e3:.2f} -> {tot[('bwd', True)] / 1e3:.2f} ms")
+if len(sys.argv) == 1:
+    print(f"per step (54 layers): forward {tot[('fwd', False)] / 1e3:.2f} -> {tot[('fwd', True)] / 1e3:.2f} ms, backward {tot[('bwd', False)] / 1e3:.2f} -> {tot[('bwd', True)] / 1e3:.2f} ms")

@@ -1,0 +1,64 @@
+"""Round 6: GroupNorm's two passes per direction over GROUPS OF SAMPLES that fit the Infinity Cache (csrc/conv.hip, GN_GROUP_BYTES) against
+whole-batch passes (MERLOT_GN_GROUP_MB = 0: rounds 3 - 5), at the GroupNorm shapes of the as-shipped hybrid stem (192 x 352 frames, resnet_layers [3, 4, 9],
+896 frames per step = bench.py --native-yaml).  Experiments build, same box, every size twice in mirrored order.
+    python scripts/exp_gn_groups.py > gpurun_out/r06_z_gn_groups.txt"""
+import _exp_lib  # noqa: F401
+import os
+import torch
+from merlot_amd import ops
+
+BF16 = torch.bfloat16
+N = 896
+SIZES = (0, 32, 64, 96, 128)
+# (H, W, C, relu, res, layers of this shape in the stem)
+SHAPES = [(96, 176, 32, True, False, 2), (96, 176, 64, True, False, 1), (48, 88, 64, True, False, 6), (48, 88, 256, False, False, 1),
+          (48, 88, 256, True, True, 3), (48, 88, 128, True, False, 2), (24, 44, 512, False, False, 1), (24, 44, 512, True, True, 4),
+          (24, 44, 128, True, False, 6), (24, 44, 256, True, False, 2), (12, 22, 1024, False, False, 1), (12, 22, 1024, True, True, 9),
+          (12, 22, 256, True, False, 16)]
+
+
+def timed(fn, reps=6):
+    fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e3
+
+
+ops.GN_FUSED = False
+tot = {(d, s): 0.0 for d in ('fwd', 'bwd') for s in SIZES}
+print(f'N = {N} frames; us per call (best of the two mirrored runs) at MERLOT_GN_GROUP_MB = {SIZES} (0 = the whole batch per pass); tensor = MB of x', flush=True)
+for H, W, C, relu, res, cnt in SHAPES:
+    g = torch.Generator(device='cuda').manual_seed(0)
+    x = (torch.randn(N, H, W, C, generator=g, device='cuda') * 1.5 + 0.2).to(BF16)
+    r = torch.randn(N, H, W, C, generator=g, device='cuda').to(BF16) if res else None
+    dy = torch.randn(N, H, W, C, generator=g, device='cuda').to(BF16)
+    gamma = 1 + 0.1 * torch.randn(C, generator=g, device='cuda')
+    beta = 0.1 * torch.randn(C, generator=g, device='cuda')
+    dga, dbe = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+    best = {(d, s): 1e30 for d in ('fwd', 'bwd') for s in SIZES}
+    ref = None
+    for order in (SIZES, SIZES[::-1]):
+        for s in order:
+            os.environ['MERLOT_GN_GROUP_MB'] = str(s)
+            y, stats = ops.groupnorm_fwd(x, gamma, beta, res=r, relu=relu)
+            yy = y if (relu and res) else None
+            dx, _ = ops.groupnorm_bwd(dy, yy, x, stats, gamma, dga, dbe, beta=beta, relu=relu, want_dres=res)
+            if ref is None:
+                ref = (y.clone(), dx.clone())
+            else:                                              # same kernels, other grouping: outputs agree to the order of the fp32 atomics
+                assert (y.float() - ref[0].float()).abs().max() <= 0.0626 * ref[0].float().abs().max(), 'y'
+                assert (dx.float() - ref[1].float()).abs().max() <= 0.0626 * ref[1].float().abs().max(), 'dx'
+            best['fwd', s] = min(best['fwd', s], timed(lambda: ops.groupnorm_fwd(x, gamma, beta, res=r, relu=relu)))
+            best['bwd', s] = min(best['bwd', s], timed(lambda: ops.groupnorm_bwd(dy, yy, x, stats, gamma, dga, dbe, beta=beta, relu=relu, want_dres=res)))
+    for d in ('fwd', 'bwd'):
+        for s in SIZES:
+            tot[d, s] += best[d, s] * cnt
+    print(f'{H:3d}x{W:3d}x{C:4d} relu {int(relu)} res {int(res)} x{cnt:2d} ({x.numel() * 2 / 2**20:5.0f} MB): fwd ' + ' '.join(f'{best["fwd", s]:7.1f}' for s in SIZES) +
+          '   bwd ' + ' '.join(f'{best["bwd", s]:7.1f}' for s in SIZES), flush=True)
+    del x, r, dy
+print('per step (54 layers), ms: fwd ' + ' '.join(f'{tot["fwd", s] / 1e3:6.2f}' for s in SIZES) + '   bwd ' + ' '.join(f'{tot["bwd", s] / 1e3:6.2f}' for s in SIZES))
