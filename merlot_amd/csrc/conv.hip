@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const bf16* __restric
 // Items are CLAIMED from a counter, not derived from blockIdx: a workgroup only ever waits for items with smaller claim numbers
 // than slices it could itself still be waiting for -- items that running workgroups hold and finish without waiting for anybody --
 // so the wait terminates whatever order the hardware dispatches workgroups in and however many of them are resident.
-// Workspace (caller-owned, zeroed by the entry point): u32 ctr[16] | u32 arrive[N rounded to 16] | f32 sums[N][G][2] (forward) |
+// Workspace (caller-owned, zeroed by the entry point): u32 ctr[16] | u32 arrive[N][1024] (one counter per 4 KiB) | f32 sums[N][G][2] (forward) |
 // f32 chsum[N][C][2] (backward: per-sample channel sums; the sample's LAST arriver adds them to dgamma / dbeta -- N atomics per
 // address instead of N * split).
 // Every access to the shared words is a RELAXED device-scope atomic (performed at the memory side, coherent between the XCDs' L2s) and the order "my additions,
@@ -343,10 +343,13 @@ __device__ __forceinline__ void gn_add(float* p, float v) {   // returns only wh
 // one thread, behind a workgroup barrier that follows every thread's gn_add: count this workgroup in, wait for the sample's other slices; returns the arrival number
 __device__ __forceinline__ unsigned gn_arrive_and_wait(unsigned* slot, unsigned split) {
     const unsigned old = __hip_atomic_fetch_add(slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < split) __builtin_amdgcn_s_sleep(2);
+    while (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < split) __builtin_amdgcn_s_sleep(24);
     return old;
 }
-__host__ __device__ constexpr int64_t gn_ws_arrive_words(int N) { return (N + 15) & ~15; }
+// one arrival counter per 4 KiB: a few dozen samples are in flight at a time and every waiting workgroup polls its sample's counter -- with the counters of
+// consecutive samples 4 B apart, every poll and every arrival of the launch landed in one or two memory channels (calls 34 / 35: some shapes did not finish)
+constexpr int GN_ARRIVE_STRIDE = 1024;
+__host__ __device__ constexpr int64_t gn_ws_arrive_words(int N) { return (int64_t)N * GN_ARRIVE_STRIDE; }
 
 template <int ITER, bool RES>
 __global__ __launch_bounds__(256) void gn_fwd_fused_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(256) void gn_fwd_fused_kernel(const bf16* __restric
     __syncthreads();
     for (int i = tid; i < 2 * G; i += bd) gn_add(sums + (int64_t)n * 2 * G + i, gsm[i]);
     __syncthreads();                                       // every thread's additions are performed (returned) before thread 0 counts the workgroup in
-    if (tid == 0) gn_arrive_and_wait(arrive + n, (unsigned)split);
+    if (tid == 0) gn_arrive_and_wait(arrive + (int64_t)n * GN_ARRIVE_STRIDE, (unsigned)split);
     __syncthreads();
     for (int g = tid; g < G; g += bd) {
         const float mean = gn_ld(sums + ((int64_t)n * G + g) * 2) * inv_cnt;
@@ -534,7 +537,7 @@ __global__ __launch_bounds__(256) void gn_bwd_fused_kernel(const bf16* __restric
         gn_add(gsum + ((int64_t)n * G + g) * 2 + 1, gamma[c] * g_);
     }
     __syncthreads();
-    if (tid == 0) s_last = gn_arrive_and_wait(arrive + n, (unsigned)split) == (unsigned)split - 1u;
+    if (tid == 0) s_last = gn_arrive_and_wait(arrive + (int64_t)n * GN_ARRIVE_STRIDE, (unsigned)split) == (unsigned)split - 1u;
     __syncthreads();
     float* gs = gsm + 2 * C;
     for (int i = tid; i < 2 * G; i += bd) gs[i] = gn_ld(gsum + (int64_t)n * 2 * G + i);
@@ -664,21 +667,23 @@ extern "C" int merlot_col2im3x3(const void* x, void* dx, int N, int H, int W, in
     return merlot_launch_status("merlot_col2im3x3");
 }
 
-// Round 6: the two passes of a direction walk the batch in GROUPS OF SAMPLES whose tensors fit the 256 MiB Infinity Cache, so that the
-// second pass finds what the first one read (x forward; x | dy [| y] backward) on the die instead of in HBM: 8 tensor passes per layer become 5 HBM passes
-// without any workgroup waiting for another (the one-launch form above does that, and loses: profiles/r06_y_gn_fused.txt).  Same kernels, same grids per
-// sample, pointer offsets per group; results identical up to the order of the fp32 atomics (as between any two runs).  GN_GROUP_BYTES: bytes of the
-// re-read tensors per group (profiles/r06_z_gn_groups.txt for the sweep).
-constexpr int64_t GN_GROUP_BYTES = 64LL << 20;
-static int64_t gn_group_bytes() {
+// Round 6: the two passes of a direction can walk the batch in GROUPS OF SAMPLES whose tensors fit the 256 MiB Infinity Cache, so that the
+// second pass finds what the first one read (x forward; x | dy [| y] backward) on the die instead of in HBM -- 8 tensor passes per layer would become 5 HBM
+// passes without any workgroup waiting for another (the one-launch form above does that, and loses: profiles/r06_y_gn_fused.txt).  Same kernels, pointer
+// offsets per group.  MEASURED (profiles/r06_z_gn_groups.txt): with 64 MiB groups in both directions the as-shipped step went 400 -> 711 ms.  A group is a
+// few dozen samples and still has to fill 256 CUs, so a sample is cut into up to 64 slices instead of 3 -- and every backward block ends in 4C atomics on
+// dgamma / dbeta: 24 x 44 x 512 backward 2.0 -> 20 ms per call.  Groups are therefore OFF in the product (0 = the whole batch per pass, rounds 3 - 5); the
+// experiments build reads MERLOT_GN_GROUP_MB / MERLOT_GN_GROUP_MB_BWD for the per-shape sweep (scripts/exp_gn_groups.py).
+constexpr int64_t GN_GROUP_BYTES_FWD = 0, GN_GROUP_BYTES_BWD = 0;
+static int64_t gn_group_bytes(bool bwd) {
 #ifdef MERLOT_EXPERIMENTS
-    if (const char* e = getenv("MERLOT_GN_GROUP_MB")) return (int64_t)atoi(e) << 20;      // 0 = one group (rounds 3 - 5)
+    if (const char* e = getenv(bwd ? "MERLOT_GN_GROUP_MB_BWD" : "MERLOT_GN_GROUP_MB")) return (int64_t)atoi(e) << 20;
 #endif
-    return GN_GROUP_BYTES;
+    return bwd ? GN_GROUP_BYTES_BWD : GN_GROUP_BYTES_FWD;
 }
 // samples per group: whole samples, at least one; 0 bytes = everything in one group
-static int gn_group_samples(int N, int64_t bytes_per_sample) {
-    const int64_t lim = gn_group_bytes();
+static int gn_group_samples(int N, int64_t bytes_per_sample, bool bwd) {
+    const int64_t lim = gn_group_bytes(bwd);
     if (lim <= 0) return N;
     int64_t nb = lim / bytes_per_sample;
     if (nb < 1) nb = 1;
@@ -702,7 +707,7 @@ extern "C" int merlot_groupnorm_fwd(const void* x, const float* gamma, const flo
     const int HW = H * W;
     const int threads = gn_block_threads(C);
     const int64_t per = (int64_t)HW * C;                   // elements of one sample
-    const int nb_max = gn_group_samples(N, per * 2);
+    const int nb_max = gn_group_samples(N, per * 2, false);
     hipError_t e = hipMemsetAsync(stats, 0, sizeof(float) * 2 * (size_t)N * G, (hipStream_t)stream);
     MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
     for (int n0 = 0; n0 < N; n0 += nb_max) {
@@ -728,7 +733,7 @@ extern "C" int merlot_groupnorm_bwd(const void* dy, const void* y, const void* x
     const int HW = H * W;
     const int threads = gn_block_threads(C);
     const int64_t per = (int64_t)HW * C;
-    const int nb_max = gn_group_samples(N, per * 2 * (y ? 3 : 2));      // both passes read x | dy [| y]
+    const int nb_max = gn_group_samples(N, per * 2 * (y ? 3 : 2), true);      // both passes read x | dy [| y]
     hipError_t e = hipMemsetAsync(gsum, 0, sizeof(float) * 2 * (size_t)N * G, (hipStream_t)stream);
     MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
     for (int n0 = 0; n0 < N; n0 += nb_max) {

@@ -758,8 +758,8 @@ def col2im3x3(dpatches, N, H, W, C, stride=1):
 
 # GroupNorm in one launch per direction (merlot_groupnorm_*_fused, ABI v10).  Built, value-tested, and it LOSES: 1.7x (forward) / 2.3x (backward) the two-launch
 # entries at the first as-shipped shape and the as-shipped step did not finish inside 300 s (profiles/r06_x_gn_fused.txt, r06_y_gn_fused.txt) -- workgroups that
-# wait for other workgroups behind device-scope atomics.  OFF; bench.py --gn-fused turns it on for an A/B.  The two-launch entries walk the batch in groups of
-# samples that fit the Infinity Cache instead (csrc/conv.hip, GN_GROUP_BYTES).
+# wait for other workgroups behind device-scope atomics.  OFF; bench.py --gn-fused turns it on for an A/B.  (The other attempt at the same bytes -- the two-launch entries over groups of samples that fit the
+# Infinity Cache -- loses as well: csrc/conv.hip, GN_GROUP_BYTES_*.)
 GN_FUSED = False
 
 

@@ -9,7 +9,7 @@ from merlot_amd import ops
 
 BF16 = torch.bfloat16
 N = 896
-SIZES = (0, 32, 64, 96, 128)
+SIZES = (0, 32, 64, 128)
 # (H, W, C, relu, res, layers of this shape in the stem)
 SHAPES = [(96, 176, 32, True, False, 2), (96, 176, 64, True, False, 1), (48, 88, 64, True, False, 6), (48, 88, 256, False, False, 1),
           (48, 88, 256, True, True, 3), (48, 88, 128, True, False, 2), (24, 44, 512, False, False, 1), (24, 44, 512, True, True, 4),
@@ -44,17 +44,19 @@ for H, W, C, relu, res, cnt in SHAPES:
     ref = None
     for order in (SIZES, SIZES[::-1]):
         for s in order:
-            os.environ['MERLOT_GN_GROUP_MB'] = str(s)
+            os.environ['MERLOT_GN_GROUP_MB'] = os.environ['MERLOT_GN_GROUP_MB_BWD'] = str(s)
             y, stats = ops.groupnorm_fwd(x, gamma, beta, res=r, relu=relu)
             yy = y if (relu and res) else None
             dx, _ = ops.groupnorm_bwd(dy, yy, x, stats, gamma, dga, dbe, beta=beta, relu=relu, want_dres=res)
             if ref is None:
                 ref = (y.clone(), dx.clone())
-            else:                                              # same kernels, other grouping: outputs agree to the order of the fp32 atomics
-                assert (y.float() - ref[0].float()).abs().max() <= 0.0626 * ref[0].float().abs().max(), 'y'
-                assert (dx.float() - ref[1].float()).abs().max() <= 0.0626 * ref[1].float().abs().max(), 'dx'
+            else:        # same kernels, other grouping: the fp32 atomics' order moves the moments' last bits; an element at the ReLU threshold may flip with them
+                for got, want, what in ((y, ref[0], 'y'), (dx, ref[1], 'dx')):
+                    err = float((got.float() - want.float()).norm() / want.float().norm())
+                    assert err < 2e-2, (what, s, err)
             best['fwd', s] = min(best['fwd', s], timed(lambda: ops.groupnorm_fwd(x, gamma, beta, res=r, relu=relu)))
-            best['bwd', s] = min(best['bwd', s], timed(lambda: ops.groupnorm_bwd(dy, yy, x, stats, gamma, dga, dbe, beta=beta, relu=relu, want_dres=res)))
+            if best['bwd', s] < 5e3 or best['bwd', s] > 1e29:   # (a grouping that took > 5 ms once is not timed a second time)
+                best['bwd', s] = min(best['bwd', s], timed(lambda: ops.groupnorm_bwd(dy, yy, x, stats, gamma, dga, dbe, beta=beta, relu=relu, want_dres=res), 3))
     for d in ('fwd', 'bwd'):
         for s in SIZES:
             tot[d, s] += best[d, s] * cnt

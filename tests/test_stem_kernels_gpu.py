@@ -136,35 +136,6 @@ def test_groupnorm_forward_backward(ops, gn_mode, N, H, W, C, relu, res):
             ops.groupnorm_bwd(dy.cuda(), None, x.cuda(), stats, gamma.cuda(), dga2, dbe2, relu=True)
 
 
-def test_groupnorm_walks_a_large_batch_in_cache_sized_groups(ops):
-    """csrc/conv.hip GN_GROUP_BYTES (round 6): above 64 MiB of re-read tensors the two passes of a direction run per group of samples (here 150 samples of
-    1.03 MiB: 62 + 62 + 26 forward, five groups backward, ragged last groups).  Against the same entries called on slices of 20 samples (one group each):
-    same kernels, same per-sample arithmetic; only the fp32 atomics' order differs."""
-    g = torch.Generator(device='cuda').manual_seed(5)
-    N, H, W, C = 150, 96, 176, 32
-    x = (torch.randn(N, H, W, C, generator=g, device='cuda') * 2 + 0.3).to(BF16)
-    dy = torch.randn(N, H, W, C, generator=g, device='cuda').to(BF16)
-    gamma = (1 + 0.1 * torch.randn(C, generator=g, device='cuda'))
-    beta = 0.1 * torch.randn(C, generator=g, device='cuda')
-    was = ops.GN_FUSED
-    ops.GN_FUSED = False
-    try:
-        y, stats = ops.groupnorm_fwd(x, gamma, beta, relu=True)
-        dga, dbe = torch.zeros(C).cuda(), torch.zeros(C).cuda()
-        dx, _ = ops.groupnorm_bwd(dy, None, x, stats, gamma, dga, dbe, beta=beta, relu=True)
-        dga_p, dbe_p = torch.zeros(C).cuda(), torch.zeros(C).cuda()
-        for n0 in range(0, N, 20):
-            sl = slice(n0, min(N, n0 + 20))
-            y_p, st_p = ops.groupnorm_fwd(x[sl].contiguous(), gamma, beta, relu=True)
-            assert rel_l2(st_p, stats[sl]) < 1e-5
-            assert rel_l2(y_p, y[sl]) < 1e-4
-            dx_p, _ = ops.groupnorm_bwd(dy[sl].contiguous(), None, x[sl].contiguous(), stats[sl].contiguous(), gamma, dga_p, dbe_p, beta=beta, relu=True)
-            assert rel_l2(dx_p, dx[sl]) < 1e-4
-        assert rel_l2(dga_p, dga) < 1e-4 and rel_l2(dbe_p, dbe) < 1e-4
-    finally:
-        ops.GN_FUSED = was
-
-
 def test_avgpool2(ops):
     g = torch.Generator().manual_seed(2)
     x = torch.randn(3, 12, 8, 64, generator=g).to(BF16)
