@@ -104,14 +104,16 @@ def test_attention_backward_loops():
     assert len(p2) == 1 and _valu(p2[0]) <= 76 and p2[0]['v_add_u32_e32'] <= 10, p2       # 115 vector-ALU / 38 address additions before
     assert p2[0]['ds_read_b128'] == 16 and p2[0]['ds_read_b64_tr_b16'] == 16
     # the fused backward of the joint encoder (masked + attention log): two copies of the dK / dV chunk loop (the wave's two key blocks)
-    body, vg = _kernel(lines, r'attn_bwd_fused_kernelILi512ELb1ELb1E')
-    assert vg <= 244, vg
-    p2 = _loops(body, 16)
-    assert len(p2) == 2 and all(_valu(c) <= 145 and c['v_add_u32_e32'] <= 10 for c in p2), p2      # 164 / 187 and 34 address additions before
-    body, vg = _kernel(lines, r'attn_bwd_fused_kernelILi512ELb1ELb0E')
-    p2 = _loops(body, 16)
-    assert len(p2) == 2 and all(_valu(c) <= 108 and c['v_add_u32_e32'] <= 10 for c in p2), p2      # 131 / 156 before
-
+    # (both forms of the image arrival are in the product since the per-token-count rule of fb_bwd: <.., BPW = 2, CH = false | true>, the same chunk loops)
+    for ch in (0, 1):
+        body, vg = _kernel(lines, r'attn_bwd_fused_kernelILi512ELb1ELb1ELi2ELb%dE' % ch)
+        assert vg <= 244, (ch, vg)
+        p2 = _loops(body, 16)
+        # (the chunked form's first copy carries the counted waits for the arriving row groups between its MFMAs: only its second copy is a plain 16-MFMA loop)
+        assert len(p2) == 2 - ch and all(_valu(c) <= 145 and c['v_add_u32_e32'] <= 10 for c in p2), (ch, p2)      # 164 / 187 and 34 address additions before
+        body, vg = _kernel(lines, r'attn_bwd_fused_kernelILi512ELb1ELb0ELi2ELb%dE' % ch)
+        p2 = _loops(body, 16)
+        assert len(p2) == 2 - ch and all(_valu(c) <= 108 and c['v_add_u32_e32'] <= 10 for c in p2), (ch, p2)      # 131 / 156 before
 
 def test_gemm_main_loops():
     lines = _compile('gemm.hip')
