@@ -244,8 +244,8 @@ def main():
     ap.add_argument('--no-tn-colsum', action='store_true', help='A/B only: the Q-third bias gradient as a stand-alone column-sum pass over dQKV (rounds 1-5) instead of merlot_gemm_bf16_tn_cs')
     ap.add_argument('--ln-fold', action='store_true', help='A/B only: the LayerNorm behind every residual GEMM from that GEMM\'s launch (merlot_gemm_bf16_nt_ln, round 6: measured level to 0.4 %% slower, off by default)')
     ap.add_argument('--no-ln-fold', action='store_true', help=argparse.SUPPRESS)   # (the default since the A/B; kept so that round 6's scripts still run)
-    ap.add_argument('--gn-fused', action='store_true', help='A/B only (hybrid stem): GroupNorm in one launch per direction (merlot_groupnorm_*_fused, ABI v10: measured 1.7-2.3x slower, off by default)')
-    ap.add_argument('--no-gn-fused', action='store_true', help=argparse.SUPPRESS)   # (the default since the A/B; kept so that round 6's scripts still run)
+    ap.add_argument('--gn-fused', action='store_true', help='A/B only (hybrid stem): GroupNorm in one launch in BOTH directions (default: one-launch forward, two-launch backward -- the one-launch backward is slower on every shape)')
+    ap.add_argument('--no-gn-fused', action='store_true', help='A/B only (hybrid stem): GroupNorm as two launches per direction (rounds 3-5)')
     ap.add_argument('--exp-lib', action='store_true', help=argparse.SUPPRESS)       # A/B only: run on libmerlot_hip_exp.so (reads the MERLOT_* experiment switches)
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--cpu-baseline-worker', type=int, default=0, help=argparse.SUPPRESS)
@@ -268,7 +268,8 @@ def main():
     from merlot_amd import NeatConfig, ops
     from merlot_amd.parallel import DistContext
     from merlot_amd.train import Trainer, synthetic_batch
-    ops.GN_FUSED = bool(args.gn_fused)
+    if args.gn_fused or args.no_gn_fused:
+        ops.GN_FUSED = bool(args.gn_fused)
     if args.ln_fold or args.no_tn_colsum:
         from merlot_amd import layers
         layers.FUSE_LN = bool(args.ln_fold)

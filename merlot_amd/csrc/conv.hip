@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void gn_fwd_fused_kernel(const bf16* __restric
     const int chunk = tid % cpr, prow = tid / cpr, pstep = bd / cpr;
     const int pbase = sl * (ITER * pstep) + prow;
     const int64_t off0 = ((int64_t)n * HW) * C + chunk * 8;
-    bf16x8 v[ITER], r8[RES ? ITER : 1];
+    bf16x8 v[ITER];
 #pragma unroll
     for (int i = 0; i < ITER; ++i) {
         const int p = pbase + i * pstep;
@@ -378,13 +378,6 @@ __global__ __launch_bounds__(256) void gn_fwd_fused_kernel(const bf16* __restric
         for (int e = 0; e < 8; ++e) z[e] = (bf16)0.f;
         v[i] = z;
         if (p < HW) v[i] = *reinterpret_cast<const bf16x8*>(x + off0 + (int64_t)p * C);
-    }
-    if (RES) {
-#pragma unroll
-        for (int i = 0; i < ITER; ++i) {
-            const int p = pbase + i * pstep;
-            if (p < HW) r8[i] = *reinterpret_cast<const bf16x8*>(res + off0 + (int64_t)p * C);
-        }
     }
     float gam[8], bet[8];
 #pragma unroll
@@ -437,18 +430,32 @@ __global__ __launch_bounds__(256) void gn_fwd_fused_kernel(const bf16* __restric
     float sc[8], sh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) gn_affine(gsm[2 * G + 2 * gidx[e]], gsm[2 * G + 2 * gidx[e] + 1], gam[e], bet[e], sc[e], sh[e]);
+    // (the residual is read HERE, behind the wait, not held across it: with 16 instead of 8 positions per thread a sample is half as many slices --
+    // 48 x 88 x 256 + residual with 8: 1 520 us against 1 570 for two launches, profiles/r06_z3_gn_fused_fwd.txt)
+    constexpr int RB = RES ? 4 : 1;                        // residual loads in flight per thread
 #pragma unroll
-    for (int i = 0; i < ITER; ++i) {
-        const int p = pbase + i * pstep;
-        bf16x8 o;
+    for (int i0 = 0; i0 < ITER; i0 += RB) {
+        bf16x8 r8[RB];
+        if (RES) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float f = gn_y((float)v[i][e], sc[e], sh[e]);
-            if (RES) f += (float)r8[i][e];
-            if (relu) f = fmaxf(f, 0.f);
-            o[e] = (bf16)f;
+            for (int j = 0; j < RB; ++j) {
+                const int p = pbase + (i0 + j) * pstep;
+                if (p < HW) r8[j] = *reinterpret_cast<const bf16x8*>(res + off0 + (int64_t)p * C);
+            }
         }
-        if (p < HW) *reinterpret_cast<bf16x8*>(y + off0 + (int64_t)p * C) = o;
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            const int i = i0 + j, p = pbase + i * pstep;
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = gn_y((float)v[i][e], sc[e], sh[e]);
+                if (RES) f += (float)r8[j][e];
+                if (relu) f = fmaxf(f, 0.f);
+                o[e] = (bf16)f;
+            }
+            if (p < HW) *reinterpret_cast<bf16x8*>(y + off0 + (int64_t)p * C) = o;
+        }
     }
 }
 
@@ -772,7 +779,7 @@ extern "C" int merlot_groupnorm_fwd_fused(const void* x, const float* gamma, con
     const int HW = H * W;
     const int threads = gn_block_threads(C);
     const int pstep = threads / (C / 8);
-    const int iter = res ? 8 : 16;
+    const int iter = 16;
     const int split = (HW + iter * pstep - 1) / (iter * pstep);
     MERLOT_CHECK((int64_t)N * split < (1LL << 31), MERLOT_ESHAPE, "merlot_groupnorm_fwd_fused: too many slices");
     hipError_t e = hipMemsetAsync(ws, 0, 4 * (16 + gn_ws_arrive_words(N) + (size_t)N * 2 * G), (hipStream_t)stream);
@@ -780,7 +787,7 @@ extern "C" int merlot_groupnorm_fwd_fused(const void* x, const float* gamma, con
     const float inv_cnt = 1.0f / ((float)HW * (float)(C / G));
     const size_t lds = sizeof(float) * 4 * G;
     if (res)
-        hipLaunchKernelGGL((gn_fwd_fused_kernel<8, true>), dim3(N * split), dim3(threads), lds, (hipStream_t)stream, (const bf16*)x, gamma, beta,
+        hipLaunchKernelGGL((gn_fwd_fused_kernel<16, true>), dim3(N * split), dim3(threads), lds, (hipStream_t)stream, (const bf16*)x, gamma, beta,
                            (const bf16*)res, (bf16*)y, stats, (unsigned*)ws, N, HW, C, G, relu, split, inv_cnt, eps);
     else
         hipLaunchKernelGGL((gn_fwd_fused_kernel<16, false>), dim3(N * split), dim3(threads), lds, (hipStream_t)stream, (const bf16*)x, gamma, beta,

@@ -756,11 +756,11 @@ def col2im3x3(dpatches, N, H, W, C, stride=1):
     return dx
 
 
-# GroupNorm in one launch per direction (merlot_groupnorm_*_fused, ABI v10).  Built, value-tested, and it LOSES: 1.7x (forward) / 2.3x (backward) the two-launch
-# entries at the first as-shipped shape and the as-shipped step did not finish inside 300 s (profiles/r06_x_gn_fused.txt, r06_y_gn_fused.txt) -- workgroups that
-# wait for other workgroups behind device-scope atomics.  OFF; bench.py --gn-fused turns it on for an A/B.  (The other attempt at the same bytes -- the two-launch entries over groups of samples that fit the
-# Infinity Cache -- loses as well: csrc/conv.hip, GN_GROUP_BYTES_*.)
-GN_FUSED = False
+# GroupNorm in one launch per direction (merlot_groupnorm_*_fused, ABI v10), measured per shape of the as-shipped stem at 896 frames (profiles/r06_z2_gn_fused_shapes.txt,
+# r06_z3_gn_fused_fwd.txt): the FORWARD wins on all thirteen shapes (-3 ... -50 %: x is read once) and the BACKWARD loses on all of them (x1.4 ... x15: four returning
+# device-scope atomics per channel and workgroup).  'fwd' (default) = one-launch forward, two-launch backward; True = both one-launch; False = both two-launch
+# (bench.py --gn-fused / --no-gn-fused).
+GN_FUSED = 'fwd'
 
 
 def _gn_ws(device, N, C, groups):
@@ -793,7 +793,7 @@ def groupnorm_bwd(dy, y, x, stats, gamma, dgamma, dbeta, *, beta=None, relu=True
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
     gsum = torch.empty((N, groups, 2), device=x.device, dtype=F32)
-    if GN_FUSED:                                           # one launch, x | dy read once (ABI v10)
+    if GN_FUSED is True:                                   # one launch, x | dy read once (ABI v10; slower than the two launches below on every measured shape)
         ws = _gn_ws(x.device, N, C, groups)
         call('merlot_groupnorm_bwd_fused', _p(dy), _p(y), _p(x), _p(stats), _p(gamma), _p(beta), _p(dgamma), _p(dbeta), _p(gsum), _p(dx),
              _p(dres), N, H, W, C, groups, float(eps), 1 if relu else 0, _p(ws), ws.numel() * 4, _stream())

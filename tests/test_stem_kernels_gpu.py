@@ -93,7 +93,8 @@ def test_conv3x3_rejects_what_the_kernel_cannot_take(ops):
 
 @pytest.fixture(params=[True, False], ids=['one-launch', 'two-launch'])
 def gn_mode(ops, request):
-    """both GroupNorm implementations: the two-launch entries (the default) and merlot_groupnorm_*_fused (ABI v10: built, slower, off -- ops.GN_FUSED)"""
+    """both GroupNorm implementations in both directions: merlot_groupnorm_*_fused (ABI v10) and the two-launch entries; the product default (ops.GN_FUSED = 'fwd') is the
+    one-launch forward with the two-launch backward"""
     was = ops.GN_FUSED
     ops.GN_FUSED = request.param
     yield request.param
