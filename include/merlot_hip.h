@@ -460,8 +460,13 @@ int merlot_groupnorm_bwd(const void* dy, const void* y, const void* x, const flo
  * keeps its slice of a sample in registers between "reduce the moments" and "normalise", the slices of a sample meet at a counter in the
  * caller-owned workspace -- x is read once forward and x | dy once backward (5 tensor passes per layer instead of 8; the as-shipped
  * 192 x 352 hybrid stem of model/configs/merlot.yaml:30,36 spends 17 % of its step in GroupNorm, utils/model_utils.py:133-222).
- * ws: merlot_groupnorm_fused_workspace_bytes(N, C, G) bytes, 16-B aligned, any content (zeroed by the call, on `stream`); one block per call in
- * flight.  All other arguments as in merlot_groupnorm_fwd / merlot_groupnorm_bwd. */
+ * ws: merlot_groupnorm_fused_workspace_bytes(N, C, G) bytes (4 KiB + the sample's sums per sample: the arrival counters of consecutive samples lie in
+ * different memory channels), 16-B aligned, any content (zeroed by the call, on `stream`); one block per call in flight.  All other arguments as in
+ * merlot_groupnorm_fwd / merlot_groupnorm_bwd.
+ * Measured at the thirteen GroupNorm shapes of the as-shipped stem, 896 frames (profiles/r06_z3_gn_fused_fwd.txt, r06_z2_gn_fused_shapes.txt): the FORWARD is faster
+ * than merlot_groupnorm_fwd on every shape (-3 ... -50 %) and is what merlot_amd runs; the BACKWARD is slower than merlot_groupnorm_bwd on every shape (x1.4 ... x15:
+ * four returning device-scope atomics per channel and workgroup where the two-launch form issues fire-and-forget ones from 3 blocks per sample) -- it is exported,
+ * value-tested and NOT used. */
 int64_t merlot_groupnorm_fused_workspace_bytes(int N, int C, int G);
 int merlot_groupnorm_fwd_fused(const void* x, const float* gamma, const float* beta, const void* res, void* y, float* stats,
                                int N, int H, int W, int C, int G, float eps, int relu, void* ws, int64_t ws_bytes, merlot_stream_t stream);

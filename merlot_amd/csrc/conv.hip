@@ -351,7 +351,7 @@ __device__ __forceinline__ unsigned gn_arrive_and_wait(unsigned* slot, unsigned 
 constexpr int GN_ARRIVE_STRIDE = 1024;
 __host__ __device__ constexpr int64_t gn_ws_arrive_words(int N) { return (int64_t)N * GN_ARRIVE_STRIDE; }
 
-template <int ITER, bool RES>
+template <int ITER, bool RES, bool HOLD = false>
 __global__ __launch_bounds__(256) void gn_fwd_fused_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const bf16* __restrict__ res,
                                                            bf16* __restrict__ y, float* __restrict__ stats, unsigned* __restrict__ ws,
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void gn_fwd_fused_kernel(const bf16* __restric
     const int chunk = tid % cpr, prow = tid / cpr, pstep = bd / cpr;
     const int pbase = sl * (ITER * pstep) + prow;
     const int64_t off0 = ((int64_t)n * HW) * C + chunk * 8;
-    bf16x8 v[ITER];
+    bf16x8 v[ITER], rh[(RES && HOLD) ? ITER : 1];          // HOLD: the residual requested in front of the wait and held across it
 #pragma unroll
     for (int i = 0; i < ITER; ++i) {
         const int p = pbase + i * pstep;
@@ -378,6 +378,13 @@ __global__ __launch_bounds__(256) void gn_fwd_fused_kernel(const bf16* __restric
         for (int e = 0; e < 8; ++e) z[e] = (bf16)0.f;
         v[i] = z;
         if (p < HW) v[i] = *reinterpret_cast<const bf16x8*>(x + off0 + (int64_t)p * C);
+    }
+    if (RES && HOLD) {
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) {
+            const int p = pbase + i * pstep;
+            if (p < HW) rh[i] = *reinterpret_cast<const bf16x8*>(res + off0 + (int64_t)p * C);
+        }
     }
     float gam[8], bet[8];
 #pragma unroll
@@ -430,8 +437,9 @@ __global__ __launch_bounds__(256) void gn_fwd_fused_kernel(const bf16* __restric
     float sc[8], sh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) gn_affine(gsm[2 * G + 2 * gidx[e]], gsm[2 * G + 2 * gidx[e] + 1], gam[e], bet[e], sc[e], sh[e]);
-    // (the residual is read HERE, behind the wait, not held across it: with 16 instead of 8 positions per thread a sample is half as many slices --
-    // 48 x 88 x 256 + residual with 8: 1 520 us against 1 570 for two launches, profiles/r06_z3_gn_fused_fwd.txt)
+    // The residual: either held across the wait (HOLD, 8 positions per thread) or read HERE, behind it, with 16 positions per thread -- half as many slices per sample.
+    // Measured (profiles/r06_z3_gn_fused_fwd.txt | r06_z4_gn_fused_fwd.txt): 48 x 88 x 256 (66 | 33 slices) 1 520 | 1 330 us, 24 x 44 x 512 (33 | 17) 618 | 638,
+    // 12 x 22 x 1024 (17 | 9) 297 | 333: the host takes the late read where holding would cut a sample into more than 40 slices.
     constexpr int RB = RES ? 4 : 1;                        // residual loads in flight per thread
 #pragma unroll
     for (int i0 = 0; i0 < ITER; i0 += RB) {
@@ -440,7 +448,7 @@ __global__ __launch_bounds__(256) void gn_fwd_fused_kernel(const bf16* __restric
 #pragma unroll
             for (int j = 0; j < RB; ++j) {
                 const int p = pbase + (i0 + j) * pstep;
-                if (p < HW) r8[j] = *reinterpret_cast<const bf16x8*>(res + off0 + (int64_t)p * C);
+                if (!HOLD && p < HW) r8[j] = *reinterpret_cast<const bf16x8*>(res + off0 + (int64_t)p * C);
             }
         }
 #pragma unroll
@@ -450,7 +458,7 @@ __global__ __launch_bounds__(256) void gn_fwd_fused_kernel(const bf16* __restric
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float f = gn_y((float)v[i][e], sc[e], sh[e]);
-                if (RES) f += (float)r8[j][e];
+                if (RES) f += (float)(HOLD ? rh[i][e] : r8[j][e]);
                 if (relu) f = fmaxf(f, 0.f);
                 o[e] = (bf16)f;
             }
@@ -779,14 +787,18 @@ extern "C" int merlot_groupnorm_fwd_fused(const void* x, const float* gamma, con
     const int HW = H * W;
     const int threads = gn_block_threads(C);
     const int pstep = threads / (C / 8);
-    const int iter = 16;
+    const bool hold = res && (HW + 8 * pstep - 1) / (8 * pstep) <= 40;      // (see the kernel: the residual held across the wait, or read behind it)
+    const int iter = hold ? 8 : 16;
     const int split = (HW + iter * pstep - 1) / (iter * pstep);
     MERLOT_CHECK((int64_t)N * split < (1LL << 31), MERLOT_ESHAPE, "merlot_groupnorm_fwd_fused: too many slices");
     hipError_t e = hipMemsetAsync(ws, 0, 4 * (16 + gn_ws_arrive_words(N) + (size_t)N * 2 * G), (hipStream_t)stream);
     MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
     const float inv_cnt = 1.0f / ((float)HW * (float)(C / G));
     const size_t lds = sizeof(float) * 4 * G;
-    if (res)
+    if (res && hold)
+        hipLaunchKernelGGL((gn_fwd_fused_kernel<8, true, true>), dim3(N * split), dim3(threads), lds, (hipStream_t)stream, (const bf16*)x, gamma, beta,
+                           (const bf16*)res, (bf16*)y, stats, (unsigned*)ws, N, HW, C, G, relu, split, inv_cnt, eps);
+    else if (res)
         hipLaunchKernelGGL((gn_fwd_fused_kernel<16, true>), dim3(N * split), dim3(threads), lds, (hipStream_t)stream, (const bf16*)x, gamma, beta,
                            (const bf16*)res, (bf16*)y, stats, (unsigned*)ws, N, HW, C, G, relu, split, inv_cnt, eps);
     else

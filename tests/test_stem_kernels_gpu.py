@@ -103,11 +103,12 @@ def gn_mode(ops, request):
 
 # (the last four: several slices per sample with a ragged last one -- 1 760 positions of 64 channels = 4 forward / 7 backward slices --, a
 # channel count whose 16-byte chunks do not divide 256 threads and whose groups of 3 channels straddle a thread's 8, one slice wider than the
-# sample, and the as-shipped geometry's largest per-sample tensor)
+# sample, the as-shipped geometry's largest per-sample tensor, and its largest layer with a residual -- the one-launch forward's late residual read: 33 slices of 16 positions
+# per thread where holding the residual across the wait would make 66)
 @pytest.mark.parametrize('N,H,W,C,relu,res', [(3, 8, 8, 32, True, False), (2, 14, 14, 256, False, False),
                                                (2, 7, 9, 1024, True, True), (4, 16, 16, 64, True, False),
                                                (3, 40, 44, 64, True, True), (2, 10, 11, 96, True, False), (5, 3, 3, 256, False, True),
-                                               (2, 96, 176, 64, True, False)])
+                                               (2, 96, 176, 64, True, False), (2, 48, 88, 256, True, True)])
 def test_groupnorm_forward_backward(ops, gn_mode, N, H, W, C, relu, res):
     g = torch.Generator().manual_seed(1)
     x = (torch.randn(N, H, W, C, generator=g) * 2 + 0.3).to(BF16)
