@@ -33,7 +33,7 @@ typedef void* merlot_stream_t;
 
 /* Bumped whenever a signature of this header changes.  merlot_abi_version() returns the value the library was built with;
  * a binding must compare the two before its first call (merlot_amd/lib.py does, and refuses a mismatching library). */
-#define MERLOT_ABI_VERSION 10
+#define MERLOT_ABI_VERSION 11
 
 const char* merlot_last_error(void);
 int merlot_abi_version(void);
@@ -463,11 +463,13 @@ int merlot_groupnorm_bwd(const void* dy, const void* y, const void* x, const flo
  * ws: merlot_groupnorm_fused_workspace_bytes(N, C, G) bytes (4 KiB + the sample's sums per sample: the arrival counters of consecutive samples lie in
  * different memory channels), 16-B aligned, any content (zeroed by the call, on `stream`); one block per call in flight.  All other arguments as in
  * merlot_groupnorm_fwd / merlot_groupnorm_bwd.
- * Measured at the thirteen GroupNorm shapes of the as-shipped stem, 896 frames (profiles/r06_z3_gn_fused_fwd.txt, r06_z2_gn_fused_shapes.txt): the FORWARD is faster
- * than merlot_groupnorm_fwd on every shape (-3 ... -50 %) and is what merlot_amd runs; the BACKWARD is slower than merlot_groupnorm_bwd on every shape (x1.4 ... x15:
- * four returning device-scope atomics per channel and workgroup where the two-launch form issues fire-and-forget ones from 3 blocks per sample) -- it is exported,
- * value-tested and NOT used. */
+ * The backward's workspace (ABI v11) is merlot_groupnorm_bwd_fused_workspace_bytes(N, H, W, C, G): besides the control blocks one slot of (C + G) float pairs per
+ * (sample, slice) -- every workgroup STORES its slice's sums there and arrives with one atomic, the sample's last arriver adds the slots up (ABI v10's backward sent four
+ * returning device-scope atomics per channel and workgroup and was x1.4 ... x15 slower than merlot_groupnorm_bwd on every shape, profiles/r06_z2_gn_fused_shapes.txt).
+ * Measured at the thirteen GroupNorm shapes of the as-shipped stem, 896 frames (profiles/r06_z3_gn_fused_fwd.txt, r06_z4_gn_fused_fwd.txt): the FORWARD is faster than
+ * merlot_groupnorm_fwd on every shape (-3 ... -50 %) and is what merlot_amd runs. */
 int64_t merlot_groupnorm_fused_workspace_bytes(int N, int C, int G);
+int64_t merlot_groupnorm_bwd_fused_workspace_bytes(int N, int H, int W, int C, int G);
 int merlot_groupnorm_fwd_fused(const void* x, const float* gamma, const float* beta, const void* res, void* y, float* stats,
                                int N, int H, int W, int C, int G, float eps, int relu, void* ws, int64_t ws_bytes, merlot_stream_t stream);
 int merlot_groupnorm_bwd_fused(const void* dy, const void* y, const void* x, const float* stats, const float* gamma, const float* beta,

@@ -328,13 +328,16 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const bf16* __restric
 // Items are CLAIMED from a counter, not derived from blockIdx: a workgroup only ever waits for items with smaller claim numbers
 // than slices it could itself still be waiting for -- items that running workgroups hold and finish without waiting for anybody --
 // so the wait terminates whatever order the hardware dispatches workgroups in and however many of them are resident.
-// Workspace (caller-owned, zeroed by the entry point): u32 ctr[16] | u32 arrive[N][1024] (one counter per 4 KiB) | f32 sums[N][G][2] (forward) |
-// f32 chsum[N][C][2] (backward: per-sample channel sums; the sample's LAST arriver adds them to dgamma / dbeta -- N atomics per
-// address instead of N * split).
-// Every access to the shared words is a RELAXED device-scope atomic (performed at the memory side, coherent between the XCDs' L2s) and the order "my additions,
-// then my arrival" comes from WAITING FOR THE ADDITIONS' RETURN VALUES, not from fences: a release / acquire pair at device scope is an L2 write-back + invalidate
-// (buffer_wbl2 / buffer_inv sc1) per wave -- with tens of thousands of workgroups per launch, each between other workgroups' output stores, the first version of
+// Workspace (caller-owned, its control words zeroed by the entry point): u32 ctr[16] | u32 ctl[N][1024] (a sample's arrival counter and "published" flag: one 4 KiB block
+// per sample, so that the polls and arrivals of the few dozen samples in flight spread over the memory channels) | forward: f32 sums[N][G][2]; backward:
+// f32 slots[N][split][C + G][2] -- one slot per (sample, slice) for the slice's channel sums {dgamma_c, dbeta_c} and its two sums per group.
+// FORWARD: every access to the shared sums is a RELAXED device-scope atomic (performed at the memory side, coherent between the XCDs' L2s) and the order "my additions,
+// then my arrival" comes from WAITING FOR THE ADDITIONS' RETURN VALUES (2G per workgroup), not from fences: a release / acquire pair at device scope is an L2 write-back +
+// invalidate (buffer_wbl2 / buffer_inv sc1) per wave -- with tens of thousands of workgroups per launch, each between other workgroups' output stores, the first version of
 // these kernels (release on the arrival, __threadfence() in front of it) ran the as-shipped step into a 600 s timeout where the two-launch form takes 0.4 s.
+// BACKWARD: 4C returning atomics per workgroup were the whole cost of its first version; now a workgroup STORES its sums to its slot (write-through, waited for with
+// s_waitcnt), arrives with one atomic, the sample's last arriver adds the slots up -- channel sums into dgamma / dbeta (N atomics per address, not N * split), group sums into
+// gsum, published with a flag the other slices poll.
 __device__ __forceinline__ float gn_ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void gn_add(float* p, float v) {   // returns only when the addition has been performed
     const float old = __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -349,6 +352,16 @@ __device__ __forceinline__ unsigned gn_arrive_and_wait(unsigned* slot, unsigned 
 // one arrival counter per 4 KiB: a few dozen samples are in flight at a time and every waiting workgroup polls its sample's counter -- with the counters of
 // consecutive samples 4 B apart, every poll and every arrival of the launch landed in one or two memory channels (calls 34 / 35: some shapes did not finish)
 constexpr int GN_ARRIVE_STRIDE = 1024;
+// a pair of floats as ONE relaxed device-scope access (8-B aligned): a write-through store / a load that does not trust this XCD's L2
+__device__ __forceinline__ void gn_st2(float* p, float a, float b) {
+    const unsigned long long v = ((unsigned long long)__float_as_uint(b) << 32) | (unsigned long long)__float_as_uint(a);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void gn_ld2(const float* p, float& a, float& b) {
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a = __uint_as_float((unsigned)v);
+    b = __uint_as_float((unsigned)(v >> 32));
+}
 __host__ __device__ constexpr int64_t gn_ws_arrive_words(int N) { return (int64_t)N * GN_ARRIVE_STRIDE; }
 
 template <int ITER, bool RES, bool HOLD = false>
@@ -478,10 +491,10 @@ __global__ __launch_bounds__(256) void gn_bwd_fused_kernel(const bf16* __restric
     extern __shared__ float gsm[];                         // [C][2] per-channel partials of this slice, then [G][2] the sample's gsum
     __shared__ int s_item, s_last;
     unsigned* arrive = ws + 16;
-    float* chsum = reinterpret_cast<float*>(ws + 16 + gn_ws_arrive_words(N));
+    float* slots = reinterpret_cast<float*>(ws + 16 + gn_ws_arrive_words(N));     // [N][split][C + G][2]
     const int tid = threadIdx.x, bd = blockDim.x;
     if (tid == 0) s_item = (int)__hip_atomic_fetch_add(ws, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int i = tid; i < 2 * C; i += bd) gsm[i] = 0.f;
+    for (int i = tid; i < 2 * (C + G); i += bd) gsm[i] = 0.f;
     __syncthreads();
     const int item = s_item, n = item / split, sl = item - n * split;
     const int cpr = C / 8, cpg = C / G;
@@ -543,24 +556,69 @@ __global__ __launch_bounds__(256) void gn_bwd_fused_kernel(const bf16* __restric
         atomicAdd(&gsm[2 * (chunk * 8 + e) + 1], db[e]);
     }
     __syncthreads();
+    // This slice's sums go to ITS slot of the workspace with write-through stores, not into shared sums with atomics (the first version: four RETURNING device-scope
+    // atomics per channel and workgroup -- x1.4 ... x15 the two-launch time, profiles/r06_z2_gn_fused_shapes.txt): per workgroup one claim, one arrival, one poll loop.
+    float* gs = gsm + 2 * C;                               // [G][2]: this slice's {sum gamma * dbeta_c, sum gamma * dgamma_c} per group
+    const int P = C + G;                                   // pairs per slot: [C] {dgamma_c, dbeta_c} | [G] the two group sums
+    float* const slot0 = slots + (int64_t)n * split * 2 * P;
+    float* const slot = slot0 + (int64_t)sl * 2 * P;
     for (int c = tid; c < C; c += bd) {
         const float g_ = gsm[2 * c], b_ = gsm[2 * c + 1];
-        gn_add(chsum + ((int64_t)n * C + c) * 2, g_);
-        gn_add(chsum + ((int64_t)n * C + c) * 2 + 1, b_);
+        gn_st2(slot + 2 * c, g_, b_);
         const int g = c / cpg;
-        gn_add(gsum + ((int64_t)n * G + g) * 2, gamma[c] * b_);
-        gn_add(gsum + ((int64_t)n * G + g) * 2 + 1, gamma[c] * g_);
+        atomicAdd(&gs[2 * g], gamma[c] * b_);
+        atomicAdd(&gs[2 * g + 1], gamma[c] * g_);
     }
     __syncthreads();
-    if (tid == 0) s_last = gn_arrive_and_wait(arrive + (int64_t)n * GN_ARRIVE_STRIDE, (unsigned)split) == (unsigned)split - 1u;
+    for (int g = tid; g < G; g += bd) gn_st2(slot + 2 * (C + g), gs[2 * g], gs[2 * g + 1]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's stores are performed (sc1: written through) ...
+    __syncthreads();                                       // ... and so are every thread's, before thread 0 counts the workgroup in
+    unsigned* const ctl = arrive + (int64_t)n * GN_ARRIVE_STRIDE;      // [0] arrivals, [32] "the sample's group sums are in gsum" (another 128-B line)
+    if (tid == 0) s_last = __hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)split - 1u;
     __syncthreads();
-    float* gs = gsm + 2 * C;
-    for (int i = tid; i < 2 * G; i += bd) gs[i] = gn_ld(gsum + (int64_t)n * 2 * G + i);
-    if (s_last)                                            // the sample's channel sums into the layer's gradient: once per sample
-        for (int c = tid; c < C; c += bd) {
-            atomicAdd(dgamma + c, gn_ld(chsum + ((int64_t)n * C + c) * 2));
-            atomicAdd(dbeta + c, gn_ld(chsum + ((int64_t)n * C + c) * 2 + 1));
+    if (s_last) {
+        // the sample's LAST arriver adds up the slots (its own included): channel sums into the layer's gradient, group sums into gsum for everybody
+        for (int i = tid; i < 2 * P; i += bd) gsm[i] = 0.f;
+        __syncthreads();
+        const int SG = bd / P > 0 ? bd / P : 1;            // slice subsets walked side by side when there are fewer pairs than threads
+        for (int i = tid; i < P * SG; i += bd) {
+            const int pr = i % P, s0 = i / P;
+            float a0 = 0.f, a1 = 0.f;
+            int sidx = s0;
+            for (; sidx + 3 * SG < split; sidx += 4 * SG) {            // four loads in flight
+                float u[4], w[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) gn_ld2(slot0 + (int64_t)(sidx + k * SG) * 2 * P + 2 * pr, u[k], w[k]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    a0 += u[k];
+                    a1 += w[k];
+                }
+            }
+            for (; sidx < split; sidx += SG) {
+                float u, w;
+                gn_ld2(slot0 + (int64_t)sidx * 2 * P + 2 * pr, u, w);
+                a0 += u;
+                a1 += w;
+            }
+            atomicAdd(&gsm[2 * pr], a0);
+            atomicAdd(&gsm[2 * pr + 1], a1);
         }
+        __syncthreads();
+        for (int c = tid; c < C; c += bd) {
+            atomicAdd(dgamma + c, gsm[2 * c]);
+            atomicAdd(dbeta + c, gsm[2 * c + 1]);
+        }
+        for (int g = tid; g < G; g += bd) gn_st2(gsum + ((int64_t)n * G + g) * 2, gs[2 * g], gs[2 * g + 1]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(ctl + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        if (tid == 0)
+            while (__hip_atomic_load(ctl + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(24);
+        __syncthreads();
+        for (int g = tid; g < G; g += bd) gn_ld2(gsum + ((int64_t)n * G + g) * 2, gs[2 * g], gs[2 * g + 1]);
+    }
     __syncthreads();
     float mr[8], k2[8], k3[8];
 #pragma unroll
@@ -765,12 +823,20 @@ extern "C" int merlot_groupnorm_bwd(const void* dy, const void* y, const void* x
     return merlot_launch_status("merlot_groupnorm_bwd");
 }
 
-// One launch per direction (ABI v10): see gn_fwd_fused_kernel.  ws: merlot_groupnorm_fused_workspace_bytes(N, C, G) bytes, caller-owned, any content
-// (zeroed here, on the stream); stats / gsum as in the two-launch entries.
+// One launch per direction (ABI v10; the backward's slots ABI v11): see gn_fwd_fused_kernel.  ws: merlot_groupnorm_fused_workspace_bytes(N, C, G) bytes forward,
+// merlot_groupnorm_bwd_fused_workspace_bytes(N, H, W, C, G) backward; caller-owned, any content (control words zeroed here, on the stream); stats / gsum as in the two-launch entries.
 extern "C" int64_t merlot_groupnorm_fused_workspace_bytes(int N, int C, int G) {
     if (N <= 0 || C <= 0 || G <= 0) return 0;
-    const int64_t per_sample = 2 * (int64_t)(C > G ? C : G);
-    return 4 * (16 + gn_ws_arrive_words(N) + (int64_t)N * per_sample);
+    return 4 * (16 + gn_ws_arrive_words(N) + (int64_t)N * 2 * G);
+}
+
+// the backward's workspace: control words + one slot of (C + G) float pairs per (sample, slice); the slicing is the launch's own (GN_BWD_ITER positions per thread)
+constexpr int GN_BWD_ITER = 8;
+extern "C" int64_t merlot_groupnorm_bwd_fused_workspace_bytes(int N, int H, int W, int C, int G) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || G <= 0 || C % 8 != 0) return 0;
+    const int threads = gn_block_threads(C), pstep = threads / (C / 8);
+    const int64_t split = ((int64_t)H * W + GN_BWD_ITER * pstep - 1) / (GN_BWD_ITER * pstep);
+    return 4 * (16 + gn_ws_arrive_words(N) + (int64_t)N * split * 2 * (C + G));
 }
 
 extern "C" int merlot_groupnorm_fwd_fused(const void* x, const float* gamma, const float* beta, const void* res, void* y, float* stats,
@@ -813,20 +879,18 @@ extern "C" int merlot_groupnorm_bwd_fused(const void* dy, const void* y, const v
     CONV_CHECK_GEOM("merlot_groupnorm_bwd_fused");
     MERLOT_CHECK(dy && stats && gamma && dgamma && dbeta && gsum && dx && (!relu || y || beta) && G > 0 && C % G == 0 && C % 8 == 0 &&
                      C <= 2048 && G <= 1024, MERLOT_ESHAPE, "merlot_groupnorm_bwd_fused: bad arguments (relu needs y, or beta to recompute the mask from x)");
-    MERLOT_CHECK(ws && ws_bytes >= merlot_groupnorm_fused_workspace_bytes(N, C, G) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0, MERLOT_ESHAPE,
-                 "merlot_groupnorm_bwd_fused: workspace of merlot_groupnorm_fused_workspace_bytes(N, C, G) = %lld bytes required (got %lld)",
-                 (long long)merlot_groupnorm_fused_workspace_bytes(N, C, G), (long long)ws_bytes);
+    MERLOT_CHECK(ws && ws_bytes >= merlot_groupnorm_bwd_fused_workspace_bytes(N, H, W, C, G) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0, MERLOT_ESHAPE,
+                 "merlot_groupnorm_bwd_fused: workspace of merlot_groupnorm_bwd_fused_workspace_bytes(N, H, W, C, G) = %lld bytes required (got %lld)",
+                 (long long)merlot_groupnorm_bwd_fused_workspace_bytes(N, H, W, C, G), (long long)ws_bytes);
     MERLOT_CHECK(((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(dres)) & 15) == 0,
                  MERLOT_EALIGN, "merlot_groupnorm_bwd_fused: operands must be 16-B aligned");
     const int HW = H * W;
     const int threads = gn_block_threads(C);
     const int pstep = threads / (C / 8);
-    constexpr int ITER = 8;
+    constexpr int ITER = GN_BWD_ITER;
     const int split = (HW + ITER * pstep - 1) / (ITER * pstep);
     MERLOT_CHECK((int64_t)N * split < (1LL << 31), MERLOT_ESHAPE, "merlot_groupnorm_bwd_fused: too many slices");
-    hipError_t e = hipMemsetAsync(ws, 0, 4 * (16 + gn_ws_arrive_words(N) + (size_t)N * 2 * C), (hipStream_t)stream);
-    MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
-    e = hipMemsetAsync(gsum, 0, sizeof(float) * 2 * (size_t)N * G, (hipStream_t)stream);
+    hipError_t e = hipMemsetAsync(ws, 0, 4 * (16 + gn_ws_arrive_words(N)), (hipStream_t)stream);      // the control words; every slot and gsum entry is written before it is read
     MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
     const size_t lds = sizeof(float) * 2 * (C + G);
     const bool has_y = relu && y != nullptr;

@@ -793,8 +793,8 @@ def groupnorm_bwd(dy, y, x, stats, gamma, dgamma, dbeta, *, beta=None, relu=True
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
     gsum = torch.empty((N, groups, 2), device=x.device, dtype=F32)
-    if GN_FUSED is True:                                   # one launch, x | dy read once (ABI v10; slower than the two launches below on every measured shape)
-        ws = _gn_ws(x.device, N, C, groups)
+    if GN_FUSED is True:                                   # one launch, x | dy read once (per-slice slots in the workspace: ABI v11)
+        ws = torch.empty(LIB.query('merlot_groupnorm_bwd_fused_workspace_bytes', N, H, W, C, groups) // 4, device=x.device, dtype=torch.int32)
         call('merlot_groupnorm_bwd_fused', _p(dy), _p(y), _p(x), _p(stats), _p(gamma), _p(beta), _p(dgamma), _p(dbeta), _p(gsum), _p(dx),
              _p(dres), N, H, W, C, groups, float(eps), 1 if relu else 0, _p(ws), ws.numel() * 4, _stream())
         return dx, dres

@@ -70,7 +70,7 @@ def test_library_exports_every_declared_symbol():
     for name in lib.parse_header():
         assert hasattr(dll, name), f"{name} declared in include/merlot_hip.h but not exported"
     d = lib.LIB.load()
-    assert d.merlot_abi_version() == 10
+    assert d.merlot_abi_version() == 11
     assert d.merlot_last_error() is not None
 
 
