@@ -756,10 +756,10 @@ def col2im3x3(dpatches, N, H, W, C, stride=1):
     return dx
 
 
-# GroupNorm in one launch per direction (merlot_groupnorm_*_fused, ABI v10), measured per shape of the as-shipped stem at 896 frames (profiles/r06_z2_gn_fused_shapes.txt,
-# r06_z3_gn_fused_fwd.txt): the FORWARD wins on all thirteen shapes (-3 ... -50 %: x is read once) and the BACKWARD loses on all of them (x1.4 ... x15: four returning
-# device-scope atomics per channel and workgroup).  'fwd' (default) = one-launch forward, two-launch backward; True = both one-launch; False = both two-launch
-# (bench.py --gn-fused / --no-gn-fused).
+# GroupNorm in one launch per direction (merlot_groupnorm_*_fused, ABI v10 / v11), measured per shape of the as-shipped stem at 896 frames (profiles/r06_z3_gn_fused_fwd.txt,
+# r06_z4_gn_fused_fwd.txt, r06_z5_gn_fused_bwd.txt): the FORWARD wins on all thirteen shapes (-3 ... -50 %: x is read once); the BACKWARD loses on twelve of them (x1.15 ... x2.2
+# on per-slice slots, ABI v11; x1.4 ... x15 with its first version's returning atomics) and a call at 66 slices per sample has been seen to take seconds.
+# 'fwd' (default) = one-launch forward, two-launch backward; True = both one-launch (A/B only); False = both two-launch (bench.py --gn-fused / --no-gn-fused).
 GN_FUSED = 'fwd'
 
 
