@@ -768,13 +768,24 @@ def _gn_ws(device, N, C, groups):
     return torch.empty(LIB.query('merlot_groupnorm_fused_workspace_bytes', N, C, groups) // 4, device=device, dtype=torch.int32)
 
 
+def _gn_fused_slices(HW, C, res, bwd=False):
+    """slices per sample of the one-launch GroupNorm entries (csrc/conv.hip: 256-thread blocks, a thread holds 8 or 16 positions of 8 channels); they refuse more than 40."""
+    cpr = C // 8
+    threads = max(cpr, (256 // cpr) * cpr)
+    pstep = threads // cpr
+    s8 = -(-HW // (8 * pstep))
+    if bwd or (res and s8 <= 40):
+        return s8
+    return -(-HW // (16 * pstep))
+
+
 def groupnorm_fwd(x, gamma, beta, *, res=None, relu=True, groups=32, eps=1e-4):
     _chk(x, BF16, 'x'); _chk(gamma, F32, 'gamma'); _chk(beta, F32, 'beta'); _chk(res, BF16, 'res')
     N, H, W, C = x.shape
     assert x.is_contiguous() and (res is None or res.is_contiguous())
     y = torch.empty_like(x)
     stats = torch.empty((N, groups, 2), device=x.device, dtype=F32)
-    if GN_FUSED:                                           # one launch, x read once (ABI v10)
+    if GN_FUSED and _gn_fused_slices(H * W, C, res is not None) <= 40:      # one launch, x read once (ABI v10); above 40 slices per sample (unmeasured) two launches
         ws = _gn_ws(x.device, N, C, groups)
         call('merlot_groupnorm_fwd_fused', _p(x), _p(gamma), _p(beta), _p(res), _p(y), _p(stats), N, H, W, C, groups, float(eps),
              1 if relu else 0, _p(ws), ws.numel() * 4, _stream())
@@ -793,7 +804,7 @@ def groupnorm_bwd(dy, y, x, stats, gamma, dgamma, dbeta, *, beta=None, relu=True
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
     gsum = torch.empty((N, groups, 2), device=x.device, dtype=F32)
-    if GN_FUSED is True:                                   # one launch, x | dy read once (per-slice slots in the workspace: ABI v11)
+    if GN_FUSED is True and _gn_fused_slices(H * W, C, True, bwd=True) <= 40:      # one launch, x | dy read once (per-slice slots in the workspace: ABI v11); A/B only
         ws = torch.empty(LIB.query('merlot_groupnorm_bwd_fused_workspace_bytes', N, H, W, C, groups) // 4, device=x.device, dtype=torch.int32)
         call('merlot_groupnorm_bwd_fused', _p(dy), _p(y), _p(x), _p(stats), _p(gamma), _p(beta), _p(dgamma), _p(dbeta), _p(gsum), _p(dx),
              _p(dres), N, H, W, C, groups, float(eps), 1 if relu else 0, _p(ws), ws.numel() * 4, _stream())

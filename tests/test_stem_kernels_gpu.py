@@ -258,3 +258,26 @@ def test_groupnorm_one_launch_rejects_a_short_workspace(ops):
     with pytest.raises(MerlotHipError, match='workspace'):
         call('merlot_groupnorm_fwd_fused', x.data_ptr(), gam.data_ptr(), gam.data_ptr(), None, y.data_ptr(), stats.data_ptr(), 2, 4, 4, 64, 32, 1e-4, 1,
              ws.data_ptr(), ws.numel() * 4, None)
+
+
+def test_groupnorm_one_launch_refuses_more_slices_than_were_measured(ops):
+    """csrc/conv.hip GN_FUSED_MAX_SLICES = 40: the one-launch backward at 66 slices per sample had calls that never returned at 896 frames (profiles/r06_z6_gn_stress.txt); both
+    entries refuse such a shape, and ops.groupnorm_* takes the two-launch entries for it (same results as ever: test_groupnorm_forward_backward's 96 x 176 x 64 case)."""
+    from merlot_amd.lib import LIB, MerlotHipError, call
+    N, H, W, C = 1, 96, 176, 64                            # backward: 16 896 positions / (8 x 32 per slice) = 66 slices
+    assert ops._gn_fused_slices(H * W, C, False, bwd=True) == 66 and ops._gn_fused_slices(H * W, C, False) == 33
+    x = torch.zeros(N, H, W, C, dtype=BF16).cuda()
+    dx, stats, gsum = torch.empty_like(x), torch.zeros(N, 32, 2).cuda(), torch.empty(N, 32, 2).cuda()
+    gam, dga, dbe = torch.ones(C).cuda(), torch.zeros(C).cuda(), torch.zeros(C).cuda()
+    ws = torch.zeros(LIB.query('merlot_groupnorm_bwd_fused_workspace_bytes', N, H, W, C, 32) // 4, dtype=torch.int32).cuda()
+    with pytest.raises(MerlotHipError, match='slices per sample'):
+        call('merlot_groupnorm_bwd_fused', x.data_ptr(), None, x.data_ptr(), stats.data_ptr(), gam.data_ptr(), gam.data_ptr(), dga.data_ptr(), dbe.data_ptr(), gsum.data_ptr(),
+             dx.data_ptr(), None, N, H, W, C, 32, 1e-4, 1, ws.data_ptr(), ws.numel() * 4, None)
+    H2 = 4 * H                                             # forward: 67 584 positions / (16 x 32) = 132 slices
+    x2 = torch.zeros(N, H2, W, C, dtype=BF16).cuda()
+    ws2 = torch.zeros(LIB.query('merlot_groupnorm_fused_workspace_bytes', N, C, 32) // 4, dtype=torch.int32).cuda()
+    with pytest.raises(MerlotHipError, match='slices per sample'):
+        call('merlot_groupnorm_fwd_fused', x2.data_ptr(), gam.data_ptr(), gam.data_ptr(), None, torch.empty_like(x2).data_ptr(), stats.data_ptr(), N, H2, W, C, 32, 1e-4, 1,
+             ws2.data_ptr(), ws2.numel() * 4, None)
+    y, st = ops.groupnorm_fwd((torch.randn(N, H2, W, C, device='cuda') * 2).to(BF16), gam, dbe)     # the product's route for it: two launches, no error
+    assert torch.isfinite(y.float()).all() and torch.isfinite(st).all()
