@@ -833,6 +833,12 @@ extern "C" int64_t merlot_groupnorm_fused_workspace_bytes(int N, int C, int G) {
 // Slices per sample the one-launch entries accept.  Every as-shipped shape is <= 33 (forward, thousands of timed calls without an outlier: profiles/r06_z6_gn_stress.txt);
 // the BACKWARD at 66 slices has calls that never return (same file) and the cause was not found, so both entries refuse what was not measured to be safe.
 constexpr int GN_FUSED_MAX_SLICES = 40;
+static int gn_fused_max_slices() {
+#ifdef MERLOT_EXPERIMENTS
+    if (const char* e = getenv("MERLOT_GN_MAX_SLICES")) return atoi(e);       // scripts/exp_gn_slices.py: where the stall begins
+#endif
+    return GN_FUSED_MAX_SLICES;
+}
 // the backward's workspace: control words + one slot of (C + G) float pairs per (sample, slice); the slicing is the launch's own (GN_BWD_ITER positions per thread)
 constexpr int GN_BWD_ITER = 8;
 extern "C" int64_t merlot_groupnorm_bwd_fused_workspace_bytes(int N, int H, int W, int C, int G) {
@@ -856,11 +862,11 @@ extern "C" int merlot_groupnorm_fwd_fused(const void* x, const float* gamma, con
     const int HW = H * W;
     const int threads = gn_block_threads(C);
     const int pstep = threads / (C / 8);
-    const bool hold = res && (HW + 8 * pstep - 1) / (8 * pstep) <= 40;      // (see the kernel: the residual held across the wait, or read behind it)
+    const bool hold = res && (HW + 8 * pstep - 1) / (8 * pstep) <= gn_fused_max_slices();      // (see the kernel: the residual held across the wait, or read behind it)
     const int iter = hold ? 8 : 16;
     const int split = (HW + iter * pstep - 1) / (iter * pstep);
     MERLOT_CHECK((int64_t)N * split < (1LL << 31), MERLOT_ESHAPE, "merlot_groupnorm_fwd_fused: too many slices");
-    MERLOT_CHECK(split <= GN_FUSED_MAX_SLICES, MERLOT_ESHAPE, "merlot_groupnorm_fwd_fused: %d slices per sample (H * W = %d positions of %d channels); measured up to %d -- use merlot_groupnorm_fwd",
+    MERLOT_CHECK(split <= gn_fused_max_slices(), MERLOT_ESHAPE, "merlot_groupnorm_fwd_fused: %d slices per sample (H * W = %d positions of %d channels); measured up to %d -- use merlot_groupnorm_fwd",
                  split, HW, C, GN_FUSED_MAX_SLICES);
     hipError_t e = hipMemsetAsync(ws, 0, 4 * (16 + gn_ws_arrive_words(N) + (size_t)N * 2 * G), (hipStream_t)stream);
     MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
@@ -896,7 +902,7 @@ extern "C" int merlot_groupnorm_bwd_fused(const void* dy, const void* y, const v
     const int split = (HW + ITER * pstep - 1) / (ITER * pstep);
     MERLOT_CHECK((int64_t)N * split < (1LL << 31), MERLOT_ESHAPE, "merlot_groupnorm_bwd_fused: too many slices");
     // 66 slices per sample: calls that never return (profiles/r06_z6_gn_stress.txt; cause not found -- every shape up to 33 slices ran, thousands of calls forward)
-    MERLOT_CHECK(split <= GN_FUSED_MAX_SLICES, MERLOT_ESHAPE, "merlot_groupnorm_bwd_fused: %d slices per sample (H * W = %d positions of %d channels); this entry stalls above %d -- use merlot_groupnorm_bwd",
+    MERLOT_CHECK(split <= gn_fused_max_slices(), MERLOT_ESHAPE, "merlot_groupnorm_bwd_fused: %d slices per sample (H * W = %d positions of %d channels); this entry stalls above %d -- use merlot_groupnorm_bwd",
                  split, HW, C, GN_FUSED_MAX_SLICES);
     hipError_t e = hipMemsetAsync(ws, 0, 4 * (16 + gn_ws_arrive_words(N)), (hipStream_t)stream);      // the control words; every slot and gsum entry is written before it is read
     MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));

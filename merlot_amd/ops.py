@@ -761,6 +761,7 @@ def col2im3x3(dpatches, N, H, W, C, stride=1):
 # on per-slice slots, ABI v11; x1.4 ... x15 with its first version's returning atomics) and a call at 66 slices per sample has been seen to take seconds.
 # 'fwd' (default) = one-launch forward, two-launch backward; True = both one-launch (A/B only); False = both two-launch (bench.py --gn-fused / --no-gn-fused).
 GN_FUSED = 'fwd'
+GN_FUSED_MAX_SLICES = 40                                   # csrc/conv.hip: both one-launch entries refuse more slices per sample (see _gn_fused_slices)
 
 
 def _gn_ws(device, N, C, groups):
@@ -774,7 +775,7 @@ def _gn_fused_slices(HW, C, res, bwd=False):
     threads = max(cpr, (256 // cpr) * cpr)
     pstep = threads // cpr
     s8 = -(-HW // (8 * pstep))
-    if bwd or (res and s8 <= 40):
+    if bwd or (res and s8 <= GN_FUSED_MAX_SLICES):
         return s8
     return -(-HW // (16 * pstep))
 
@@ -785,7 +786,7 @@ def groupnorm_fwd(x, gamma, beta, *, res=None, relu=True, groups=32, eps=1e-4):
     assert x.is_contiguous() and (res is None or res.is_contiguous())
     y = torch.empty_like(x)
     stats = torch.empty((N, groups, 2), device=x.device, dtype=F32)
-    if GN_FUSED and _gn_fused_slices(H * W, C, res is not None) <= 40:      # one launch, x read once (ABI v10); above 40 slices per sample (unmeasured) two launches
+    if GN_FUSED and _gn_fused_slices(H * W, C, res is not None) <= GN_FUSED_MAX_SLICES:      # one launch, x read once (ABI v10); above 40 slices per sample (unmeasured) two launches
         ws = _gn_ws(x.device, N, C, groups)
         call('merlot_groupnorm_fwd_fused', _p(x), _p(gamma), _p(beta), _p(res), _p(y), _p(stats), N, H, W, C, groups, float(eps),
              1 if relu else 0, _p(ws), ws.numel() * 4, _stream())
@@ -804,7 +805,7 @@ def groupnorm_bwd(dy, y, x, stats, gamma, dgamma, dbeta, *, beta=None, relu=True
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
     gsum = torch.empty((N, groups, 2), device=x.device, dtype=F32)
-    if GN_FUSED is True and _gn_fused_slices(H * W, C, True, bwd=True) <= 40:      # one launch, x | dy read once (per-slice slots in the workspace: ABI v11); A/B only
+    if GN_FUSED is True and _gn_fused_slices(H * W, C, True, bwd=True) <= GN_FUSED_MAX_SLICES:      # one launch, x | dy read once (per-slice slots in the workspace: ABI v11); A/B only
         ws = torch.empty(LIB.query('merlot_groupnorm_bwd_fused_workspace_bytes', N, H, W, C, groups) // 4, device=x.device, dtype=torch.int32)
         call('merlot_groupnorm_bwd_fused', _p(dy), _p(y), _p(x), _p(stats), _p(gamma), _p(beta), _p(dgamma), _p(dbeta), _p(gsum), _p(dx),
              _p(dres), N, H, W, C, groups, float(eps), 1 if relu else 0, _p(ws), ws.numel() * 4, _stream())
