@@ -764,7 +764,11 @@ static int gn_group_samples(int N, int64_t bytes_per_sample, bool bwd) {
 }
 // slices per sample: enough blocks to fill the chip (>= ~2048) but no more: every block ends in atomics (2G forward, 4C in the backward)
 static int gn_split(int nb, int HW, int C, int threads) {
-    int split = (2048 + nb - 1) / nb;
+    int target = 2048;
+#ifdef MERLOT_EXPERIMENTS
+    if (const char* e = getenv("MERLOT_GN_BLOCKS")) target = atoi(e);       // scripts/exp_gn_blocks.py: blocks per launch of the two-launch entries
+#endif
+    int split = (target + nb - 1) / nb;
     const int max_split = (HW * (C / 8) + threads * 4 - 1) / (threads * 4);
     if (split > max_split) split = max_split;
     if (split > 64) split = 64;
