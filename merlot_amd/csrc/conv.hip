@@ -762,9 +762,13 @@ static int gn_group_samples(int N, int64_t bytes_per_sample, bool bwd) {
     if (nb < 1) nb = 1;
     return nb > N ? N : (int)nb;
 }
-// slices per sample: enough blocks to fill the chip (>= ~2048) but no more: every block ends in atomics (2G forward, 4C in the backward)
-static int gn_split(int nb, int HW, int C, int threads) {
-    int target = 2048;
+// Slices per sample = blocks per launch / samples.  Forward (2G trailing atomics per block): enough blocks to fill the chip, >= ~2048.  BACKWARD: every block ends in 4C
+// atomics on dgamma / dbeta / the group sums, and the sweep over the thirteen as-shipped shapes at 896 / 448 / 224 / 64 frames (scripts/exp_gn_blocks.py,
+// profiles/r06_z8_gn_blocks.txt, r06_z9_gn_blocks_n.txt) says FEWER blocks at every batch size: 3 slices per sample (the >= 2048 rule of rounds 3 - 6) -> 1 at 896 frames =
+// 47.4 -> 40.7 ms per step over the stem's 54 layers; at 64 frames 12.1 -> 5.5 ... 6.3 ms.  Rule: 512 blocks for samples of >= 1 MiB (they stream long enough to want two
+// rounds of the chip), 256 = one per CU otherwise.
+static int gn_split(int nb, int HW, int C, int threads, bool bwd = false) {
+    int target = !bwd ? 2048 : ((int64_t)HW * C >= 512 * 1024 ? 512 : 256);
 #ifdef MERLOT_EXPERIMENTS
     if (const char* e = getenv("MERLOT_GN_BLOCKS")) target = atoi(e);       // scripts/exp_gn_blocks.py: blocks per launch of the two-launch entries
 #endif
@@ -815,14 +819,24 @@ extern "C" int merlot_groupnorm_bwd(const void* dy, const void* y, const void* x
     MERLOT_CHECK(e == hipSuccess, MERLOT_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
     for (int n0 = 0; n0 < N; n0 += nb_max) {
         const int nb = N - n0 < nb_max ? N - n0 : nb_max;
-        const int split = gn_split(nb, HW, C, threads), ppb = (HW + split - 1) / split;
+        const int split = gn_split(nb, HW, C, threads, true), ppb = (HW + split - 1) / split;
+        int split2 = split;                                // the apply pass has no trailing atomics: its own slicing (profiles/r06_z10_gn_blocks_apply.txt)
+#ifdef MERLOT_EXPERIMENTS
+        if (const char* e2 = getenv("MERLOT_GN_BLOCKS_APPLY")) {
+            split2 = (atoi(e2) + nb - 1) / nb;
+            const int mx = (HW * (C / 8) + threads * 4 - 1) / (threads * 4);
+            split2 = split2 > mx ? mx : split2;
+            split2 = split2 > 64 ? 64 : (split2 < 1 ? 1 : split2);
+        }
+#endif
+        const int ppb2 = (HW + split2 - 1) / split2;
         const bf16 *dyg = (const bf16*)dy + n0 * per, *yg = y ? (const bf16*)y + n0 * per : nullptr, *xg = (const bf16*)x + n0 * per;
         const float* sg = stats + (int64_t)n0 * 2 * G;
         float* gg = gsum + (int64_t)n0 * 2 * G;
         hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(nb, split), dim3(threads), sizeof(float) * 2 * C, (hipStream_t)stream, dyg, yg, xg, sg,
                            gamma, beta, dgamma, dbeta, gg, HW, C, G, eps, relu, ppb);
-        hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nb, split), dim3(threads), 0, (hipStream_t)stream, dyg, yg, xg, sg, gg, gamma, beta,
-                           (bf16*)dx + n0 * per, dres ? (bf16*)dres + n0 * per : nullptr, HW, C, G, relu, ppb);
+        hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nb, split2), dim3(threads), 0, (hipStream_t)stream, dyg, yg, xg, sg, gg, gamma, beta,
+                           (bf16*)dx + n0 * per, dres ? (bf16*)dres + n0 * per : nullptr, HW, C, G, relu, ppb2);
     }
     return merlot_launch_status("merlot_groupnorm_bwd");
 }
