@@ -324,7 +324,15 @@ int ln_bwd_launch(int combo, const void* dy, const void* x, const float* mean, c
     const uint32_t thresh = (dx_drop && drop_p > 0.f) ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
     const float dscale = 1.0f / (1.0f - drop_p);
     int nblk = cdiv(rows, 4);
-    if (nblk > 2048) nblk = 2048;
+    // Every block ends in 2 - 3 atomics per column (1 536 - 2 304 per block): like the GroupNorm backward (csrc/conv.hip gn_split) this kernel wants FEW blocks, and whole
+    // multiples of the 256 CUs -- 2 048 blocks (rounds 1 - 6) against 512 / 256: ViT rows 468 -> 439 us, with the branch gradient's dropout and column sums 596 -> 556 (256 blocks),
+    // joint rows 203 -> 184 / 250 -> 228, text-only rows 102 -> 79 / 111 -> 94; 384 and 768 blocks (1.5 and 3 per CU: no, 1.5 and 3 rounds of an uneven chip) are 10 - 20 % WORSE than
+    // either neighbour, 128 blocks 70 % worse (profiles/r06_z11_ln_bwd_blocks.txt).
+    int cap = dcolsum ? 256 : 512;
+#ifdef MERLOT_EXPERIMENTS
+    if (const char* e = getenv("MERLOT_LN_BWD_BLOCKS")) cap = atoi(e);      // scripts/exp_ln_bwd_blocks.py: every block ends in 2 - 3 atomics per column
+#endif
+    if (nblk > cap) nblk = cap;
     const dim3 grid(nblk), block(256);
 #define LN_BWD(TDY, TX, TR, TDX)                                                                                      \
     hipLaunchKernelGGL((ln_bwd_kernel<NS, TDY, TX, TR, TDX>), grid, block, 0, s, (const TDY*)dy, (const TX*)x, mean,  \
