@@ -324,11 +324,10 @@ int ln_bwd_launch(int combo, const void* dy, const void* x, const float* mean, c
     const uint32_t thresh = (dx_drop && drop_p > 0.f) ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
     const float dscale = 1.0f / (1.0f - drop_p);
     int nblk = cdiv(rows, 4);
-    // Every block ends in 2 - 3 atomics per column (1 536 - 2 304 per block): like the GroupNorm backward (csrc/conv.hip gn_split) this kernel wants FEW blocks, and whole
-    // multiples of the 256 CUs -- 2 048 blocks (rounds 1 - 6) against 512 / 256: ViT rows 468 -> 439 us, with the branch gradient's dropout and column sums 596 -> 556 (256 blocks),
-    // joint rows 203 -> 184 / 250 -> 228, text-only rows 102 -> 79 / 111 -> 94; 384 and 768 blocks (1.5 and 3 per CU: no, 1.5 and 3 rounds of an uneven chip) are 10 - 20 % WORSE than
-    // either neighbour, 128 blocks 70 % worse (profiles/r06_z11_ln_bwd_blocks.txt).
-    int cap = dcolsum ? 256 : 512;
+    // Every block ends in 2 - 3 atomics per column.  Fewer blocks (512 / 256 = whole multiples of the CUs, as the GroupNorm backward's sweep suggested) are 5 - 22 % faster per
+    // launch in isolation (profiles/r06_z11_ln_bwd_blocks.txt: ViT rows 468 -> 439 us, text-only 102 -> 79) and 0.3 % SLOWER in the step (421.3 / 421.7 -> 422.6 / 423.4 ms,
+    // same box, mirrored: profiles/r06_z12_ln_bwd_cap_ab.txt) -- the cap stays.
+    int cap = 2048;
 #ifdef MERLOT_EXPERIMENTS
     if (const char* e = getenv("MERLOT_LN_BWD_BLOCKS")) cap = atoi(e);      // scripts/exp_ln_bwd_blocks.py: every block ends in 2 - 3 atomics per column
 #endif
