@@ -466,8 +466,9 @@ int merlot_groupnorm_bwd(const void* dy, const void* y, const void* x, const flo
  * The backward's workspace (ABI v11) is merlot_groupnorm_bwd_fused_workspace_bytes(N, H, W, C, G): besides the control blocks one slot of (C + G) float pairs per
  * (sample, slice) -- every workgroup STORES its slice's sums there and arrives with one atomic, the sample's last arriver adds the slots up (ABI v10's backward sent four
  * returning device-scope atomics per channel and workgroup: x1.4 ... x15 the time of merlot_groupnorm_bwd, profiles/r06_z2_gn_fused_shapes.txt).  MEASURED, v11
- * (profiles/r06_z5_gn_fused_bwd.txt): same gradients, x0.93 ... x2.2 the time of merlot_groupnorm_bwd (faster on one shape of thirteen), and at 66 slices per sample a call
- * has been seen to take SECONDS.  merlot_groupnorm_bwd_fused is exported for the A/B and value-tested; merlot_amd does not call it, and neither should a training loop.
+ * (profiles/r06_z5_gn_fused_bwd.txt): same gradients, x0.93 ... x2.2 the time of merlot_groupnorm_bwd (faster on one shape of thirteen), and above 64 slices per sample (its resident
+ * workgroups per XCD) calls stall or never return -- see csrc/conv.hip GN_FUSED_MAX_SLICES: both one-launch entries refuse more than 40 slices per sample (MERLOT_ESHAPE).
+ * merlot_groupnorm_bwd_fused is exported for the A/B and value-tested; merlot_amd does not call it.
  * Measured at the thirteen GroupNorm shapes of the as-shipped stem, 896 frames (profiles/r06_z3_gn_fused_fwd.txt, r06_z4_gn_fused_fwd.txt): the FORWARD is faster than
  * merlot_groupnorm_fwd on every shape (-3 ... -50 %) and is what merlot_amd runs. */
 int64_t merlot_groupnorm_fused_workspace_bytes(int N, int C, int G);

@@ -365,7 +365,7 @@ __device__ __forceinline__ void gn_ld2(const float* p, float& a, float& b) {
 __host__ __device__ constexpr int64_t gn_ws_arrive_words(int N) { return (int64_t)N * GN_ARRIVE_STRIDE; }
 
 template <int ITER, bool RES, bool HOLD = false>
-__global__ __launch_bounds__(256) void gn_fwd_fused_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256, 2) void gn_fwd_fused_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const bf16* __restrict__ res,
                                                            bf16* __restrict__ y, float* __restrict__ stats, unsigned* __restrict__ ws,
                                                            int N, int HW, int C, int G, int relu, int split, float inv_cnt, float eps) {
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256) void gn_fwd_fused_kernel(const bf16* __restric
 // backward in one launch: phase 1 = gn_bwd_stats_kernel's sums on the held slice (x, dy' kept as bf16: dy' is dy or 0), phase 2 = gn_bwd_apply_kernel's
 // expression.  HAS_Y: the ReLU mask from the stored output (layers with a residual add); otherwise recomputed from x (relu) or absent.
 template <int ITER, bool HAS_Y>
-__global__ __launch_bounds__(256) void gn_bwd_fused_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ y, const bf16* __restrict__ x,
+__global__ __launch_bounds__(256, 2) void gn_bwd_fused_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ y, const bf16* __restrict__ x,
                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                            float* __restrict__ gsum, bf16* __restrict__ dx, bf16* __restrict__ dres,
@@ -848,8 +848,16 @@ extern "C" int64_t merlot_groupnorm_fused_workspace_bytes(int N, int C, int G) {
     return 4 * (16 + gn_ws_arrive_words(N) + (int64_t)N * 2 * G);
 }
 
-// Slices per sample the one-launch entries accept.  Every as-shipped shape is <= 33 (forward, thousands of timed calls without an outlier: profiles/r06_z6_gn_stress.txt);
-// the BACKWARD at 66 slices has calls that never return (same file) and the cause was not found, so both entries refuse what was not measured to be safe.
+// Slices per sample the one-launch entries accept, and why there is a limit at all.  The wait of these kernels terminates if a free workgroup slot ANYWHERE on the chip gets the
+// next workgroup.  Measured (profiles/r06_z7_gn_slices.txt, r06_z6_gn_stress.txt): a kernel stops returning once a sample has more slices than the kernel has resident
+// workgroups PER XCD (backward, 2 per CU = 64 per XCD: 65 slices run, 70 hang; forward holding 8 positions, 3 per CU = 96: 90 run, 100 stalls for 21 s, 132 hang).  That is what
+// in-order round-robin dispatch with head-of-line blocking does: workgroups go to XCD (id mod 8) in id order, and a workgroup whose XCD is full holds up every later one.  The
+// slots a finished sample frees on one XCD are refilled in a burst, the burst claims consecutive items, so samples become XCD-local; a sample with more slices than the XCD has
+// slots fills it with waiters, the next workgroup in line is (within 8 ids) one for that XCD, and nothing starts any more -- the other XCDs drain and idle.  (Stalls that
+// resolve do so after ~20 s: something outside the kernel re-dispatches the waves.)  With S slices <= the per-XCD capacity C the same argument gives termination: a blocked
+// dispatcher means a full XCD; if the oldest unfinished sample still had unclaimed slices every resident workgroup would hold one of ITS slices, so C <= claimed < S.
+// Hence: both kernels are compiled for >= 2 workgroups per CU (__launch_bounds__(256, 2): C >= 64; tests/test_loop_isa.py checks the register counts) and both entries
+// refuse more than 40 slices.  Every as-shipped forward shape is <= 33; the forward default ran 3 900 individually timed calls without an outlier.
 constexpr int GN_FUSED_MAX_SLICES = 40;
 static int gn_fused_max_slices() {
 #ifdef MERLOT_EXPERIMENTS

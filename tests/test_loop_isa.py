@@ -145,3 +145,18 @@ def test_gemm_main_loops():
     body, vg = _kernel(lines, r'gemm_tn_p1_kernelILb0E')
     steady = [c for c in _loops(body, 32, inner_labels=True) if c['ds_read_b64_tr_b16'] == 48 and sum(c.values()) < 200]
     assert len(steady) == 1 and _valu(steady[0]) <= 6, steady
+
+
+def test_one_launch_groupnorm_kernels_keep_two_workgroups_per_cu():
+    """csrc/conv.hip (GN_FUSED_MAX_SLICES): the wait of the one-launch GroupNorm kernels terminates only while a sample has no more slices than the kernel has resident workgroups
+    per XCD (measured: profiles/r06_z7_gn_slices.txt).  The 40-slice guard leans on >= 2 workgroups per CU = 64 per XCD: every instantiation at <= 256 registers (256-thread
+    workgroups, 512 registers per SIMD lane), no scratch, LDS a few hundred bytes."""
+    text = '\n'.join(_compile('conv.hip'))
+    found = 0
+    for blk in text.split('- .agpr_count:')[1:]:
+        name = re.search(r'\.name:\s+(\S+)', blk).group(1)
+        if 'gn_fwd_fused_kernel' in name or 'gn_bwd_fused_kernel' in name:
+            found += 1
+            val = lambda k: int(re.search(r'\.%s:\s+(\d+)' % k, blk).group(1))      # noqa: E731
+            assert val('vgpr_count') <= 256 and val('private_segment_fixed_size') == 0 and val('group_segment_fixed_size') <= 64, (name, blk[:400])
+    assert found == 5, found                               # forward <8, res, hold>, <16, res>, <16>; backward with / without the stored output
