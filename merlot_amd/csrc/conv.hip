@@ -368,13 +368,14 @@ template <int ITER, bool RES, bool HOLD = false>
 __global__ __launch_bounds__(256, 2) void gn_fwd_fused_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const bf16* __restrict__ res,
                                                            bf16* __restrict__ y, float* __restrict__ stats, unsigned* __restrict__ ws,
-                                                           int N, int HW, int C, int G, int relu, int split, float inv_cnt, float eps) {
+                                                           int N, int HW, int C, int G, int relu, int split, float inv_cnt, float eps, int static_items) {
     extern __shared__ float gsm[];                         // [G][2] this slice's sums, then [G][2] {mean, rstd} of the sample
     __shared__ int s_item;
     unsigned* arrive = ws + 16;
     float* sums = reinterpret_cast<float*>(ws + 16 + gn_ws_arrive_words(N));
     const int tid = threadIdx.x, bd = blockDim.x;
-    if (tid == 0) s_item = (int)__hip_atomic_fetch_add(ws, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (static_items: experiments only -- item = workgroup id instead of a claim, scripts/exp_gn_slices.py: the test of the dispatch model in the GN_FUSED_MAX_SLICES comment)
+    if (tid == 0) s_item = static_items ? (int)blockIdx.x : (int)__hip_atomic_fetch_add(ws, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int i = tid; i < 2 * G; i += bd) gsm[i] = 0.f;
     __syncthreads();
     const int item = s_item, n = item / split, sl = item - n * split;
@@ -487,13 +488,14 @@ __global__ __launch_bounds__(256, 2) void gn_bwd_fused_kernel(const bf16* __rest
                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                            float* __restrict__ gsum, bf16* __restrict__ dx, bf16* __restrict__ dres,
-                                                           unsigned* __restrict__ ws, int N, int HW, int C, int G, int relu, int split) {
+                                                           unsigned* __restrict__ ws, int N, int HW, int C, int G, int relu, int split, int static_items) {
     extern __shared__ float gsm[];                         // [C][2] per-channel partials of this slice, then [G][2] the sample's gsum
     __shared__ int s_item, s_last;
     unsigned* arrive = ws + 16;
     float* slots = reinterpret_cast<float*>(ws + 16 + gn_ws_arrive_words(N));     // [N][split][C + G][2]
     const int tid = threadIdx.x, bd = blockDim.x;
-    if (tid == 0) s_item = (int)__hip_atomic_fetch_add(ws, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (static_items: experiments only -- item = workgroup id instead of a claim, scripts/exp_gn_slices.py: the test of the dispatch model in the GN_FUSED_MAX_SLICES comment)
+    if (tid == 0) s_item = static_items ? (int)blockIdx.x : (int)__hip_atomic_fetch_add(ws, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int i = tid; i < 2 * (C + G); i += bd) gsm[i] = 0.f;
     __syncthreads();
     const int item = s_item, n = item / split, sl = item - n * split;
@@ -859,6 +861,12 @@ extern "C" int64_t merlot_groupnorm_fused_workspace_bytes(int N, int C, int G) {
 // Hence: both kernels are compiled for >= 2 workgroups per CU (__launch_bounds__(256, 2): C >= 64; tests/test_loop_isa.py checks the register counts) and both entries
 // refuse more than 40 slices.  Every as-shipped forward shape is <= 33; the forward default ran 3 900 individually timed calls without an outlier.
 constexpr int GN_FUSED_MAX_SLICES = 40;
+static int gn_static_items() {
+#ifdef MERLOT_EXPERIMENTS
+    if (const char* e = getenv("MERLOT_GN_STATIC")) return atoi(e);
+#endif
+    return 0;
+}
 static int gn_fused_max_slices() {
 #ifdef MERLOT_EXPERIMENTS
     if (const char* e = getenv("MERLOT_GN_MAX_SLICES")) return atoi(e);       // scripts/exp_gn_slices.py: where the stall begins
@@ -900,13 +908,13 @@ extern "C" int merlot_groupnorm_fwd_fused(const void* x, const float* gamma, con
     const size_t lds = sizeof(float) * 4 * G;
     if (res && hold)
         hipLaunchKernelGGL((gn_fwd_fused_kernel<8, true, true>), dim3(N * split), dim3(threads), lds, (hipStream_t)stream, (const bf16*)x, gamma, beta,
-                           (const bf16*)res, (bf16*)y, stats, (unsigned*)ws, N, HW, C, G, relu, split, inv_cnt, eps);
+                           (const bf16*)res, (bf16*)y, stats, (unsigned*)ws, N, HW, C, G, relu, split, inv_cnt, eps, gn_static_items());
     else if (res)
         hipLaunchKernelGGL((gn_fwd_fused_kernel<16, true>), dim3(N * split), dim3(threads), lds, (hipStream_t)stream, (const bf16*)x, gamma, beta,
-                           (const bf16*)res, (bf16*)y, stats, (unsigned*)ws, N, HW, C, G, relu, split, inv_cnt, eps);
+                           (const bf16*)res, (bf16*)y, stats, (unsigned*)ws, N, HW, C, G, relu, split, inv_cnt, eps, gn_static_items());
     else
         hipLaunchKernelGGL((gn_fwd_fused_kernel<16, false>), dim3(N * split), dim3(threads), lds, (hipStream_t)stream, (const bf16*)x, gamma, beta,
-                           (const bf16*)nullptr, (bf16*)y, stats, (unsigned*)ws, N, HW, C, G, relu, split, inv_cnt, eps);
+                           (const bf16*)nullptr, (bf16*)y, stats, (unsigned*)ws, N, HW, C, G, relu, split, inv_cnt, eps, gn_static_items());
     return merlot_launch_status("merlot_groupnorm_fwd_fused");
 }
 
@@ -936,11 +944,11 @@ extern "C" int merlot_groupnorm_bwd_fused(const void* dy, const void* y, const v
     const bool has_y = relu && y != nullptr;
     if (has_y)
         hipLaunchKernelGGL((gn_bwd_fused_kernel<ITER, true>), dim3(N * split), dim3(threads), lds, (hipStream_t)stream, (const bf16*)dy, (const bf16*)y,
-                           (const bf16*)x, stats, gamma, beta, dgamma, dbeta, gsum, (bf16*)dx, (bf16*)dres, (unsigned*)ws, N, HW, C, G, relu, split);
+                           (const bf16*)x, stats, gamma, beta, dgamma, dbeta, gsum, (bf16*)dx, (bf16*)dres, (unsigned*)ws, N, HW, C, G, relu, split, gn_static_items());
     else
         hipLaunchKernelGGL((gn_bwd_fused_kernel<ITER, false>), dim3(N * split), dim3(threads), lds, (hipStream_t)stream, (const bf16*)dy,
                            (const bf16*)nullptr, (const bf16*)x, stats, gamma, beta, dgamma, dbeta, gsum, (bf16*)dx, (bf16*)dres, (unsigned*)ws, N,
-                           HW, C, G, relu, split);
+                           HW, C, G, relu, split, gn_static_items());
     return merlot_launch_status("merlot_groupnorm_bwd_fused");
 }
 
