@@ -858,6 +858,8 @@ extern "C" int64_t merlot_groupnorm_fused_workspace_bytes(int N, int C, int G) {
 // slots fills it with waiters, the next workgroup in line is (within 8 ids) one for that XCD, and nothing starts any more -- the other XCDs drain and idle.  (Stalls that
 // resolve do so after ~20 s: something outside the kernel re-dispatches the waves.)  With S slices <= the per-XCD capacity C the same argument gives termination: a blocked
 // dispatcher means a full XCD; if the oldest unfinished sample still had unclaimed slices every resident workgroup would hold one of ITS slices, so C <= claimed < S.
+// The model predicts that with item = workgroup id (no claims) the round-robin itself spreads a sample over the eight XCDs and the limit becomes 8 C: measured with
+// MERLOT_GN_STATIC=1 in the experiments build (profiles/r06_z13_gn_static.txt) -- the 64-per-XCD backward runs at 70 / 132 / 256 / 480 slices and hangs at 520 and 640.
 // Hence: both kernels are compiled for >= 2 workgroups per CU (__launch_bounds__(256, 2): C >= 64; tests/test_loop_isa.py checks the register counts) and both entries
 // refuse more than 40 slices.  Every as-shipped forward shape is <= 33; the forward default ran 3 900 individually timed calls without an outlier.
 constexpr int GN_FUSED_MAX_SLICES = 40;
