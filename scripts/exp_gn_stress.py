@@ -1,10 +1,14 @@
 """Round 6, call 42: does the one-launch GroupNorm FORWARD (the product default) ever take a call of seconds, as its backward did once at 66 slices per sample
 (profiles/r06_z5_gn_fused_bwd.txt)?  Every as-shipped shape at 896 frames, CALLS calls each timed on its own (events), median / max / calls above 3x the median.
 argv[1] = 'bwd <shape>': the same for the one-launch backward of one shape."""
+import os
 import sys
-import torch
 
 sys.path.insert(0, '.')
+if os.environ.get('MERLOT_GN_STATIC'):                    # the experiments build reads it (item = workgroup id instead of a claim)
+    sys.path.insert(0, 'scripts')
+    import _exp_lib  # noqa: F401
+import torch  # noqa: E402
 from merlot_amd import ops  # noqa: E402
 
 BF16 = torch.bfloat16
