@@ -325,8 +325,8 @@ int ln_bwd_launch(int combo, const void* dy, const void* x, const float* mean, c
     const float dscale = 1.0f / (1.0f - drop_p);
     int nblk = cdiv(rows, 4);
     // Every block ends in 2 - 3 atomics per column.  Fewer blocks (512 / 256 = whole multiples of the CUs, as the GroupNorm backward's sweep suggested) are 5 - 22 % faster per
-    // launch in isolation (profiles/r06_z11_ln_bwd_blocks.txt: ViT rows 468 -> 439 us, text-only 102 -> 79) and 0.3 % SLOWER in the step (421.3 / 421.7 -> 422.6 / 423.4 ms,
-    // same box, mirrored: profiles/r06_z12_ln_bwd_cap_ab.txt) -- the cap stays.
+    // launch in an isolated sweep (profiles/r06_z11_ln_bwd_blocks.txt) and LEVEL in the step: its main variant takes 294 - 296 us at either cap under rocprofv3, the step
+    // 426.5 / 426.6 ms at either (profiles/r06_z15_ln_bwd_in_step.txt; an earlier same-box pair read +0.3 %, r06_z12) -- the cap stays.
     int cap = 2048;
 #ifdef MERLOT_EXPERIMENTS
     if (const char* e = getenv("MERLOT_LN_BWD_BLOCKS")) cap = atoi(e);      // scripts/exp_ln_bwd_blocks.py: every block ends in 2 - 3 atomics per column
