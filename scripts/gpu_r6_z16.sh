@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 6, call 56: HBM-side traffic of the GroupNorm forward, two launches against one (TCC counters, one --pmc pass per counter with --kernel-trace only), shape 5 of the as-shipped stem
 # (48 x 88 x 128, 896 frames: x = y = 969 MB)
-export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out; cd /tmp
+export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out; cd $R
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_gn_$c
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_gn_$c -o g -- python $R/scripts/exp_gn_fused_fwd.py 5 > /tmp/pmc_gn_$c.log 2>&1
