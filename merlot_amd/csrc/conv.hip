@@ -212,6 +212,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16* __restrict__ 
 //   gsum[n][g] = {sum_c gamma_c * dbeta_c(n), sum_c gamma_c * dgamma_c(n)}   (per sample)
 // (relu with y == nullptr: the ReLU mask is recomputed from x -- y = (x - mean) * rstd * gamma + beta, the forward's own expression --
 // instead of reading the stored output: one tensor pass less in each of the two backward kernels; layers with a residual add pass y)
+template <int U>
 __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ y,
                                                            const bf16* __restrict__ x, const float* __restrict__ stats,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -237,19 +238,32 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const bf16* __restric
         if (from_x) gn_affine(mean[e], rstd[e], gamma[chunk * 8 + e], beta[chunk * 8 + e], gam[e], bet[e]);     // y = x * gam + bet
     }
     if (prow < pstep) {
-        for (int p = p0 + prow; p < p1; p += pstep) {
-            const int64_t off = ((int64_t)n * HW + p) * C + chunk * 8;
-            const bf16x8 d8 = *reinterpret_cast<const bf16x8*>(dy + off);
-            const bf16x8 x8 = *reinterpret_cast<const bf16x8*>(x + off);
-            bf16x8 y8;
-            if (relu && !from_x) y8 = *reinterpret_cast<const bf16x8*>(y + off);
+        // U positions per iteration, every load of the iteration issued before the first use (one block per sample since round 6: 14 waves per CU have to keep the
+        // memory pipe full on their own; profiles/r06_z18_gn_unroll.txt)
+        for (int pb = p0 + prow; pb < p1; pb += U * pstep) {
+            bf16x8 d8[U], x8[U], y8[U];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float d = (float)d8[e];
-                const float yv = from_x ? gn_y((float)x8[e], gam[e], bet[e]) : (float)y8[e];
-                if (relu && !gn_relu_passes(yv)) d = 0.f;
-                dg[e] += d * ((float)x8[e] - mean[e]) * rstd[e];
-                db[e] += d;
+            for (int u = 0; u < U; ++u) {
+                const int p = pb + u * pstep;
+                if (p < p1) {
+                    const int64_t off = ((int64_t)n * HW + p) * C + chunk * 8;
+                    d8[u] = *reinterpret_cast<const bf16x8*>(dy + off);
+                    x8[u] = *reinterpret_cast<const bf16x8*>(x + off);
+                    if (relu && !from_x) y8[u] = *reinterpret_cast<const bf16x8*>(y + off);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (pb + u * pstep < p1) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float d = (float)d8[u][e];
+                        const float yv = from_x ? gn_y((float)x8[u][e], gam[e], bet[e]) : (float)y8[u][e];
+                        if (relu && !gn_relu_passes(yv)) d = 0.f;
+                        dg[e] += d * ((float)x8[u][e] - mean[e]) * rstd[e];
+                        db[e] += d;
+                    }
+                }
             }
         }
     }
@@ -272,6 +286,7 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const bf16* __restric
 // backward, pass 2: dx = rstd * (dy' * gamma - gsum0 / cnt - xhat * gsum1 / cnt); optionally dres = dy' (residual branch).
 // Same indexing as gn_apply_kernel: per-thread constants k1 = rstd * gamma, k2 = rstd * gsum0 / cnt, k3 = rstd * gsum1 / cnt, and
 // xhat = x * rstd - mean * rstd.
+template <int U>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ y,
                                                            const bf16* __restrict__ x, const float* __restrict__ stats,
                                                            const float* __restrict__ gsum, const float* __restrict__ gamma,
@@ -298,24 +313,37 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const bf16* __restric
         k2[e] = rstd * gsum[((int64_t)n * G + g) * 2] * inv_cnt;
         k3[e] = rstd * gsum[((int64_t)n * G + g) * 2 + 1] * inv_cnt;
     }
-    for (int p = p0 + prow; p < p1; p += pstep) {
-        const int64_t off = ((int64_t)n * HW + p) * C + chunk * 8;
-        const bf16x8 d8 = *reinterpret_cast<const bf16x8*>(dy + off);
-        const bf16x8 x8 = *reinterpret_cast<const bf16x8*>(x + off);
-        bf16x8 y8;
-        if (relu && !from_x) y8 = *reinterpret_cast<const bf16x8*>(y + off);
-        bf16x8 o, r;
+    for (int pb = p0 + prow; pb < p1; pb += U * pstep) {     // (U positions per iteration, loads first: see gn_bwd_stats_kernel)
+        bf16x8 d8[U], x8[U], y8[U];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float d = (float)d8[e];
-            const float xhat = __builtin_fmaf((float)x8[e], rs[e], -mr[e]);
-            const float yv = from_x ? gn_y((float)x8[e], k1[e], bet[e]) : (float)y8[e];
-            if (relu && !gn_relu_passes(yv)) d = 0.f;
-            o[e] = (bf16)(d * k1[e] - k2[e] - xhat * k3[e]);
-            r[e] = (bf16)d;
+        for (int u = 0; u < U; ++u) {
+            const int p = pb + u * pstep;
+            if (p < p1) {
+                const int64_t off = ((int64_t)n * HW + p) * C + chunk * 8;
+                d8[u] = *reinterpret_cast<const bf16x8*>(dy + off);
+                x8[u] = *reinterpret_cast<const bf16x8*>(x + off);
+                if (relu && !from_x) y8[u] = *reinterpret_cast<const bf16x8*>(y + off);
+            }
         }
-        *reinterpret_cast<bf16x8*>(dx + off) = o;
-        if (dres) *reinterpret_cast<bf16x8*>(dres + off) = r;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int p = pb + u * pstep;
+            if (p < p1) {
+                const int64_t off = ((int64_t)n * HW + p) * C + chunk * 8;
+                bf16x8 o, r;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float d = (float)d8[u][e];
+                    const float xhat = __builtin_fmaf((float)x8[u][e], rs[e], -mr[e]);
+                    const float yv = from_x ? gn_y((float)x8[u][e], k1[e], bet[e]) : (float)y8[u][e];
+                    if (relu && !gn_relu_passes(yv)) d = 0.f;
+                    o[e] = (bf16)(d * k1[e] - k2[e] - xhat * k3[e]);
+                    r[e] = (bf16)d;
+                }
+                *reinterpret_cast<bf16x8*>(dx + off) = o;
+                if (dres) *reinterpret_cast<bf16x8*>(dres + off) = r;
+            }
+        }
     }
 }
 
@@ -764,6 +792,13 @@ static int gn_group_samples(int N, int64_t bytes_per_sample, bool bwd) {
     if (nb < 1) nb = 1;
     return nb > N ? N : (int)nb;
 }
+constexpr int GN_BWD_UNROLL = 1;                          // positions per loop iteration of the two-launch backward (sweep: profiles/r06_z18_gn_unroll.txt)
+static int gn_bwd_unroll() {
+#ifdef MERLOT_EXPERIMENTS
+    if (const char* e = getenv("MERLOT_GN_UNROLL")) return atoi(e);
+#endif
+    return GN_BWD_UNROLL;
+}
 // Slices per sample = blocks per launch / samples.  Forward (2G trailing atomics per block): enough blocks to fill the chip, >= ~2048.  BACKWARD: every block ends in 4C
 // atomics on dgamma / dbeta / the group sums, and the sweep over the thirteen as-shipped shapes at 896 / 448 / 224 / 64 frames (scripts/exp_gn_blocks.py,
 // profiles/r06_z8_gn_blocks.txt, r06_z9_gn_blocks_n.txt) says FEWER blocks at every batch size: 3 slices per sample (the >= 2048 rule of rounds 3 - 6) -> 1 at 896 frames =
@@ -835,10 +870,17 @@ extern "C" int merlot_groupnorm_bwd(const void* dy, const void* y, const void* x
         const bf16 *dyg = (const bf16*)dy + n0 * per, *yg = y ? (const bf16*)y + n0 * per : nullptr, *xg = (const bf16*)x + n0 * per;
         const float* sg = stats + (int64_t)n0 * 2 * G;
         float* gg = gsum + (int64_t)n0 * 2 * G;
-        hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(nb, split), dim3(threads), sizeof(float) * 2 * C, (hipStream_t)stream, dyg, yg, xg, sg,
-                           gamma, beta, dgamma, dbeta, gg, HW, C, G, eps, relu, ppb);
-        hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nb, split2), dim3(threads), 0, (hipStream_t)stream, dyg, yg, xg, sg, gg, gamma, beta,
-                           (bf16*)dx + n0 * per, dres ? (bf16*)dres + n0 * per : nullptr, HW, C, G, relu, ppb2);
+#define GN_BWD_LAUNCH(U)                                                                                                                             \
+    hipLaunchKernelGGL(gn_bwd_stats_kernel<U>, dim3(nb, split), dim3(threads), sizeof(float) * 2 * C, (hipStream_t)stream, dyg, yg, xg, sg, gamma,     \
+                       beta, dgamma, dbeta, gg, HW, C, G, eps, relu, ppb);                                                                             \
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<U>, dim3(nb, split2), dim3(threads), 0, (hipStream_t)stream, dyg, yg, xg, sg, gg, gamma, beta,              \
+                       (bf16*)dx + n0 * per, dres ? (bf16*)dres + n0 * per : nullptr, HW, C, G, relu, ppb2)
+        switch (gn_bwd_unroll()) {
+            case 4: GN_BWD_LAUNCH(4); break;
+            case 2: GN_BWD_LAUNCH(2); break;
+            default: GN_BWD_LAUNCH(1); break;
+        }
+#undef GN_BWD_LAUNCH
     }
     return merlot_launch_status("merlot_groupnorm_bwd");
 }
