@@ -47,7 +47,8 @@ for H, W, C, relu, res, cnt in SHAPES:
             dx, _ = ops.groupnorm_bwd(dy, yy, x, stats, gamma, dga, dbe, beta=beta, relu=relu, want_dres=res)
             if ref is None:
                 ref = dx.clone()
-            assert torch.equal(dx, ref), ('dx differs', u)       # same arithmetic per element
+            err = float((dx.float() - ref.float()).norm() / ref.float().norm())      # (the sums pass adds with atomics: last bits move between any two runs)
+            assert err < 1e-3, ('dx differs', u, err)
             best[u] = min(best[u], timed(lambda: ops.groupnorm_bwd(dy, yy, x, stats, gamma, dga, dbe, beta=beta, relu=relu, want_dres=res)))
     for u in US:
         tot[u] += best[u] * cnt
