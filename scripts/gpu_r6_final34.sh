@@ -3,7 +3,7 @@
 # the whole GPU suite + smoke, the default bench line (CPU baseline included), the driver's own command line, rocprofv3 kernel statistics of the bench command, the TCC traffic
 # passes (hash-stamped for the current sources), the SQ counter pass, the stem / native-yaml lines with the native-yaml kernel statistics, config #5 (all-bf16 and the default)
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-export TAG=${TAG:-r06_final6}
+export TAG=${TAG:-r06_final7}
 timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | grep -v Warning | grep "passed\|failed\|FAILED\|Error" | head -5 > gpurun_out/${TAG}_pytest_gpu.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 >> gpurun_out/${TAG}_pytest_gpu.txt
 cat gpurun_out/${TAG}_pytest_gpu.txt
